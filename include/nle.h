@@ -1,0 +1,175 @@
+/*
+ * nle.h -- C ABI of the MI355X-native nonlocal-filter hot path.
+ *
+ * This is the drop-in boundary for the path `src/filter.cpp` of
+ * lightalchemist/nonlocal-image-edit names (computeKernel -> nystromApproximation ->
+ * sinkhorn -> orthogonalize -> P*V, then NLEFilter::apply).  The reference has no FFI
+ * of its own (it is one C++ translation unit calling Eigen/OpenCV); the symbols below
+ * are what a binding for this path binds, and `include/nle/filter.hpp` is the C++
+ * surface with the reference's own names layered over them.  Each entry point cites
+ * the reference interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (0 == NLE_OK);
+ *     the message for the last failure is `nle_last_error(ctx)`.
+ *   - "d_" pointers are DEVICE (HIP) pointers, "h_" pointers are HOST pointers.
+ *   - N-sized matrices are fp32, ROW-PER-PIXEL (row-major, leading dimension `ld`,
+ *     a multiple of 4; columns >= the logical width are zero), in NATURAL pixel order
+ *     (row-major image scan), not the reference's [selected; rest] order.
+ *   - small (p x p, r x r, r- and K-sized) quantities are fp64 on the host, matrices
+ *     COLUMN-MAJOR like the reference's Eigen::MatrixXd (include/filter.hpp:10-12).
+ *   - all device work is stream-ordered on the ctx's stream; a ctx is used by one
+ *     host thread at a time (the reference is single-threaded and keeps no globals).
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails
+ *     with NLE_ERR_HIP.
+ */
+#ifndef NLE_H
+#define NLE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NLE_OK 0
+#define NLE_ERR_INVALID 1  /* bad argument / shape; message mirrors the reference's runtime_error text */
+#define NLE_ERR_HIP 2      /* HIP runtime failure (incl. no device) */
+#define NLE_ERR_NUMERIC 3  /* eigensolver did not converge / empty spectrum */
+#define NLE_ERR_COMM 4     /* all-reduce callback failed */
+
+#define NLE_EPS 1e-10 /* include/filter.hpp:14 */
+
+typedef struct nle_ctx nle_ctx;
+typedef struct nle_filter nle_filter;
+
+/* ---- context ------------------------------------------------------------------- */
+/* `stream` is a hipStream_t to run on (e.g. torch.cuda.current_stream().cuda_stream),
+ * or NULL to let the ctx create and own one. */
+int nle_ctx_create(int device, void* stream, nle_ctx** out);
+void nle_ctx_destroy(nle_ctx* ctx);
+const char* nle_last_error(const nle_ctx* ctx); /* ctx may be NULL: last create error */
+int nle_ctx_synchronize(nle_ctx* ctx);
+
+/* Multi-GPU (one process per GPU).  Rank `rank` of `world` owns image rows
+ * [rank*H/world, (rank+1)*H/world).  `allreduce(user, d_buf, count)` must sum, in place
+ * and stream-ordered with the ctx's stream, `count` doubles at DEVICE pointer d_buf over
+ * all ranks (torch.distributed / RCCL all_reduce on that stream).  `d_comm` is a device
+ * buffer of `comm_len` doubles owned by the caller, comm_len >= nle_comm_len(p).
+ * world == 1 (default) needs no callback.  New in this build (the reference is
+ * single-process). */
+typedef int (*nle_allreduce_fn)(void* user, void* d_buf, size_t count);
+int nle_ctx_set_shard(nle_ctx* ctx, int rank, int world, nle_allreduce_fn allreduce,
+                      void* user, double* d_comm, size_t comm_len);
+size_t nle_comm_len(int n_samples);
+
+/* ---- host-only helpers (no GPU needed) ----------------------------------------- */
+/* samplePixels, src/filter.cpp:56-80, in closed form: the selected set is
+ * {row_off + i*row_step, i < n_sel_rows} x {col_off + j*col_step, j < n_sel_cols}. */
+int nle_sample_grid(int H, int W, int n_row_samples, int n_col_samples, int* row_step,
+                    int* row_off, int* n_sel_rows, int* col_step, int* col_off,
+                    int* n_sel_cols);
+/* rows [*row0, *row1) owned by `rank` of `world` */
+int nle_slab_rows(int H, int rank, int world, int* row0, int* row1);
+/* eigenDecomposition, src/filter.cpp:204-228 (decl include/filter.hpp:23-24): symmetric
+ * n x n (col-major, LOWER triangle read), eigenvalues DESCENDING, leading run >= eps kept.
+ * h_U: n x n col-major (first *r columns valid), h_D: n (first *r valid). */
+int nle_eigen_decomposition(const double* h_M, int n, double eps, double* h_U, double* h_D,
+                            int* r);
+/* transformEigenValues, src/filter.cpp:334-347 */
+int nle_transform_eigenvalues(const double* h_eigvals, int K, const double* h_weights, int L,
+                              double* h_fS);
+/* per-layer spectral responses implied by :334-347: h_resp[l*K + k] */
+int nle_layer_responses(const double* h_eigvals, int K, int L, double* h_resp);
+
+/* ---- stage-level entry points (unit parity; all sizes generic) ------------------- */
+/* computeKernel, src/filter.cpp:114-167 (decl include/filter.hpp:20-21), for this rank's
+ * slab.  d_lum: FULL H x W luminance plane (fp32).  Outputs: h_Ka (p x p col-major fp64,
+ * may be NULL), d_kab: n_local x ld fp32 affinity rows k_i[s] = exp(negDist(pixel i,
+ * sample s)) for EVERY local pixel in natural order (sample pixels included: their rows
+ * are rows of Ka).  ld = nle_ld(p).  The permutation `P` (:156-164) is implicit:
+ * nle_sample_grid gives it in closed form. */
+int nle_compute_kernel(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples,
+                       int n_col_samples, double hx, double hy, double* h_Ka, float* d_kab);
+/* nystromApproximation, src/filter.cpp:257-280 (decl include/filter.hpp:26-27), fused with
+ * the affinity evaluation (K_AB is never written): h_eigvals[r], d_phi n_local x nle_ld(r)
+ * (allocated by the caller for r = p, i.e. n_local * nle_ld(p) floats). */
+int nle_nystrom(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples,
+                int n_col_samples, double hx, double hy, double* h_eigvals, int* r,
+                float* d_phi);
+/* Generic tall-skinny product of :275 for caller-supplied matrices:
+ * d_C (M x nle_ld(nc)) = d_A (M x lda, logical width kd) * h_B (kd x nc col-major fp64). */
+int nle_ts_gemm(nle_ctx* ctx, const float* d_A, long long M, int lda, int kd,
+                const double* h_B, int nc, float* d_C);
+/* sinkhorn iterations, src/filter.cpp:238-245 (decl include/filter.hpp:29-30), on a
+ * device-resident phi (M x ld, logical width r): returns the two r-vectors
+ * u_c = lambda o Phi^T r_{T-1}, u_r = lambda o Phi^T c_T that define the final scalings
+ * c_i = recip(phi_i . u_c), r_i = recip(phi_i . u_r).  max_iter >= 1. */
+int nle_sinkhorn_scalings(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r,
+                          const double* h_eigvals, int max_iter, double* h_u_c,
+                          double* h_u_r);
+/* Gram matrix of the scaled rows, the N-sized half of `Wab*Wab^T` (src/filter.cpp:296):
+ * h_G (r x r col-major) = sum_i c_i^2 phi_i phi_i^T, c_i = recip(phi_i . h_u) (all rows). */
+int nle_gram(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r, const double* h_u,
+             double* h_G);
+/* per-row scalings c_i = recip(phi_i . h_u) (inplaceReciprocal, src/filter.cpp:42-54) */
+int nle_row_scalings(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r,
+                     const double* h_u, double* d_out);
+
+/* ---- the fused path ---------------------------------------------------------------- */
+/* NLEFilter::trainFilter, src/filter.cpp:480-502.  d_lum: FULL H x W fp32 luminance on the
+ * device.  The filter keeps V (n_local x ld(K') fp32, pixel order) and eigvals on the
+ * device/host: the reference's m_eigvecs / m_eigvals (include/filter.hpp:52-53).
+ * Errors: n_row_samples > H or n_col_samples > W -> NLE_ERR_INVALID with the reference's
+ * message (:117-119). */
+int nle_train(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples,
+              int n_col_samples, double hx, double hy, int n_sinkhorn_iter,
+              int n_eigen_vectors, nle_filter** out);
+/* same, luminance plane in HOST memory (what NLEFilter::trainFilter is handed) */
+int nle_train_host(nle_ctx* ctx, const float* h_lum, int H, int W, int n_row_samples,
+                   int n_col_samples, double hx, double hy, int n_sinkhorn_iter,
+                   int n_eigen_vectors, nle_filter** out);
+void nle_filter_destroy(nle_filter* f);
+/* any out pointer may be NULL.  n_local = pixels of this rank's slab, K = kept eigenpairs
+ * (K' of src/filter.cpp:314), r = retained rank of Ka, p = realised sample count. */
+int nle_filter_info(const nle_filter* f, long long* n_local, int* K, int* r, int* p,
+                    int* row0, int* row1);
+int nle_filter_eigvals(const nle_filter* f, double* h_eigvals /* K */);
+/* device pointer + leading dimension of V (n_local x ld), for inspection */
+int nle_filter_eigvecs(const nle_filter* f, const float** d_V, int* ld);
+/* copy V (n_local x ld floats) into a caller-owned DEVICE buffer */
+int nle_filter_copy_eigvecs(const nle_filter* f, float* d_out);
+/* per-stage milliseconds of the last train (HIP events): affinity+nystrom, sinkhorn, gram,
+ * project, host eigensolves, total; h_ms[6] */
+int nle_filter_timings(const nle_filter* f, double* h_ms);
+
+/* NLEFilter::apply, src/filter.cpp:445-458: y = V diag(fS) V^T x for this rank's slab.
+ * d_x: FULL H x W fp32 channel on the device; d_y: n_local fp32.  Size mismatch with the
+ * training image -> NLE_ERR_INVALID (:447-449). */
+int nle_apply(nle_filter* f, const float* d_x, int H, int W, const double* h_fS, float* d_y);
+/* the L per-layer outputs y_l = V ((lambda^l - lambda^(l+1)) o V^T x), base layer
+ * lambda^(L-1) (src/filter.cpp:334-347); d_y: L x n_local fp32 (layer-major). */
+int nle_apply_layers(nle_filter* f, const float* d_x, int H, int W, int L, float* d_y);
+/* host-buffer forms */
+int nle_apply_host(nle_filter* f, const float* h_x, int H, int W, const double* h_fS,
+                   float* h_y);
+int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, float* h_y);
+
+/* leading dimension used for a logical width n: (n + 3) & ~3 */
+int nle_ld(int n);
+
+/* ---- measurement hooks (bench.py) --------------------------------------------------- */
+/* Run `reps` launches of the materialising affinity kernel (the HBM-roofline pass of
+ * computeKernel) and return the average launch duration in ms, measured with HIP events on
+ * the ctx's stream. */
+int nle_bench_affinity(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples,
+                       int n_col_samples, double hx, double hy, float* d_kab, int reps,
+                       double* h_avg_ms);
+/* same for one Sinkhorn half-iteration pass over a device-resident phi */
+int nle_bench_sinkhorn_pass(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r,
+                            int reps, double* h_avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLE_H */

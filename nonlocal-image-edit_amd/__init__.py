@@ -1,0 +1,414 @@
+"""Python mirror of the C ABI in include/nle.h (ctypes; no compute happens in Python).
+
+The product is `lib/libnle_hip.so` (HIP kernels for gfx950 + host pipeline).  This module
+only binds it for tests and `bench.py`, using torch tensors as device memory and the
+torch current stream as the HIP stream -- plumbing, not the product.  There is no CPU
+fallback: every compute call needs the shared library and a HIP device and raises
+otherwise.  Nothing here imports `oracle/`.
+
+Names follow the reference (`include/filter.hpp:20-54`): `NLEFilter.train_filter`
+<-> `NLEFilter::trainFilter`, `.apply` <-> `::apply`, `transform_eigenvalues`
+<-> `transformEigenValues`, `eigen_decomposition` <-> `eigenDecomposition`, ...
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnle_hip.so")
+
+NLE_OK, NLE_ERR_INVALID, NLE_ERR_HIP, NLE_ERR_NUMERIC, NLE_ERR_COMM = 0, 1, 2, 3, 4
+EPS = 1e-10
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+
+# every symbol include/nle.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_SIGNATURES = {
+    "nle_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    "nle_ctx_destroy": (None, [_P]),
+    "nle_last_error": (C.c_char_p, [_P]),
+    "nle_ctx_synchronize": (C.c_int, [_P]),
+    "nle_ctx_set_shard": (C.c_int, [_P, C.c_int, C.c_int, ALLREDUCE_FN, _P, _P, C.c_size_t]),
+    "nle_comm_len": (C.c_size_t, [C.c_int]),
+    "nle_sample_grid": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int)] * 6),
+    "nle_slab_rows": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_int)] * 2),
+    "nle_eigen_decomposition": (C.c_int, [_P, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),
+    "nle_transform_eigenvalues": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
+    "nle_layer_responses": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "nle_compute_kernel": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P]),
+    "nle_nystrom": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P,
+                              C.POINTER(C.c_int), _P]),
+    "nle_ts_gemm": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "nle_sinkhorn_scalings": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
+    "nle_gram": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, _P]),
+    "nle_row_scalings": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, _P]),
+    "nle_train": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                            C.POINTER(_P)]),
+    "nle_train_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                 C.c_int, C.POINTER(_P)]),
+    "nle_filter_destroy": (None, [_P]),
+    "nle_filter_info": (C.c_int, [_P, C.POINTER(C.c_longlong)] + [C.POINTER(C.c_int)] * 5),
+    "nle_filter_eigvals": (C.c_int, [_P, _P]),
+    "nle_filter_eigvecs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int)]),
+    "nle_filter_copy_eigvecs": (C.c_int, [_P, _P]),
+    "nle_filter_timings": (C.c_int, [_P, _P]),
+    "nle_apply": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "nle_apply_layers": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "nle_apply_host": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "nle_apply_layers_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "nle_ld": (C.c_int, [C.c_int]),
+    "nle_bench_affinity": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P, C.c_int,
+                                     C.POINTER(C.c_double)]),
+    "nle_bench_sinkhorn_pass": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class NLEError(RuntimeError):
+    """Non-zero status from the C ABI (the C++ surface maps these to std::runtime_error)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+
+
+def lib() -> C.CDLL:
+    """Load libnle_hip.so (built by build.py).  Fails loudly if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: run `python nonlocal-image-edit_amd/build.py` "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _check(status: int, ctx=None):
+    if status != NLE_OK:
+        msg = lib().nle_last_error(ctx)
+        raise NLEError(status, (msg or b"").decode() or f"nle status {status}")
+
+
+# ------------------------------------------------------------------ host-only helpers
+def ld(n: int) -> int:
+    return int(lib().nle_ld(int(n)))
+
+
+def sample_grid(H, W, n_row_samples, n_col_samples):
+    """`samplePixels` (src/filter.cpp:56-80) in closed form.
+    Returns dict(row_step,row_off,n_sel_rows,col_step,col_off,n_sel_cols)."""
+    out = [C.c_int() for _ in range(6)]
+    st = lib().nle_sample_grid(H, W, n_row_samples, n_col_samples, *[C.byref(o) for o in out])
+    if st != NLE_OK:
+        raise NLEError(st, "Number of samples per row and col must be <= that of image.")
+    keys = ("row_step", "row_off", "n_sel_rows", "col_step", "col_off", "n_sel_cols")
+    return dict(zip(keys, (o.value for o in out)))
+
+
+def slab_rows(H, rank, world):
+    r0, r1 = C.c_int(), C.c_int()
+    st = lib().nle_slab_rows(H, rank, world, C.byref(r0), C.byref(r1))
+    if st != NLE_OK:
+        raise NLEError(st, "bad slab arguments")
+    return r0.value, r1.value
+
+
+def eigen_decomposition(M: np.ndarray, eps: float = EPS):
+    """`eigenDecomposition` (src/filter.cpp:204-228): returns (U, D), descending, cut at eps."""
+    M = np.asfortranarray(np.asarray(M, dtype=np.float64))
+    n = M.shape[0]
+    if M.ndim != 2 or M.shape[1] != n or n == 0:
+        raise NLEError(NLE_ERR_INVALID, "eigen_decomposition needs a non-empty square matrix")
+    U = np.zeros((n, n), dtype=np.float64, order="F")
+    D = np.zeros(n, dtype=np.float64)
+    r = C.c_int()
+    st = lib().nle_eigen_decomposition(_np_ptr(M), n, float(eps), _np_ptr(U), _np_ptr(D), C.byref(r))
+    if st != NLE_OK:
+        raise NLEError(st, "eigensolver did not converge")
+    return np.ascontiguousarray(U[:, :r.value]), D[:r.value].copy()
+
+
+def transform_eigenvalues(eigvals, weights):
+    """`transformEigenValues` (src/filter.cpp:334-347)."""
+    ev = np.ascontiguousarray(eigvals, dtype=np.float64)
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    out = np.zeros_like(ev)
+    st = lib().nle_transform_eigenvalues(_np_ptr(ev), ev.size, _np_ptr(w), w.size, _np_ptr(out))
+    if st != NLE_OK:
+        raise NLEError(st, "bad arguments")
+    return out
+
+
+def layer_responses(eigvals, n_layers):
+    ev = np.ascontiguousarray(eigvals, dtype=np.float64)
+    out = np.zeros((n_layers, ev.size), dtype=np.float64)
+    st = lib().nle_layer_responses(_np_ptr(ev), ev.size, n_layers, _np_ptr(out))
+    if st != NLE_OK:
+        raise NLEError(st, "bad arguments")
+    return out
+
+
+# ------------------------------------------------------------------ device side
+def _torch():
+    import torch
+    return torch
+
+
+class Context:
+    """`nle_ctx`: one per process/GPU.  Uses torch's current stream on `device`."""
+
+    def __init__(self, device: int = 0, rank: int = 0, world: int = 1, allreduce=None):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device: nonlocal-image-edit_amd has no CPU fallback")
+        self.device = int(device)
+        torch.cuda.set_device(self.device)
+        self._h = C.c_void_p()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        st = lib().nle_ctx_create(self.device, C.c_void_p(stream), C.byref(self._h))
+        if st != NLE_OK:
+            raise NLEError(st, (lib().nle_last_error(None) or b"").decode())
+        self.rank, self.world = rank, world
+        self._cb = None
+        self._comm = None
+        self._allreduce = allreduce
+
+    def set_shard(self, rank: int, world: int, n_samples: int, allreduce):
+        """`allreduce(tensor)` sums a float64 CUDA tensor in place over all ranks (e.g.
+        torch.distributed.all_reduce)."""
+        torch = _torch()
+        n = int(lib().nle_comm_len(int(n_samples)))
+        self._comm = torch.zeros(n, dtype=torch.float64, device=f"cuda:{self.device}")
+        comm = self._comm
+        base = comm.data_ptr()
+
+        def _cb(user, d_buf, count):
+            try:
+                off = (int(d_buf) - base) // 8
+                allreduce(comm[off:off + int(count)])
+                return 0
+            except Exception as e:  # noqa: BLE001 - must not propagate through C
+                print("nle allreduce callback failed:", repr(e), flush=True)
+                return 1
+
+        self._cb = ALLREDUCE_FN(_cb)
+        _check(lib().nle_ctx_set_shard(self._h, rank, world, self._cb, None, C.c_void_p(base), n), self._h)
+        self.rank, self.world = rank, world
+
+    def synchronize(self):
+        _check(lib().nle_ctx_synchronize(self._h), self._h)
+
+    def close(self):
+        if self._h:
+            lib().nle_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ---- stage-level entry points (device tensors in/out) ----
+    def _lum(self, lum):
+        torch = _torch()
+        t = torch.as_tensor(lum, dtype=torch.float32, device=f"cuda:{self.device}").contiguous()
+        if t.ndim != 2:
+            raise NLEError(NLE_ERR_INVALID, "luminance must be H x W")
+        return t
+
+    def local_pixels(self, H, W):
+        r0, r1 = slab_rows(H, self.rank, self.world)
+        return (r1 - r0) * W
+
+    def compute_kernel(self, lum, n_row_samples, n_col_samples, hx, hy, want_kab=True):
+        """`computeKernel` (src/filter.cpp:114-167): returns (Ka [p x p fp64 numpy],
+        kab [n_local x ld(p) fp32 CUDA tensor, natural pixel order])."""
+        torch = _torch()
+        lum = self._lum(lum)
+        H, W = lum.shape
+        if n_row_samples > H or n_col_samples > W:
+            raise NLEError(NLE_ERR_INVALID, "Number of samples per row and col must be <= that of image.")
+        g = sample_grid(H, W, n_row_samples, n_col_samples)
+        p = g["n_sel_rows"] * g["n_sel_cols"]
+        Ka = np.zeros((p, p), dtype=np.float64, order="F")
+        kab = None
+        if want_kab:
+            kab = torch.empty((self.local_pixels(H, W), ld(p)), dtype=torch.float32, device=lum.device)
+        _check(lib().nle_compute_kernel(self._h, C.c_void_p(lum.data_ptr()), H, W, n_row_samples, n_col_samples,
+                                        float(hx), float(hy), _np_ptr(Ka),
+                                        C.c_void_p(kab.data_ptr()) if want_kab else None), self._h)
+        return np.ascontiguousarray(Ka), kab
+
+    def nystrom(self, lum, n_row_samples, n_col_samples, hx, hy):
+        """`nystromApproximation` fused with the affinity evaluation: (eigvals, phi[n_local x ld(r)])."""
+        torch = _torch()
+        lum = self._lum(lum)
+        H, W = lum.shape
+        if n_row_samples > H or n_col_samples > W:
+            raise NLEError(NLE_ERR_INVALID, "Number of samples per row and col must be <= that of image.")
+        g = sample_grid(H, W, n_row_samples, n_col_samples)
+        p = g["n_sel_rows"] * g["n_sel_cols"]
+        n_local = self.local_pixels(H, W)
+        buf = torch.empty(n_local * ld(p), dtype=torch.float32, device=lum.device)
+        ev = np.zeros(p, dtype=np.float64)
+        r = C.c_int()
+        _check(lib().nle_nystrom(self._h, C.c_void_p(lum.data_ptr()), H, W, n_row_samples, n_col_samples, float(hx),
+                                 float(hy), _np_ptr(ev), C.byref(r), C.c_void_p(buf.data_ptr())), self._h)
+        rr = r.value
+        return ev[:rr].copy(), buf[: n_local * ld(rr)].view(n_local, ld(rr)), rr
+
+    def ts_gemm(self, A, kd, B):
+        """C = A[:, :kd] @ B  (A fp32 CUDA M x lda, B fp64 numpy kd x nc) -> CUDA M x ld(nc)."""
+        torch = _torch()
+        B = np.asfortranarray(np.asarray(B, dtype=np.float64))
+        M, lda = A.shape
+        nc = B.shape[1]
+        Cc = torch.empty((M, ld(nc)), dtype=torch.float32, device=A.device)
+        _check(lib().nle_ts_gemm(self._h, C.c_void_p(A.data_ptr()), M, lda, kd, _np_ptr(B), nc,
+                                 C.c_void_p(Cc.data_ptr())), self._h)
+        return Cc
+
+    def sinkhorn_scalings(self, phi, r, eigvals, max_iter=10):
+        """Sinkhorn iterations (src/filter.cpp:238-245) on device phi -> (u_c, u_r)."""
+        ev = np.ascontiguousarray(eigvals, dtype=np.float64)
+        uc, ur = np.zeros(r), np.zeros(r)
+        M, ldp = phi.shape
+        _check(lib().nle_sinkhorn_scalings(self._h, C.c_void_p(phi.data_ptr()), M, ldp, r, _np_ptr(ev), max_iter,
+                                           _np_ptr(uc), _np_ptr(ur)), self._h)
+        return uc, ur
+
+    def gram(self, phi, r, u):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        G = np.zeros((r, r), dtype=np.float64, order="F")
+        M, ldp = phi.shape
+        _check(lib().nle_gram(self._h, C.c_void_p(phi.data_ptr()), M, ldp, r, _np_ptr(u), _np_ptr(G)), self._h)
+        return np.ascontiguousarray(G)
+
+    def row_scalings(self, phi, r, u):
+        torch = _torch()
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        M, ldp = phi.shape
+        out = torch.empty(M, dtype=torch.float64, device=phi.device)
+        _check(lib().nle_row_scalings(self._h, C.c_void_p(phi.data_ptr()), M, ldp, r, _np_ptr(u),
+                                      C.c_void_p(out.data_ptr())), self._h)
+        return out
+
+    def bench_affinity(self, lum, n_row_samples, n_col_samples, hx, hy, reps=10):
+        torch = _torch()
+        lum = self._lum(lum)
+        H, W = lum.shape
+        g = sample_grid(H, W, n_row_samples, n_col_samples)
+        p = g["n_sel_rows"] * g["n_sel_cols"]
+        kab = torch.empty((self.local_pixels(H, W), ld(p)), dtype=torch.float32, device=lum.device)
+        ms = C.c_double()
+        _check(lib().nle_bench_affinity(self._h, C.c_void_p(lum.data_ptr()), H, W, n_row_samples, n_col_samples,
+                                        float(hx), float(hy), C.c_void_p(kab.data_ptr()), reps, C.byref(ms)), self._h)
+        return ms.value, kab
+
+    def bench_sinkhorn_pass(self, phi, r, reps=10):
+        ms = C.c_double()
+        M, ldp = phi.shape
+        _check(lib().nle_bench_sinkhorn_pass(self._h, C.c_void_p(phi.data_ptr()), M, ldp, r, reps, C.byref(ms)),
+               self._h)
+        return ms.value
+
+
+class NLEFilter:
+    """`nle::NLEFilter` (include/filter.hpp:35-54) over the C ABI; state = V, eigvals on the GPU."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._f = C.c_void_p()
+        self.shape = None
+
+    def close(self):
+        if self._f:
+            lib().nle_filter_destroy(self._f)
+            self._f = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def train_filter(self, lum, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter=10, n_eigen_vectors=5):
+        """`NLEFilter::trainFilter` (src/filter.cpp:480-502); lum: H x W luminance (CUDA tensor
+        stays on the device; numpy is uploaded)."""
+        self.close()
+        lum = self.ctx._lum(lum)
+        H, W = lum.shape
+        _check(lib().nle_train(self.ctx._h, C.c_void_p(lum.data_ptr()), H, W, int(n_row_samples), int(n_col_samples),
+                               float(hx), float(hy), int(n_sinkhorn_iter), int(n_eigen_vectors), C.byref(self._f)),
+               self.ctx._h)
+        self.shape = (H, W)
+        return self
+
+    def info(self):
+        n = C.c_longlong()
+        v = [C.c_int() for _ in range(5)]
+        _check(lib().nle_filter_info(self._f, C.byref(n), *[C.byref(x) for x in v]))
+        return dict(n_local=n.value, K=v[0].value, r=v[1].value, p=v[2].value, row0=v[3].value, row1=v[4].value)
+
+    @property
+    def eigvals(self):
+        K = self.info()["K"]
+        out = np.zeros(K, dtype=np.float64)
+        _check(lib().nle_filter_eigvals(self._f, _np_ptr(out)))
+        return out
+
+    def eigvecs(self):
+        """m_eigvecs as a CUDA tensor view (n_local x ld(K)), pixel order."""
+        torch = _torch()
+        ptr, ldv = C.c_void_p(), C.c_int()
+        _check(lib().nle_filter_eigvecs(self._f, C.byref(ptr), C.byref(ldv)))
+        n = self.info()["n_local"]
+        out = torch.empty((n, ldv.value), dtype=torch.float32, device=f"cuda:{self.ctx.device}")
+        _check(lib().nle_filter_copy_eigvecs(self._f, C.c_void_p(out.data_ptr())), self.ctx._h)
+        return out
+
+    def timings(self):
+        ms = np.zeros(6)
+        _check(lib().nle_filter_timings(self._f, _np_ptr(ms)))
+        return dict(zip(("affinity_nystrom", "sinkhorn", "gram", "project", "host", "total"), ms.tolist()))
+
+    def apply(self, x, f_s, out=None):
+        """`NLEFilter::apply` (src/filter.cpp:445-458): y = V diag(fS) V^T x (local slab)."""
+        torch = _torch()
+        x = self.ctx._lum(x)
+        H, W = x.shape
+        fs = np.ascontiguousarray(f_s, dtype=np.float64)
+        n = self.info()["n_local"]
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=x.device)
+        _check(lib().nle_apply(self._f, C.c_void_p(x.data_ptr()), H, W, _np_ptr(fs), C.c_void_p(out.data_ptr())),
+               self.ctx._h)
+        return out
+
+    def apply_layers(self, x, n_layers, out=None):
+        torch = _torch()
+        x = self.ctx._lum(x)
+        H, W = x.shape
+        n = self.info()["n_local"]
+        if out is None:
+            out = torch.empty((n_layers, n), dtype=torch.float32, device=x.device)
+        _check(lib().nle_apply_layers(self._f, C.c_void_p(x.data_ptr()), H, W, int(n_layers),
+                                      C.c_void_p(out.data_ptr())), self.ctx._h)
+        return out

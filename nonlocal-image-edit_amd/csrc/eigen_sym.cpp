@@ -1,0 +1,214 @@
+// Host fp64 symmetric eigensolver: Householder tridiagonalisation with accumulated
+// transforms, then implicit-shift QL (the classic EISPACK tred2/tql2 scheme), written
+// for column-major storage so every inner loop is unit stride.
+//
+// Replaces Eigen::SelfAdjointEigenSolver at the reference's call site
+// src/filter.cpp:207-210 (Eigen3 is a system dependency of the reference, version floor
+// 3.3, not vendored).  Same contract: symmetric input, LOWER triangle referenced,
+// orthonormal eigenvectors; `eigen_decomposition` adds the reference's post-processing
+// (:209-216): descending order, keep the leading run with D >= eps.
+#include "eigen_sym.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <vector>
+
+namespace nleh {
+
+namespace {
+
+inline double& at(double* v, int n, int row, int col) { return v[(size_t)col * n + row]; }
+
+// V: n x n col-major, in: symmetric matrix (lower triangle valid, mirrored by caller);
+// out: orthogonal Q with Q^T A Q tridiagonal (d diag, e[1..n-1] sub-diagonal).
+void tridiagonalize(int n, double* V, double* d, double* e) {
+    for (int j = 0; j < n; ++j) d[j] = at(V, n, n - 1, j);
+    for (int i = n - 1; i > 0; --i) {
+        double scale = 0.0, h = 0.0;
+        for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
+            for (int j = 0; j < i; ++j) {
+                d[j] = at(V, n, i - 1, j);
+                at(V, n, i, j) = 0.0;
+                at(V, n, j, i) = 0.0;
+            }
+        } else {
+            for (int k = 0; k < i; ++k) {
+                d[k] /= scale;
+                h += d[k] * d[k];
+            }
+            double f = d[i - 1];
+            double g = std::sqrt(h);
+            if (f > 0) g = -g;
+            e[i] = scale * g;
+            h -= f * g;
+            d[i - 1] = f - g;
+            for (int j = 0; j < i; ++j) e[j] = 0.0;
+            for (int j = 0; j < i; ++j) {
+                f = d[j];
+                at(V, n, j, i) = f;
+                g = e[j] + at(V, n, j, j) * f;
+                const double* col = &at(V, n, 0, j);
+                double gs = 0.0;
+                for (int k = j + 1; k <= i - 1; ++k) {
+                    gs += col[k] * d[k];
+                    e[k] += col[k] * f;
+                }
+                e[j] = g + gs;
+            }
+            f = 0.0;
+            for (int j = 0; j < i; ++j) {
+                e[j] /= h;
+                f += e[j] * d[j];
+            }
+            const double hh = f / (h + h);
+            for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+            for (int j = 0; j < i; ++j) {
+                f = d[j];
+                g = e[j];
+                double* col = &at(V, n, 0, j);
+                for (int k = j; k <= i - 1; ++k) col[k] -= (f * e[k] + g * d[k]);
+                d[j] = at(V, n, i - 1, j);
+                at(V, n, i, j) = 0.0;
+            }
+        }
+        d[i] = h;
+    }
+    // accumulate transformations
+    for (int i = 0; i < n - 1; ++i) {
+        at(V, n, n - 1, i) = at(V, n, i, i);
+        at(V, n, i, i) = 1.0;
+        const double h = d[i + 1];
+        if (h != 0.0) {
+            const double* ci1 = &at(V, n, 0, i + 1);
+            for (int k = 0; k <= i; ++k) d[k] = ci1[k] / h;
+            for (int j = 0; j <= i; ++j) {
+                double* cj = &at(V, n, 0, j);
+                double g = 0.0;
+                for (int k = 0; k <= i; ++k) g += ci1[k] * cj[k];
+                for (int k = 0; k <= i; ++k) cj[k] -= g * d[k];
+            }
+        }
+        for (int k = 0; k <= i; ++k) at(V, n, k, i + 1) = 0.0;
+    }
+    for (int j = 0; j < n; ++j) {
+        d[j] = at(V, n, n - 1, j);
+        at(V, n, n - 1, j) = 0.0;
+    }
+    at(V, n, n - 1, n - 1) = 1.0;
+    e[0] = 0.0;
+}
+
+// implicit QL on (d, e) accumulating rotations into V's columns; returns false if an
+// eigenvalue needs more than 60 sweeps.
+bool ql_implicit(int n, double* V, double* d, double* e) {
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = std::ldexp(1.0, -52);
+    for (int l = 0; l < n; ++l) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int m = l;
+        while (m < n) {
+            if (std::fabs(e[m]) <= eps * tst1) break;
+            ++m;
+        }
+        if (m > l) {
+            int iter = 0;
+            do {
+                if (++iter > 60) return false;
+                double g = d[l];
+                double p = (d[l + 1] - g) / (2.0 * e[l]);
+                double r = std::hypot(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r);
+                d[l + 1] = e[l] * (p + r);
+                const double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] -= h;
+                f += h;
+                p = d[m];
+                double c = 1.0, c2 = c, c3 = c;
+                const double el1 = e[l + 1];
+                double s = 0.0, s2 = 0.0;
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2;
+                    c2 = c;
+                    s2 = s;
+                    g = c * e[i];
+                    h = c * p;
+                    r = std::hypot(p, e[i]);
+                    e[i + 1] = s * r;
+                    s = e[i] / r;
+                    c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    double* vi = &at(V, n, 0, i);
+                    double* vi1 = &at(V, n, 0, i + 1);
+                    for (int k = 0; k < n; ++k) {
+                        const double hk = vi1[k];
+                        vi1[k] = s * vi[k] + c * hk;
+                        vi[k] = c * vi[k] - s * hk;
+                    }
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p;
+                d[l] = c * p;
+            } while (std::fabs(e[l]) > eps * tst1);
+        }
+        d[l] += f;
+        e[l] = 0.0;
+    }
+    return true;
+}
+
+}  // namespace
+
+bool sym_eigen(const double* M, int n, double* U, double* D) {
+    if (n <= 0) return true;
+    // mirror the lower triangle (SelfAdjointEigenSolver reads only the lower one)
+    for (int c = 0; c < n; ++c)
+        for (int r = 0; r < n; ++r) {
+            const double v = (r >= c) ? M[(size_t)c * n + r] : M[(size_t)r * n + c];
+            U[(size_t)c * n + r] = v;
+        }
+    std::vector<double> e(n);
+    if (n == 1) {
+        D[0] = U[0];
+        U[0] = 1.0;
+        return true;
+    }
+    tridiagonalize(n, U, D, e.data());
+    if (!ql_implicit(n, U, D, e.data())) return false;
+    // ascending order
+    std::vector<int> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return D[a] < D[b]; });
+    std::vector<double> Ds(n), Us((size_t)n * n);
+    for (int j = 0; j < n; ++j) {
+        Ds[j] = D[idx[j]];
+        std::copy(U + (size_t)idx[j] * n, U + (size_t)idx[j] * n + n, Us.begin() + (size_t)j * n);
+    }
+    std::copy(Ds.begin(), Ds.end(), D);
+    std::copy(Us.begin(), Us.end(), U);
+    return true;
+}
+
+bool eigen_decomposition(const double* M, int n, double eps, double* U, double* D, int* r_out) {
+    std::vector<double> Ua((size_t)n * n), Da(n);
+    if (!sym_eigen(M, n, Ua.data(), Da.data())) return false;
+    // reference src/filter.cpp:209-216: reverse to descending, keep leading run >= eps
+    int r = 0;
+    for (int j = 0; j < n; ++j) {
+        const int src = n - 1 - j;
+        D[j] = Da[src];
+        std::copy(Ua.begin() + (size_t)src * n, Ua.begin() + (size_t)src * n + n, U + (size_t)j * n);
+    }
+    while (r < n && D[r] >= eps) ++r;
+    *r_out = r;
+    return true;
+}
+
+}  // namespace nleh

@@ -1,0 +1,1002 @@
+// Host orchestration of the hot path behind the C ABI (include/nle.h): context, the
+// fused train pipeline (NLEFilter::trainFilter, reference src/filter.cpp:480-502) and
+// apply (:445-458).  Small (p x p, r x r) algebra and the three symmetric eigensolves run
+// on the host in fp64; everything N-sized is a HIP kernel (kernels.hip).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nle.h"
+#include "eigen_sym.h"
+#include "kernels.h"
+
+using nlek::GridSpec;
+
+// ------------------------------------------------------------------------------ types
+struct nle_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int rank = 0, world = 1;
+    nle_allreduce_fn allreduce = nullptr;
+    void* ar_user = nullptr;
+    double* d_comm = nullptr;
+    size_t comm_len = 0;
+    std::string err;
+};
+
+struct nle_filter {
+    nle_ctx* ctx = nullptr;
+    int H = 0, W = 0, row0 = 0, row1 = 0;
+    long long n_local = 0;
+    int K = 0, ldv = 0, r = 0, p = 0;
+    float* d_V = nullptr;
+    std::vector<double> eigvals;
+    double ms[6] = {0, 0, 0, 0, 0, 0};
+};
+
+static thread_local std::string g_create_err;
+
+namespace {
+
+struct Fail {
+    int code;
+    std::string msg;
+};
+
+#define HIP_OK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            throw Fail{NLE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)};           \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    void alloc(size_t count) {
+        release();
+        if (count) HIP_OK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        n = count;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    T* take() {
+        T* q = p;
+        p = nullptr;
+        n = 0;
+        return q;
+    }
+    ~DevBuf() { release(); }
+};
+
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
+    explicit Timer(hipStream_t st) : s(st) {
+        HIP_OK(hipEventCreate(&a));
+        HIP_OK(hipEventCreate(&b));
+    }
+    ~Timer() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+    void start() { HIP_OK(hipEventRecord(a, s)); }
+    void stop() { HIP_OK(hipEventRecord(b, s)); }
+    double ms() {
+        HIP_OK(hipEventSynchronize(b));
+        float t = 0.f;
+        HIP_OK(hipEventElapsedTime(&t, a, b));
+        return t;
+    }
+};
+
+inline int ld4(int n) { return (n + 3) & ~3; }
+
+bool make_grid(int H, int W, int nRow, int nCol, GridSpec* gs) {
+    // samplePixels, reference src/filter.cpp:56-71, closed form
+    if (H <= 0 || W <= 0 || nRow <= 0 || nCol <= 0 || nRow > H || nCol > W) return false;
+    gs->H = H;
+    gs->W = W;
+    gs->rowStep = H / nRow;
+    gs->colStep = W / nCol;
+    gs->rowOff = (gs->rowStep - 1 + (H - gs->rowStep * nRow)) / 2;
+    gs->colOff = (gs->colStep - 1 + (W - gs->colStep * nCol)) / 2;
+    // r >= off, r <= H - off, (r - off) % step == 0, r < H
+    auto count = [](int n, int off, int step) {
+        const int hi = std::min(n - 1, n - off);
+        if (hi < off) return 0;
+        return (hi - off) / step + 1;
+    };
+    gs->nSelRows = count(H, gs->rowOff, gs->rowStep);
+    gs->nSelCols = count(W, gs->colOff, gs->colStep);
+    return gs->nSelRows > 0 && gs->nSelCols > 0;
+}
+
+void slab(int H, int rank, int world, int* row0, int* row1) {
+    *row0 = (int)(((long long)rank * H) / world);
+    *row1 = (int)(((long long)(rank + 1) * H) / world);
+}
+
+inline double recip0(double v, double eps = NLE_EPS) { return std::fabs(v) >= eps ? 1.0 / v : 0.0; }
+
+void check_image_size(int H, int W) {
+    if (H <= 0 || W <= 0) throw Fail{NLE_ERR_INVALID, "image must be non-empty"};
+    if ((long long)H * W >= (1ll << 31)) throw Fail{NLE_ERR_INVALID, "image too large (H*W must be < 2^31)"};
+}
+
+// sum over ranks of n doubles at device pointer d (stream ordered)
+void all_reduce(nle_ctx* c, double* d, size_t n) {
+    if (c->world <= 1) return;
+    if (!c->allreduce || !c->d_comm || c->comm_len < n)
+        throw Fail{NLE_ERR_COMM, "world > 1 but no all-reduce callback / comm buffer too small"};
+    HIP_OK(hipMemcpyAsync(c->d_comm, d, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (c->allreduce(c->ar_user, c->d_comm, n) != 0) throw Fail{NLE_ERR_COMM, "all-reduce callback failed"};
+    HIP_OK(hipMemcpyAsync(d, c->d_comm, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+}
+
+// ---- sample set + Ka (host) ----
+struct SampleSet {
+    GridSpec gs;
+    int p = 0;
+    std::vector<long long> pix;     // row-major pixel index of each sample (permuted order)
+    std::vector<float> val;         // luminance
+    std::vector<float4> packed;     // {row, col, lum, 0}
+};
+
+SampleSet fetch_samples(nle_ctx* c, const float* d_lum, const GridSpec& gs) {
+    SampleSet s;
+    s.gs = gs;
+    s.p = gs.p();
+    DevBuf<float> d_val(s.p);
+    HIP_OK(nlek::gather_samples(c->stream, d_lum, gs, d_val.p));
+    s.val.resize(s.p);
+    HIP_OK(hipMemcpyAsync(s.val.data(), d_val.p, s.p * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    s.pix.resize(s.p);
+    s.packed.resize(s.p);
+    for (int k = 0; k < s.p; ++k) {
+        const int r = gs.rowOff + (k / gs.nSelCols) * gs.rowStep;
+        const int cc = gs.colOff + (k % gs.nSelCols) * gs.colStep;
+        s.pix[k] = (long long)r * gs.W + cc;
+        s.packed[k] = make_float4((float)r, (float)cc, s.val[k], 0.f);
+    }
+    return s;
+}
+
+// Ka(i,j), reference src/filter.cpp:128-137,144 (fp64, integer spatial term)
+std::vector<double> build_Ka(const SampleSet& s, double hx, double hy) {
+    const int p = s.p;
+    const double sw = 1.0 / (hx * hx), pw = 1.0 / (hy * hy);
+    std::vector<double> Ka((size_t)p * p);
+    for (int j = 0; j < p; ++j) {
+        const int rj = (int)(s.pix[j] / s.gs.W), cj = (int)(s.pix[j] % s.gs.W);
+        for (int i = j; i < p; ++i) {
+            const int ri = (int)(s.pix[i] / s.gs.W), ci = (int)(s.pix[i] % s.gs.W);
+            const long long dr = ri - rj, dc = ci - cj;
+            const double sq = (double)(dr * dr + dc * dc);
+            const double dv = (double)s.val[i] - (double)s.val[j];
+            const double v = std::exp(-sw * sq - pw * (dv * dv));
+            Ka[(size_t)j * p + i] = v;
+            Ka[(size_t)i * p + j] = v;
+        }
+    }
+    return Ka;
+}
+
+struct Nystrom {
+    int r = 0, ldr = 0;
+    std::vector<double> VA;   // p x r col-major
+    std::vector<double> lam;  // r
+};
+
+Nystrom solve_Ka(const std::vector<double>& Ka, int p) {
+    // nystromApproximation, reference src/filter.cpp:262-271
+    std::vector<double> U((size_t)p * p), D(p);
+    int r = 0;
+    if (!nleh::eigen_decomposition(Ka.data(), p, NLE_EPS, U.data(), D.data(), &r))
+        throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Ka"};
+    int nnz = 0;
+    for (int k = 0; k < r; ++k)
+        if (std::fabs(D[k]) >= NLE_EPS) ++nnz;  // inplaceReciprocal count (:266)
+    r = std::min(r, nnz);
+    if (r <= 0) throw Fail{NLE_ERR_NUMERIC, "Ka has no eigenvalue >= 1e-10"};
+    Nystrom n;
+    n.r = r;
+    n.ldr = ld4(r);
+    n.VA.assign(U.begin(), U.begin() + (size_t)p * r);
+    n.lam.assign(D.begin(), D.begin() + r);
+    return n;
+}
+
+// B = V_A diag(1/lambda) as fp32 row-major p x ldr
+std::vector<float> build_B(const Nystrom& n, int p) {
+    std::vector<float> B((size_t)p * n.ldr, 0.f);
+    for (int k = 0; k < n.r; ++k) {
+        const double inv = recip0(n.lam[k]);
+        for (int s = 0; s < p; ++s) B[(size_t)s * n.ldr + k] = (float)(n.VA[(size_t)k * p + s] * inv);
+    }
+    return B;
+}
+
+// Phi for the local slab: fused affinity + Nystrom extension, then exact V_A sample rows
+void build_phi(nle_ctx* c, const float* d_lum, const SampleSet& ss, const Nystrom& ny, double hx,
+               double hy, long long pix0, long long M, float* d_phi) {
+    const int p = ss.p;
+    DevBuf<float4> d_samples(p);
+    HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), p * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    std::vector<float> B = build_B(ny, p);
+    DevBuf<float> d_B(B.size());
+    HIP_OK(hipMemcpyAsync(d_B.p, B.data(), B.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const float sw = (float)(1.0 / (hx * hx)), pw = (float)(1.0 / (hy * hy));
+    HIP_OK(nlek::ts_gemm(c->stream, true, nullptr, 0, d_lum, ss.gs, d_samples.p, sw, pw, pix0, d_B.p,
+                         ny.ldr, p, d_phi, ny.ldr, M, nullptr, NLE_EPS));
+    // sample pixels carry their exact V_A row (top block of phi, reference :275)
+    std::vector<float> rows;
+    std::vector<long long> idx;
+    for (int k = 0; k < p; ++k) {
+        const long long loc = ss.pix[k] - pix0;
+        if (loc < 0 || loc >= M) continue;
+        idx.push_back(loc);
+        const size_t off = rows.size();
+        rows.resize(off + ny.ldr, 0.f);
+        for (int j = 0; j < ny.r; ++j) rows[off + j] = (float)ny.VA[(size_t)j * p + k];
+    }
+    DevBuf<float> d_rows(rows.size());
+    DevBuf<long long> d_idx(idx.size());
+    if (!idx.empty()) {
+        HIP_OK(hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_idx.p, idx.data(), idx.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(nlek::scatter_rows(c->stream, d_rows.p, d_idx.p, (int)idx.size(), ny.ldr, d_phi, M));
+    }
+    HIP_OK(hipStreamSynchronize(c->stream));  // host staging vectors go out of scope
+}
+
+// Sinkhorn (reference :238-245) as 2T passes: t0 = Phi^T 1, then alternately
+// t <- Phi^T recip(Phi (lam o t)).  Returns u_c, u_r (host) and leaves lam o t_c_in on d_u_c.
+void sinkhorn_passes(nle_ctx* c, const float* d_phi, long long M, int ld, int r,
+                     const std::vector<double>& lam, int T, std::vector<double>* u_c,
+                     std::vector<double>* u_r, double* d_u_c_out /* ld doubles or null */) {
+    if (T < 1) throw Fail{NLE_ERR_INVALID, "nSinkhornIter must be >= 1"};
+    std::vector<double> lam_pad(ld, 0.0);
+    std::copy(lam.begin(), lam.begin() + r, lam_pad.begin());
+    DevBuf<double> d_lam(ld), d_t[3], d_partial((size_t)nlek::kRowpassMaxBlocks * ld);
+    for (auto& b : d_t) b.alloc(ld);
+    HIP_OK(hipMemcpyAsync(d_lam.p, lam_pad.data(), ld * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int nb = 0;
+    // t_r(0) = Phi^T 1
+    HIP_OK(nlek::rowpass(c->stream, nlek::ROWPASS_COLSUM, d_phi, M, ld, nullptr, nullptr, nullptr, NLE_EPS,
+                         d_partial.p, &nb));
+    HIP_OK(nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t[0].p));
+    all_reduce(c, d_t[0].p, ld);
+    // cur = index of the t feeding the next pass
+    int cur = 0;
+    int idx_c_in = 0, idx_r_in = 0;
+    for (int it = 0; it < T; ++it) {
+        // c = recip(Phi (lam o t_r));  t_c = Phi^T c
+        idx_c_in = cur;
+        int nxt = (cur + 1) % 3;
+        HIP_OK(nlek::rowpass(c->stream, nlek::ROWPASS_RECIP, d_phi, M, ld, d_t[cur].p, d_lam.p, nullptr,
+                             NLE_EPS, d_partial.p, &nb));
+        HIP_OK(nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t[nxt].p));
+        all_reduce(c, d_t[nxt].p, ld);
+        cur = nxt;
+        idx_r_in = cur;
+        if (it + 1 < T) {
+            // r = recip(Phi (lam o t_c));  t_r = Phi^T r  (not needed after the last iteration:
+            // only u_r = lam o t_c enters the W blocks)
+            nxt = (cur + 1) % 3;
+            if (nxt == idx_c_in) nxt = (nxt + 1) % 3;
+            HIP_OK(nlek::rowpass(c->stream, nlek::ROWPASS_RECIP, d_phi, M, ld, d_t[cur].p, d_lam.p, nullptr,
+                                 NLE_EPS, d_partial.p, &nb));
+            HIP_OK(nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t[nxt].p));
+            all_reduce(c, d_t[nxt].p, ld);
+            cur = nxt;
+        }
+    }
+    std::vector<double> tc(ld), tr(ld);
+    HIP_OK(hipMemcpyAsync(tc.data(), d_t[idx_c_in].p, ld * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipMemcpyAsync(tr.data(), d_t[idx_r_in].p, ld * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (d_u_c_out) HIP_OK(nlek::scale_vec(c->stream, d_lam.p, d_t[idx_c_in].p, ld, d_u_c_out));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    u_c->assign(r, 0.0);
+    u_r->assign(r, 0.0);
+    for (int k = 0; k < r; ++k) {
+        (*u_c)[k] = lam[k] * tc[k];
+        (*u_r)[k] = lam[k] * tr[k];
+    }
+}
+
+// G (r x r col-major) = sum_i c_i^2 phi_i phi_i^T over ALL rows of every rank
+std::vector<double> gram_all(nle_ctx* c, const float* d_phi, long long M, int ld, int r, const double* d_u) {
+    const int ntiles = nlek::gram_num_tiles(ld);
+    DevBuf<double> d_partial(std::max<size_t>(nlek::gram_partial_elems(std::max<long long>(M, 1), ld), 1));
+    DevBuf<double> d_tiles((size_t)ntiles * 1024);
+    if (M > 0) {
+        HIP_OK(nlek::gram(c->stream, d_phi, M, ld, d_u, NLE_EPS, d_partial.p, d_tiles.p));
+    } else {
+        HIP_OK(hipMemsetAsync(d_tiles.p, 0, (size_t)ntiles * 1024 * sizeof(double), c->stream));
+    }
+    all_reduce(c, d_tiles.p, (size_t)ntiles * 1024);
+    std::vector<double> tiles((size_t)ntiles * 1024);
+    HIP_OK(hipMemcpyAsync(tiles.data(), d_tiles.p, tiles.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    std::vector<double> G((size_t)r * r, 0.0);
+    const int nt = (ld + 31) / 32;
+    int t = 0;
+    for (int ti = 0; ti < nt; ++ti)
+        for (int tj = ti; tj < nt; ++tj, ++t) {
+            const double* tl = tiles.data() + (size_t)t * 1024;
+            for (int a = 0; a < 32; ++a)
+                for (int b = 0; b < 32; ++b) {
+                    const int i = ti * 32 + a, j = tj * 32 + b;
+                    if (i >= r || j >= r) continue;
+                    if (ti == tj && j < i) continue;  // diagonal tiles: take the upper half
+                    const double v = tl[a * 32 + b];
+                    G[(size_t)j * r + i] = v;
+                    G[(size_t)i * r + j] = v;
+                }
+        }
+    return G;
+}
+
+// ---- small host algebra, column-major ----
+// C (m x n) = A (m x k) * B (k x n)
+void mm(const double* A, const double* B, double* C, int m, int k, int n) {
+    std::fill(C, C + (size_t)m * n, 0.0);
+    for (int j = 0; j < n; ++j)
+        for (int l = 0; l < k; ++l) {
+            const double b = B[(size_t)j * k + l];
+            const double* a = A + (size_t)l * m;
+            double* cc = C + (size_t)j * m;
+            for (int i = 0; i < m; ++i) cc[i] += a[i] * b;
+        }
+}
+// C (m x n) = A (m x k) * B^T (B is n x k)
+void mm_nt(const double* A, const double* B, double* C, int m, int k, int n) {
+    std::fill(C, C + (size_t)m * n, 0.0);
+    for (int l = 0; l < k; ++l)
+        for (int j = 0; j < n; ++j) {
+            const double b = B[(size_t)l * n + j];
+            const double* a = A + (size_t)l * m;
+            double* cc = C + (size_t)j * m;
+            for (int i = 0; i < m; ++i) cc[i] += a[i] * b;
+        }
+}
+// C (k x n) = A^T (A is m x k) * B (m x n)
+void mm_tn(const double* A, const double* B, double* C, int m, int k, int n) {
+    for (int j = 0; j < n; ++j)
+        for (int l = 0; l < k; ++l) {
+            const double* a = A + (size_t)l * m;
+            const double* b = B + (size_t)j * m;
+            double s = 0.0;
+            for (int i = 0; i < m; ++i) s += a[i] * b[i];
+            C[(size_t)j * k + l] = s;
+        }
+}
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+// The W blocks and the orthogonalisation on the host.  Inputs: V_A (p x r), lambda, u_c, u_r,
+// G = sum over ALL pixels of c^2 phi phi^T.  Outputs: Sq (K'), Cproj (r x K'), VArows (q x K').
+// reference src/filter.cpp:247-250 (W blocks, q = phi.cols()), :282-331 (orthogonalize).
+namespace {
+struct Ortho {
+    int q = 0, K = 0;
+    std::vector<double> Sq, Cproj, VArows, Wa;
+};
+
+Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_c,
+                         const std::vector<double>& u_r, std::vector<double> G, int n_eig) {
+    const int r = ny.r, q = ny.r;  // :247 -- the A block is the first q = r permuted rows
+    // phi_A = V_A[:q] (exact, fp64); what the device holds for those rows is float(V_A)
+    std::vector<double> cA(q), rA(q), cA32(q);
+    std::vector<double> left((size_t)q * r), right((size_t)q * r), phi32((size_t)q * r);
+    for (int a = 0; a < q; ++a) {
+        double sc = 0.0, sr = 0.0, sc32 = 0.0;
+        for (int k = 0; k < r; ++k) {
+            const double v = ny.VA[(size_t)k * p + a];
+            const double v32 = (double)(float)v;
+            phi32[(size_t)k * q + a] = v32;
+            sc += v * u_c[k];
+            sr += v * u_r[k];
+            sc32 += v32 * u_c[k];
+        }
+        cA[a] = recip0(sc);
+        rA[a] = recip0(sr);
+        cA32[a] = recip0(sc32);
+    }
+    for (int k = 0; k < r; ++k)
+        for (int a = 0; a < q; ++a) {
+            const double v = ny.VA[(size_t)k * p + a];
+            left[(size_t)k * q + a] = rA[a] * v * ny.lam[k];  // R * (phi_top * D)
+            right[(size_t)k * q + a] = cA[a] * v;             // c o phi_top
+        }
+    Ortho o;
+    o.q = q;
+    o.Wa.resize((size_t)q * q);
+    mm_nt(left.data(), right.data(), o.Wa.data(), q, r, q);  // :249
+    // remove the A rows from the all-pixel Gram: G_B = G - sum_a c_a^2 phi_a phi_a^T
+    for (int a = 0; a < q; ++a) {
+        const double c2 = cA32[a] * cA32[a];
+        for (int j = 0; j < r; ++j) {
+            const double vj = c2 * phi32[(size_t)j * q + a];
+            for (int i = 0; i < r; ++i) G[(size_t)j * r + i] -= phi32[(size_t)i * q + a] * vj;
+        }
+    }
+    // Wab Wab^T = left * G_B * left^T  (:296)
+    std::vector<double> LG((size_t)q * r), WW((size_t)q * q);
+    mm(left.data(), G.data(), LG.data(), q, r, r);
+    mm_nt(LG.data(), left.data(), WW.data(), q, r, q);
+    // S = Wa^{-1/2} (pseudo-inverse root), :287-292
+    std::vector<double> U2((size_t)q * q), l2(q);
+    int r2 = 0;
+    if (!nleh::eigen_decomposition(o.Wa.data(), q, NLE_EPS, U2.data(), l2.data(), &r2))
+        throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Wa"};
+    std::vector<double> Us((size_t)q * std::max(r2, 1)), S((size_t)q * q);
+    for (int k = 0; k < r2; ++k) {
+        const double s = std::sqrt(recip0(l2[k]));
+        for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * s;
+    }
+    mm_nt(Us.data(), U2.data(), S.data(), q, r2, q);
+    // Q = Wa + S * WW * S  (:296)
+    std::vector<double> T1((size_t)q * q), Qm((size_t)q * q);
+    mm(S.data(), WW.data(), T1.data(), q, q, q);
+    mm(T1.data(), S.data(), Qm.data(), q, q, q);
+    for (size_t i = 0; i < Qm.size(); ++i) Qm[i] += o.Wa[i];
+    std::vector<double> Vq((size_t)q * q), Sq(q);
+    int rq = 0;
+    if (!nleh::eigen_decomposition(Qm.data(), q, NLE_EPS, Vq.data(), Sq.data(), &rq))
+        throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Q"};
+    const int K = std::min(n_eig, rq);  // :314
+    if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
+    o.K = K;
+    o.Sq.assign(Sq.begin(), Sq.begin() + K);
+    // T2 = S * Vq * diag(Sq^-1/2)  (q x K)
+    std::vector<double> T2((size_t)q * K);
+    mm(S.data(), Vq.data(), T2.data(), q, q, K);
+    for (int k = 0; k < K; ++k) {
+        const double s = std::sqrt(recip0(Sq[k]));
+        for (int i = 0; i < q; ++i) T2[(size_t)k * q + i] *= s;
+    }
+    o.Cproj.resize((size_t)r * K);
+    mm_tn(left.data(), T2.data(), o.Cproj.data(), q, r, K);  // M * T2, M = left^T
+    o.VArows.resize((size_t)q * K);
+    mm(o.Wa.data(), T2.data(), o.VArows.data(), q, q, K);  // top block of :327
+    return o;
+}
+
+nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, int nCol, double hx,
+                       double hy, int T, int n_eig) {
+    check_image_size(H, W);
+    if (nRow > H || nCol > W)  // reference src/filter.cpp:117-119
+        throw Fail{NLE_ERR_INVALID, "Number of samples per row and col must be <= that of image."};
+    GridSpec gs;
+    if (!make_grid(H, W, nRow, nCol, &gs)) throw Fail{NLE_ERR_INVALID, "invalid sample counts"};
+    if (T < 1) throw Fail{NLE_ERR_INVALID, "nSinkhornIter must be >= 1"};
+    if (n_eig < 1) throw Fail{NLE_ERR_INVALID, "nEigenVectors must be >= 1"};
+    if (!(hx > 0) || !(hy > 0)) throw Fail{NLE_ERR_INVALID, "hx and hy must be > 0"};
+    if (gs.p() > 2048) throw Fail{NLE_ERR_INVALID, "more than 2048 samples is not supported"};
+    HIP_OK(hipSetDevice(c->device));
+
+    auto f = new nle_filter();
+    try {
+        f->ctx = c;
+        f->H = H;
+        f->W = W;
+        slab(H, c->rank, c->world, &f->row0, &f->row1);
+        const long long pix0 = (long long)f->row0 * W;
+        const long long M = (long long)(f->row1 - f->row0) * W;
+        f->n_local = M;
+        const double t_begin = now_ms();
+        Timer tm_a(c->stream), tm_s(c->stream), tm_g(c->stream), tm_p(c->stream);
+        double host_ms = 0.0;
+
+        // --- affinity blocks + Nystrom (:486-491)
+        tm_a.start();
+        SampleSet ss = fetch_samples(c, d_lum, gs);
+        f->p = ss.p;
+        double h0 = now_ms();
+        std::vector<double> Ka = build_Ka(ss, hx, hy);
+        Nystrom ny = solve_Ka(Ka, ss.p);
+        host_ms += now_ms() - h0;
+        f->r = ny.r;
+        DevBuf<float> d_phi((size_t)std::max<long long>(M, 1) * ny.ldr);
+        build_phi(c, d_lum, ss, ny, hx, hy, pix0, M, d_phi.p);
+        tm_a.stop();
+
+        // --- Sinkhorn (:495)
+        tm_s.start();
+        std::vector<double> u_c, u_r;
+        DevBuf<double> d_u_c(ny.ldr);
+        sinkhorn_passes(c, d_phi.p, M, ny.ldr, ny.r, ny.lam, T, &u_c, &u_r, d_u_c.p);
+        tm_s.stop();
+
+        // --- Gram (the N-sized part of :296)
+        tm_g.start();
+        std::vector<double> G = gram_all(c, d_phi.p, M, ny.ldr, ny.r, d_u_c.p);
+        tm_g.stop();
+
+        // --- orthogonalize on the host (:499)
+        h0 = now_ms();
+        Ortho o = orthogonalize_host(ny, ss.p, u_c, u_r, std::move(G), n_eig);
+        host_ms += now_ms() - h0;
+        f->K = o.K;
+        f->ldv = ld4(o.K);
+        f->eigvals = o.Sq;
+
+        // --- V = diag(c) Phi Cproj, A rows = Wa T2, already in pixel order (:327, :502)
+        tm_p.start();
+        std::vector<float> Cp((size_t)ny.r * f->ldv, 0.f);
+        for (int k = 0; k < o.K; ++k)
+            for (int j = 0; j < ny.r; ++j) Cp[(size_t)j * f->ldv + k] = (float)o.Cproj[(size_t)k * ny.r + j];
+        DevBuf<float> d_Cp(Cp.size());
+        HIP_OK(hipMemcpyAsync(d_Cp.p, Cp.data(), Cp.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        DevBuf<float> d_V((size_t)std::max<long long>(M, 1) * f->ldv);
+        HIP_OK(nlek::ts_gemm(c->stream, false, d_phi.p, ny.ldr, nullptr, gs, nullptr, 0.f, 0.f, 0, d_Cp.p,
+                             f->ldv, ny.r, d_V.p, f->ldv, M, d_u_c.p, NLE_EPS));
+        std::vector<float> rows;
+        std::vector<long long> idx;
+        for (int a = 0; a < o.q; ++a) {
+            const long long loc = ss.pix[a] - pix0;
+            if (loc < 0 || loc >= M) continue;
+            idx.push_back(loc);
+            const size_t off = rows.size();
+            rows.resize(off + f->ldv, 0.f);
+            for (int k = 0; k < o.K; ++k) rows[off + k] = (float)o.VArows[(size_t)k * o.q + a];
+        }
+        DevBuf<float> d_rows(rows.size());
+        DevBuf<long long> d_idx(idx.size());
+        if (!idx.empty()) {
+            HIP_OK(hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipMemcpyAsync(d_idx.p, idx.data(), idx.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+            HIP_OK(nlek::scatter_rows(c->stream, d_rows.p, d_idx.p, (int)idx.size(), f->ldv, d_V.p, M));
+        }
+        tm_p.stop();
+        HIP_OK(hipStreamSynchronize(c->stream));
+        f->d_V = d_V.take();
+        f->ms[0] = tm_a.ms();
+        f->ms[1] = tm_s.ms();
+        f->ms[2] = tm_g.ms();
+        f->ms[3] = tm_p.ms();
+        f->ms[4] = host_ms;
+        f->ms[5] = now_ms() - t_begin;
+    } catch (...) {
+        delete f;
+        throw;
+    }
+    return f;
+}
+
+// t = V^T x (all ranks), then Y[l] = V (g_l o t)
+void apply_impl(nle_filter* f, const float* d_x, int H, int W, const double* h_g /* L x K */, int L,
+                float* d_y) {
+    nle_ctx* c = f->ctx;
+    if ((long long)H * W != (long long)f->H * f->W)  // reference src/filter.cpp:447-449
+        throw Fail{NLE_ERR_INVALID, "Number of values in channel must match that of training image."};
+    if (L < 1 || L > 64) throw Fail{NLE_ERR_INVALID, "number of layers must be in [1, 64]"};
+    HIP_OK(hipSetDevice(c->device));
+    const int ld = f->ldv;
+    const long long M = f->n_local;
+    const long long pix0 = (long long)f->row0 * f->W;
+    DevBuf<double> d_partial((size_t)nlek::kRowpassMaxBlocks * ld), d_t(ld), d_resp((size_t)L * ld),
+        d_g((size_t)L * ld);
+    std::vector<double> resp((size_t)L * ld, 0.0);
+    for (int l = 0; l < L; ++l)
+        for (int k = 0; k < f->K; ++k) resp[(size_t)l * ld + k] = h_g[(size_t)l * f->K + k];
+    HIP_OK(hipMemcpyAsync(d_resp.p, resp.data(), resp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int nb = 0;
+    HIP_OK(nlek::rowpass(c->stream, nlek::ROWPASS_XVEC, f->d_V, M, ld, nullptr, nullptr, d_x + pix0, NLE_EPS,
+                         d_partial.p, &nb));
+    HIP_OK(nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t.p));
+    all_reduce(c, d_t.p, ld);
+    for (int l = 0; l < L; ++l)
+        HIP_OK(nlek::scale_vec(c->stream, d_resp.p + (size_t)l * ld, d_t.p, ld, d_g.p + (size_t)l * ld));
+    HIP_OK(nlek::apply_expand(c->stream, f->d_V, M, ld, d_g.p, L, d_y, M));
+    HIP_OK(hipStreamSynchronize(c->stream));
+}
+
+void layer_resp(const double* ev, int K, int L, double* out) {
+    // detail layer j <-> lambda^j - lambda^(j+1); base <-> lambda^(L-1)  (reference :334-347)
+    for (int j = 0; j < L; ++j)
+        for (int k = 0; k < K; ++k) {
+            const double a = std::pow(ev[k], (double)j);
+            out[(size_t)j * K + k] = (j < L - 1) ? a - std::pow(ev[k], (double)(j + 1)) : a;
+        }
+}
+
+template <typename Fn>
+int guard(nle_ctx* c, Fn&& fn) {
+    try {
+        fn();
+        return NLE_OK;
+    } catch (const Fail& e) {
+        if (c) c->err = e.msg; else g_create_err = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        if (c) c->err = e.what(); else g_create_err = e.what();
+        return NLE_ERR_INVALID;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int nle_ld(int n) { return ld4(n); }
+
+size_t nle_comm_len(int n_samples) {
+    const int ld = ld4(n_samples);
+    return (size_t)nlek::gram_num_tiles(ld) * 1024 + (size_t)ld;
+}
+
+int nle_ctx_create(int device, void* stream, nle_ctx** out) {
+    if (!out) return NLE_ERR_INVALID;
+    *out = nullptr;
+    return guard(nullptr, [&] {
+        int ndev = 0;
+        HIP_OK(hipGetDeviceCount(&ndev));
+        if (ndev <= 0) throw Fail{NLE_ERR_HIP, "no HIP device (this library has no CPU fallback)"};
+        if (device < 0 || device >= ndev) throw Fail{NLE_ERR_INVALID, "device index out of range"};
+        HIP_OK(hipSetDevice(device));
+        auto c = new nle_ctx();
+        c->device = device;
+        if (stream) {
+            c->stream = reinterpret_cast<hipStream_t>(stream);
+        } else {
+            hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+            if (e != hipSuccess) {
+                delete c;
+                throw Fail{NLE_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)};
+            }
+            c->own_stream = true;
+        }
+        *out = c;
+    });
+}
+
+void nle_ctx_destroy(nle_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* nle_last_error(const nle_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int nle_ctx_synchronize(nle_ctx* ctx) {
+    if (!ctx) return NLE_ERR_INVALID;
+    return guard(ctx, [&] { HIP_OK(hipStreamSynchronize(ctx->stream)); });
+}
+
+int nle_ctx_set_shard(nle_ctx* ctx, int rank, int world, nle_allreduce_fn allreduce, void* user,
+                      double* d_comm, size_t comm_len) {
+    if (!ctx) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        if (world < 1 || rank < 0 || rank >= world) throw Fail{NLE_ERR_INVALID, "bad rank/world"};
+        if (world > 1 && (!allreduce || !d_comm || comm_len == 0))
+            throw Fail{NLE_ERR_INVALID, "world > 1 needs an all-reduce callback and a comm buffer"};
+        ctx->rank = rank;
+        ctx->world = world;
+        ctx->allreduce = allreduce;
+        ctx->ar_user = user;
+        ctx->d_comm = d_comm;
+        ctx->comm_len = comm_len;
+    });
+}
+
+int nle_sample_grid(int H, int W, int n_row_samples, int n_col_samples, int* row_step, int* row_off,
+                    int* n_sel_rows, int* col_step, int* col_off, int* n_sel_cols) {
+    GridSpec gs;
+    if (!make_grid(H, W, n_row_samples, n_col_samples, &gs)) return NLE_ERR_INVALID;
+    if (row_step) *row_step = gs.rowStep;
+    if (row_off) *row_off = gs.rowOff;
+    if (n_sel_rows) *n_sel_rows = gs.nSelRows;
+    if (col_step) *col_step = gs.colStep;
+    if (col_off) *col_off = gs.colOff;
+    if (n_sel_cols) *n_sel_cols = gs.nSelCols;
+    return NLE_OK;
+}
+
+int nle_slab_rows(int H, int rank, int world, int* row0, int* row1) {
+    if (H <= 0 || world < 1 || rank < 0 || rank >= world || !row0 || !row1) return NLE_ERR_INVALID;
+    slab(H, rank, world, row0, row1);
+    return NLE_OK;
+}
+
+int nle_eigen_decomposition(const double* h_M, int n, double eps, double* h_U, double* h_D, int* r) {
+    if (!h_M || n <= 0 || !h_U || !h_D || !r) return NLE_ERR_INVALID;
+    return nleh::eigen_decomposition(h_M, n, eps, h_U, h_D, r) ? NLE_OK : NLE_ERR_NUMERIC;
+}
+
+int nle_transform_eigenvalues(const double* h_eigvals, int K, const double* h_weights, int L, double* h_fS) {
+    if (!h_eigvals || !h_weights || !h_fS || K < 0 || L < 1) return NLE_ERR_INVALID;
+    for (int i = 0; i < K; ++i) {  // reference src/filter.cpp:338-344
+        double v = h_weights[0];
+        for (int k = 1; k < L; ++k) v += (h_weights[k] - h_weights[k - 1]) * std::pow(h_eigvals[i], (double)k);
+        h_fS[i] = v;
+    }
+    return NLE_OK;
+}
+
+int nle_layer_responses(const double* h_eigvals, int K, int L, double* h_resp) {
+    if (!h_eigvals || !h_resp || K < 0 || L < 1) return NLE_ERR_INVALID;
+    layer_resp(h_eigvals, K, L, h_resp);
+    return NLE_OK;
+}
+
+int nle_compute_kernel(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples, int n_col_samples,
+                       double hx, double hy, double* h_Ka, float* d_kab) {
+    if (!ctx || !d_lum) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        check_image_size(H, W);
+        if (n_row_samples > H || n_col_samples > W)
+            throw Fail{NLE_ERR_INVALID, "Number of samples per row and col must be <= that of image."};
+        GridSpec gs;
+        if (!make_grid(H, W, n_row_samples, n_col_samples, &gs)) throw Fail{NLE_ERR_INVALID, "invalid sample counts"};
+        HIP_OK(hipSetDevice(ctx->device));
+        SampleSet ss = fetch_samples(ctx, d_lum, gs);
+        if (h_Ka) {
+            std::vector<double> Ka = build_Ka(ss, hx, hy);
+            std::copy(Ka.begin(), Ka.end(), h_Ka);
+        }
+        if (d_kab) {
+            int row0, row1;
+            slab(H, ctx->rank, ctx->world, &row0, &row1);
+            DevBuf<float4> d_samples(ss.p);
+            HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), ss.p * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+            HIP_OK(nlek::affinity(ctx->stream, d_lum, gs, d_samples.p, ss.p, ld4(ss.p), (float)(1.0 / (hx * hx)),
+                                  (float)(1.0 / (hy * hy)), (long long)row0 * W, (long long)(row1 - row0) * W, d_kab));
+            HIP_OK(hipStreamSynchronize(ctx->stream));
+        }
+    });
+}
+
+int nle_nystrom(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples, int n_col_samples, double hx,
+                double hy, double* h_eigvals, int* r, float* d_phi) {
+    if (!ctx || !d_lum || !d_phi || !r) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        check_image_size(H, W);
+        if (n_row_samples > H || n_col_samples > W)
+            throw Fail{NLE_ERR_INVALID, "Number of samples per row and col must be <= that of image."};
+        GridSpec gs;
+        if (!make_grid(H, W, n_row_samples, n_col_samples, &gs)) throw Fail{NLE_ERR_INVALID, "invalid sample counts"};
+        HIP_OK(hipSetDevice(ctx->device));
+        SampleSet ss = fetch_samples(ctx, d_lum, gs);
+        std::vector<double> Ka = build_Ka(ss, hx, hy);
+        Nystrom ny = solve_Ka(Ka, ss.p);
+        int row0, row1;
+        slab(H, ctx->rank, ctx->world, &row0, &row1);
+        build_phi(ctx, d_lum, ss, ny, hx, hy, (long long)row0 * W, (long long)(row1 - row0) * W, d_phi);
+        *r = ny.r;
+        if (h_eigvals) std::copy(ny.lam.begin(), ny.lam.end(), h_eigvals);
+    });
+}
+
+int nle_ts_gemm(nle_ctx* ctx, const float* d_A, long long M, int lda, int kd, const double* h_B, int nc, float* d_C) {
+    if (!ctx || !d_A || !h_B || !d_C || M < 0 || kd < 1 || nc < 1 || lda < kd || (lda & 3)) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        const int ldc = ld4(nc);
+        std::vector<float> B((size_t)kd * ldc, 0.f);
+        for (int j = 0; j < nc; ++j)
+            for (int k = 0; k < kd; ++k) B[(size_t)k * ldc + j] = (float)h_B[(size_t)j * kd + k];
+        DevBuf<float> d_B(B.size());
+        HIP_OK(hipMemcpyAsync(d_B.p, B.data(), B.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        GridSpec gs{};
+        HIP_OK(nlek::ts_gemm(ctx->stream, false, d_A, lda, nullptr, gs, nullptr, 0.f, 0.f, 0, d_B.p, ldc, kd, d_C, ldc,
+                             M, nullptr, NLE_EPS));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int nle_sinkhorn_scalings(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r, const double* h_eigvals,
+                          int max_iter, double* h_u_c, double* h_u_r) {
+    if (!ctx || !d_phi || !h_eigvals || !h_u_c || !h_u_r || M < 0 || r < 1 || ld < r || (ld & 3)) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        std::vector<double> lam(h_eigvals, h_eigvals + r), uc, ur;
+        sinkhorn_passes(ctx, d_phi, M, ld, r, lam, max_iter, &uc, &ur, nullptr);
+        std::copy(uc.begin(), uc.end(), h_u_c);
+        std::copy(ur.begin(), ur.end(), h_u_r);
+    });
+}
+
+int nle_gram(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r, const double* h_u, double* h_G) {
+    if (!ctx || !d_phi || !h_u || !h_G || M < 0 || r < 1 || ld < r || (ld & 3)) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        std::vector<double> u(ld, 0.0);
+        std::copy(h_u, h_u + r, u.begin());
+        DevBuf<double> d_u(ld);
+        HIP_OK(hipMemcpyAsync(d_u.p, u.data(), ld * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        std::vector<double> G = gram_all(ctx, d_phi, M, ld, r, d_u.p);
+        std::copy(G.begin(), G.end(), h_G);
+    });
+}
+
+int nle_row_scalings(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r, const double* h_u, double* d_out) {
+    if (!ctx || !d_phi || !h_u || !d_out || M < 0 || r < 1 || ld < r || (ld & 3)) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        std::vector<double> u(ld, 0.0);
+        std::copy(h_u, h_u + r, u.begin());
+        DevBuf<double> d_u(ld);
+        HIP_OK(hipMemcpyAsync(d_u.p, u.data(), ld * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(nlek::row_scalings(ctx->stream, d_phi, M, ld, d_u.p, NLE_EPS, d_out));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int nle_train(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples, int n_col_samples, double hx,
+              double hy, int n_sinkhorn_iter, int n_eigen_vectors, nle_filter** out) {
+    if (!ctx || !d_lum || !out) return NLE_ERR_INVALID;
+    *out = nullptr;
+    return guard(ctx, [&] {
+        *out = train_impl(ctx, d_lum, H, W, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter, n_eigen_vectors);
+    });
+}
+
+int nle_train_host(nle_ctx* ctx, const float* h_lum, int H, int W, int n_row_samples, int n_col_samples, double hx,
+                   double hy, int n_sinkhorn_iter, int n_eigen_vectors, nle_filter** out) {
+    if (!ctx || !h_lum || !out) return NLE_ERR_INVALID;
+    *out = nullptr;
+    return guard(ctx, [&] {
+        check_image_size(H, W);
+        HIP_OK(hipSetDevice(ctx->device));
+        DevBuf<float> d_lum((size_t)H * W);
+        HIP_OK(hipMemcpyAsync(d_lum.p, h_lum, (size_t)H * W * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        *out = train_impl(ctx, d_lum.p, H, W, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter, n_eigen_vectors);
+    });
+}
+
+void nle_filter_destroy(nle_filter* f) {
+    if (!f) return;
+    if (f->d_V) (void)hipFree(f->d_V);
+    delete f;
+}
+
+int nle_filter_info(const nle_filter* f, long long* n_local, int* K, int* r, int* p, int* row0, int* row1) {
+    if (!f) return NLE_ERR_INVALID;
+    if (n_local) *n_local = f->n_local;
+    if (K) *K = f->K;
+    if (r) *r = f->r;
+    if (p) *p = f->p;
+    if (row0) *row0 = f->row0;
+    if (row1) *row1 = f->row1;
+    return NLE_OK;
+}
+
+int nle_filter_eigvals(const nle_filter* f, double* h_eigvals) {
+    if (!f || !h_eigvals) return NLE_ERR_INVALID;
+    std::copy(f->eigvals.begin(), f->eigvals.end(), h_eigvals);
+    return NLE_OK;
+}
+
+int nle_filter_eigvecs(const nle_filter* f, const float** d_V, int* ld) {
+    if (!f || !d_V || !ld) return NLE_ERR_INVALID;
+    *d_V = f->d_V;
+    *ld = f->ldv;
+    return NLE_OK;
+}
+
+int nle_filter_copy_eigvecs(const nle_filter* f, float* d_out) {
+    if (!f || !d_out) return NLE_ERR_INVALID;
+    return guard(f->ctx, [&] {
+        HIP_OK(hipSetDevice(f->ctx->device));
+        HIP_OK(hipMemcpyAsync(d_out, f->d_V, (size_t)f->n_local * f->ldv * sizeof(float), hipMemcpyDeviceToDevice,
+                              f->ctx->stream));
+        HIP_OK(hipStreamSynchronize(f->ctx->stream));
+    });
+}
+
+int nle_filter_timings(const nle_filter* f, double* h_ms) {
+    if (!f || !h_ms) return NLE_ERR_INVALID;
+    std::copy(f->ms, f->ms + 6, h_ms);
+    return NLE_OK;
+}
+
+int nle_apply(nle_filter* f, const float* d_x, int H, int W, const double* h_fS, float* d_y) {
+    if (!f || !d_x || !h_fS || !d_y) return NLE_ERR_INVALID;
+    return guard(f->ctx, [&] { apply_impl(f, d_x, H, W, h_fS, 1, d_y); });
+}
+
+int nle_apply_layers(nle_filter* f, const float* d_x, int H, int W, int L, float* d_y) {
+    if (!f || !d_x || !d_y || L < 1) return NLE_ERR_INVALID;
+    return guard(f->ctx, [&] {
+        std::vector<double> resp((size_t)L * f->K);
+        layer_resp(f->eigvals.data(), f->K, L, resp.data());
+        apply_impl(f, d_x, H, W, resp.data(), L, d_y);
+    });
+}
+
+static void apply_host_common(nle_filter* f, const float* h_x, int H, int W, const double* g, int L, float* h_y) {
+    nle_ctx* c = f->ctx;
+    if ((long long)H * W != (long long)f->H * f->W)
+        throw Fail{NLE_ERR_INVALID, "Number of values in channel must match that of training image."};
+    HIP_OK(hipSetDevice(c->device));
+    DevBuf<float> d_x((size_t)H * W), d_y((size_t)L * std::max<long long>(f->n_local, 1));
+    HIP_OK(hipMemcpyAsync(d_x.p, h_x, (size_t)H * W * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    apply_impl(f, d_x.p, H, W, g, L, d_y.p);
+    HIP_OK(hipMemcpyAsync(h_y, d_y.p, (size_t)L * f->n_local * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+}
+
+int nle_apply_host(nle_filter* f, const float* h_x, int H, int W, const double* h_fS, float* h_y) {
+    if (!f || !h_x || !h_fS || !h_y) return NLE_ERR_INVALID;
+    return guard(f->ctx, [&] { apply_host_common(f, h_x, H, W, h_fS, 1, h_y); });
+}
+
+int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, float* h_y) {
+    if (!f || !h_x || !h_y || L < 1) return NLE_ERR_INVALID;
+    return guard(f->ctx, [&] {
+        std::vector<double> resp((size_t)L * f->K);
+        layer_resp(f->eigvals.data(), f->K, L, resp.data());
+        apply_host_common(f, h_x, H, W, resp.data(), L, h_y);
+    });
+}
+
+int nle_bench_affinity(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples, int n_col_samples, double hx,
+                       double hy, float* d_kab, int reps, double* h_avg_ms) {
+    if (!ctx || !d_lum || !d_kab || reps < 1 || !h_avg_ms) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        check_image_size(H, W);
+        GridSpec gs;
+        if (!make_grid(H, W, n_row_samples, n_col_samples, &gs)) throw Fail{NLE_ERR_INVALID, "invalid sample counts"};
+        HIP_OK(hipSetDevice(ctx->device));
+        SampleSet ss = fetch_samples(ctx, d_lum, gs);
+        int row0, row1;
+        slab(H, ctx->rank, ctx->world, &row0, &row1);
+        DevBuf<float4> d_samples(ss.p);
+        HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), ss.p * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        const float sw = (float)(1.0 / (hx * hx)), pw = (float)(1.0 / (hy * hy));
+        const long long pix0 = (long long)row0 * W, M = (long long)(row1 - row0) * W;
+        HIP_OK(nlek::affinity(ctx->stream, d_lum, gs, d_samples.p, ss.p, ld4(ss.p), sw, pw, pix0, M, d_kab));
+        Timer tm(ctx->stream);
+        tm.start();
+        for (int i = 0; i < reps; ++i)
+            HIP_OK(nlek::affinity(ctx->stream, d_lum, gs, d_samples.p, ss.p, ld4(ss.p), sw, pw, pix0, M, d_kab));
+        tm.stop();
+        *h_avg_ms = tm.ms() / reps;
+    });
+}
+
+int nle_bench_sinkhorn_pass(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r, int reps, double* h_avg_ms) {
+    if (!ctx || !d_phi || reps < 1 || !h_avg_ms || M < 1 || r < 1 || ld < r || (ld & 3)) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        std::vector<double> ones(ld, 1.0);
+        DevBuf<double> d_lam(ld), d_t(ld), d_partial((size_t)nlek::kRowpassMaxBlocks * ld);
+        HIP_OK(hipMemcpyAsync(d_lam.p, ones.data(), ld * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(hipMemcpyAsync(d_t.p, ones.data(), ld * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        int nb = 0;
+        HIP_OK(nlek::rowpass(ctx->stream, nlek::ROWPASS_RECIP, d_phi, M, ld, d_t.p, d_lam.p, nullptr, NLE_EPS, d_partial.p, &nb));
+        Timer tm(ctx->stream);
+        tm.start();
+        for (int i = 0; i < reps; ++i)
+            HIP_OK(nlek::rowpass(ctx->stream, nlek::ROWPASS_RECIP, d_phi, M, ld, d_t.p, d_lam.p, nullptr, NLE_EPS, d_partial.p, &nb));
+        tm.stop();
+        *h_avg_ms = tm.ms() / reps;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,456 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+A literal fp64 numpy restatement of the nonlocal-filter hot path of
+lightalchemist/nonlocal-image-edit (reference tree `/root/reference`, cited as
+`src/filter.cpp:LINE`).  It exists to CHECK the MI355X HIP path, never to be it:
+only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this module.  The product (`nonlocal-image-edit_amd/`) never does.
+
+Pinning (see DESIGN.md "Oracle"):
+  * The reference cannot be compiled here (needs Eigen3 + OpenCV, neither in the
+    image -- an ordinary missing dependency), so there is no
+    `oracle/_ref`.
+  * This restatement is pinned by the reference's own unit tests
+    (`test/test_filter.cpp`: 3x3 eigen KAT, Sinkhorn row/col-sum properties,
+    orthogonalize V^T V = I, conversion order) -- `tests/test_oracle_reference_cases.py`
+    -- and loosely end-to-end by the README pair flower-50.bmp -> flower-filtered.png
+    (`README.md:74`), `tests/test_oracle_flower.py`.
+  * `computeKernel`, `nystromApproximation`, `transformEigenValues`, `apply` have no
+    reference unit test: for those the only pin is the README pair ("loose").
+
+Third-party arithmetic restated: Eigen `SelfAdjointEigenSolver` (lower triangle,
+ascending) -> `numpy.linalg.eigh(UPLO="L")`; Eigen dense products -> numpy matmul.
+Everything is fp64 like the reference (`include/filter.hpp:10-14`).
+
+Two forms are provided:
+  * the LITERAL form: the reference's `[selected; rest]` row order and its N x p
+    temporaries (`compute_kernel` ... `train_filter`), usable up to ~1 MP;
+  * the STREAMING form (`train_filter_streaming`): same math in natural pixel order,
+    tiled over pixels, never holding N x p -- this is the CPU baseline for 2048^2+ and
+    mirrors the decomposition the GPU path uses (and, with `shard=(g, G)`, the
+    per-rank slab decomposition of the multi-GPU path).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+EPS = 1e-10  # include/filter.hpp:14
+
+
+# --------------------------------------------------------------------------- helpers
+def inplace_reciprocal(v: np.ndarray, eps: float = EPS):
+    """src/filter.cpp:42-54 -- 1/v where |v| >= eps, else 0; returns (out, nnz)."""
+    v = np.asarray(v, dtype=np.float64)
+    mask = np.abs(v) >= eps
+    out = np.zeros_like(v)
+    out[mask] = 1.0 / v[mask]
+    return out, int(mask.sum())
+
+
+def sample_grid(nrows: int, ncols: int, n_row_samples: int, n_col_samples: int):
+    """Closed form of the predicate in `samplePixels`, src/filter.cpp:56-71.
+
+    Returns (sel_rows, sel_cols): the selected pixel set is their Cartesian product.
+    C++ int division truncates toward zero; all operands here are non-negative.
+    """
+    row_step = nrows // n_row_samples
+    col_step = ncols // n_col_samples
+    row_off = (row_step - 1 + (nrows - row_step * n_row_samples)) // 2
+    col_off = (col_step - 1 + (ncols - col_step * n_col_samples)) // 2
+    r = np.arange(nrows)
+    c = np.arange(ncols)
+    sel_r = r[(r >= row_off) & (r <= nrows - row_off) & ((r - row_off) % row_step == 0)]
+    sel_c = c[(c >= col_off) & (c <= ncols - col_off) & ((c - col_off) % col_step == 0)]
+    return sel_r, sel_c
+
+
+def sample_pixels(nrows: int, ncols: int, n_row_samples: int, n_col_samples: int):
+    """src/filter.cpp:56-80 -- (selected, rest) as flat row-major pixel indices, both in
+    row-major scan order."""
+    sel_r, sel_c = sample_grid(nrows, ncols, n_row_samples, n_col_samples)
+    mask = np.zeros((nrows, ncols), dtype=bool)
+    mask[np.ix_(sel_r, sel_c)] = True
+    flat = mask.ravel()
+    idx = np.arange(nrows * ncols)
+    return idx[flat], idx[~flat]
+
+
+def _neg_weighted_distance(img, rows_a, cols_a, vals_a, rows_b, cols_b, vals_b, sw, pw):
+    """src/filter.cpp:104-112, vectorised: spatial term in integers then promoted."""
+    dr = rows_a[:, None].astype(np.int64) - rows_b[None, :].astype(np.int64)
+    dc = cols_a[:, None].astype(np.int64) - cols_b[None, :].astype(np.int64)
+    sq_sp = (dr * dr + dc * dc).astype(np.float64)
+    di = vals_a[:, None] - vals_b[None, :]
+    return -sw * sq_sp - pw * (di * di)
+
+
+# --------------------------------------------------------------------- literal stages
+def compute_kernel(mat: np.ndarray, n_row_samples: int, n_col_samples: int,
+                   hx: float, hy: float, chunk: int = 1 << 16):
+    """`computeKernel`, src/filter.cpp:114-167.
+
+    mat: H x W fp64 luminance.  Returns (perm, Ka, Kab): perm[i] = row-major index of
+    the i-th pixel in [selected; rest] order (`P.indices()`, :156-164); Ka p x p;
+    Kab p x (N-p).
+    """
+    mat = np.asarray(mat, dtype=np.float64)
+    H, W = mat.shape
+    if n_row_samples > H or n_col_samples > W:  # :117-119
+        raise RuntimeError("Number of samples per row and col must be <= that of image.")
+    sel, rest = sample_pixels(H, W, n_row_samples, n_col_samples)
+    pw = 1.0 / (hy * hy)  # :128
+    sw = 1.0 / (hx * hx)  # :129
+    flat = mat.ravel()
+    sr, sc, sv = sel // W, sel % W, flat[sel]
+    Ka = np.exp(_neg_weighted_distance(mat, sr, sc, sv, sr, sc, sv, sw, pw))  # :133-137,144
+    Kab = np.empty((sel.size, rest.size), dtype=np.float64)
+    for s in range(0, rest.size, chunk):  # :139-141,145
+        rr = rest[s:s + chunk]
+        Kab[:, s:s + chunk] = np.exp(
+            _neg_weighted_distance(mat, sr, sc, sv, rr // W, rr % W, flat[rr], sw, pw))
+    perm = np.concatenate([sel, rest])
+    return perm, Ka, Kab
+
+
+def eigen_decomposition(M: np.ndarray, eps: float = EPS):
+    """`eigenDecomposition`, src/filter.cpp:204-228: lower-triangle symmetric eigensolve,
+    descending order, keep the leading run with D >= eps.  Returns (U, D)."""
+    M = np.asarray(M, dtype=np.float64)
+    w, v = np.linalg.eigh(M, UPLO="L")
+    D = w[::-1]
+    U = v[:, ::-1]
+    r = 0
+    while r < D.size and D[r] >= eps:  # :214
+        r += 1
+    return np.ascontiguousarray(U[:, :r]), D[:r].copy()
+
+
+def nystrom_approximation(Ka: np.ndarray, Kab: np.ndarray):
+    """`nystromApproximation`, src/filter.cpp:257-280.  Returns (eigvals (r), phi (N x r)),
+    phi = [V ; Kab^T V diag(1/lambda)] in [selected; rest] order."""
+    eigvecs, eigvals = eigen_decomposition(Ka)
+    inv, nnz = inplace_reciprocal(eigvals)  # :265-266
+    eigvecs = eigvecs[:, :nnz]  # :269
+    eigvals = eigvals[:nnz]  # :271
+    phi = np.vstack([eigvecs, (Kab.T @ eigvecs) * inv[:nnz][None, :]])  # :275
+    return eigvals, phi
+
+
+def sinkhorn(phi: np.ndarray, eigvals: np.ndarray, max_iter: int = 10):
+    """`sinkhorn`, src/filter.cpp:230-254.  Returns (Wa q x q, Wab q x (N-q)), q = phi.cols()."""
+    Wa, Wab, _, _ = sinkhorn_with_scalings(phi, eigvals, max_iter)
+    return Wa, Wab
+
+
+def sinkhorn_with_scalings(phi, eigvals, max_iter=10):
+    phi = np.asarray(phi, dtype=np.float64)
+    eigvals = np.asarray(eigvals, dtype=np.float64)
+    n = phi.shape[0]
+    r = np.ones(n)
+    c = np.zeros(n)
+    for _ in range(max_iter):  # :238-245
+        c, _ = inplace_reciprocal(phi @ (eigvals * (phi.T @ r)))
+        r, _ = inplace_reciprocal(phi @ (eigvals * (phi.T @ c)))
+    p = phi.shape[1]  # :247  (q = number of retained eigenpairs, NOT the sample count)
+    left = (r[:p, None] * (phi[:p] * eigvals[None, :]))  # R * (phi_top * D)
+    Wa = left @ (c[:p, None] * phi[:p]).T  # :249
+    Wab = left @ (c[p:, None] * phi[p:]).T  # :250
+    return Wa, Wab, r, c
+
+
+def orthogonalize(Wa: np.ndarray, Wab: np.ndarray, n_eig_vectors: int = 5, eps: float = EPS):
+    """`orthogonalize`, src/filter.cpp:282-331, default (non-Spectra) branch :313-316.
+    Returns (V (N x K'), Sq (K'))."""
+    eigvecs, eigvals = eigen_decomposition(Wa)  # :287
+    inv_root, _ = inplace_reciprocal(eigvals)  # :289-291
+    inv_root = np.sqrt(inv_root)
+    inv_root_wa = (eigvecs * inv_root[None, :]) @ eigvecs.T  # :292
+    Q = Wa + inv_root_wa @ (Wab @ Wab.T) @ inv_root_wa  # :296
+    Vq, Sq = eigen_decomposition(Q)  # :313
+    k = min(n_eig_vectors, Vq.shape[1])  # :314
+    Vq, Sq = Vq[:, :k], Sq[:k]
+    inv_root_sq, _ = inplace_reciprocal(Sq)  # :319-321
+    inv_root_sq = np.sqrt(inv_root_sq)
+    tmp = np.vstack([Wa, Wab.T])  # :324-325
+    V = ((tmp @ inv_root_wa) @ Vq) * inv_root_sq[None, :]  # :327 (left-associative)
+    return V, Sq
+
+
+def transform_eigenvalues(eigvals: np.ndarray, weights) -> np.ndarray:
+    """`transformEigenValues`, src/filter.cpp:334-347."""
+    eigvals = np.asarray(eigvals, dtype=np.float64)
+    fS = np.full(eigvals.shape, float(weights[0]))
+    for k in range(1, len(weights)):
+        fS = fS + (weights[k] - weights[k - 1]) * np.power(eigvals, float(k))
+    return fS
+
+
+def layer_responses(eigvals: np.ndarray, n_layers: int) -> np.ndarray:
+    """Spectral response of each layer implied by `transformEigenValues` (:334-347):
+    detail layer j <-> lambda^j - lambda^(j+1), base layer <-> lambda^(L-1).
+    sum_j w_j * response_j == transform_eigenvalues(eigvals, w).  Shape (L, K)."""
+    eigvals = np.asarray(eigvals, dtype=np.float64)
+    out = np.empty((n_layers, eigvals.size))
+    for j in range(n_layers - 1):
+        out[j] = np.power(eigvals, float(j)) - np.power(eigvals, float(j + 1))
+    out[n_layers - 1] = np.power(eigvals, float(n_layers - 1))
+    return out
+
+
+def train_filter(channel: np.ndarray, n_row_samples: int, n_col_samples: int,
+                 hx: float, hy: float, n_sinkhorn_iter: int, n_eigen_vectors: int,
+                 return_intermediates: bool = False):
+    """`NLEFilter::trainFilter`, src/filter.cpp:480-502 (GUI loop :504-511 omitted).
+    Returns (eigvecs N x K' in PIXEL order, eigvals K')."""
+    perm, Ka, Kab = compute_kernel(channel, n_row_samples, n_col_samples, hx, hy)
+    eigvals, phi = nystrom_approximation(Ka, Kab)
+    del Kab
+    Wa, Wab, r_vec, c_vec = sinkhorn_with_scalings(phi, eigvals, n_sinkhorn_iter)
+    V, S = orthogonalize(Wa, Wab, n_eigen_vectors)
+    out = np.empty_like(V)
+    out[perm] = V  # :502  (P*V).row(P.indices[i]) = V.row(i)
+    if return_intermediates:
+        return out, S, dict(perm=perm, Ka=Ka, lam=eigvals, phi=phi, Wa=Wa, r=r_vec, c=c_vec)
+    return out, S
+
+
+def apply_filter(eigvecs: np.ndarray, channel: np.ndarray, f_s: np.ndarray) -> np.ndarray:
+    """`NLEFilter::apply`, src/filter.cpp:445-458: y = V (diag(fS) V^T x)."""
+    if channel.size != eigvecs.shape[0]:  # :447-449
+        raise RuntimeError("Number of values in channel must match that of training image.")
+    x = np.asarray(channel, dtype=np.float64).ravel()  # row-major flatten, utils.hpp:28-41
+    return (eigvecs @ (f_s * (eigvecs.T @ x))).reshape(channel.shape)
+
+
+def apply_layers(eigvecs, eigvals, channel, n_layers: int) -> np.ndarray:
+    """Per-layer outputs y_j = V (resp_j o (V^T x)); shape (L, H, W).  The reference only
+    forms sum_j w_j y_j (:428-431); the 1e-4 per-detail-layer bar compares these."""
+    x = np.asarray(channel, dtype=np.float64).ravel()
+    t = eigvecs.T @ x
+    resp = layer_responses(eigvals, n_layers)
+    return np.stack([(eigvecs @ (resp[j] * t)).reshape(channel.shape) for j in range(n_layers)])
+
+
+# ------------------------------------------------------------------ streaming form
+def _affinity_rows(lum_flat, W, idx, sr, sc, sv, sw, pw):
+    """k_i = exp(negDist(pixel i, sample s)) for a block of pixels: (len(idx), p)."""
+    rr, cc = idx // W, idx % W
+    dr = rr[:, None] - sr[None, :]
+    dc = cc[:, None] - sc[None, :]
+    sq = (dr * dr + dc * dc).astype(np.float64)
+    di = lum_flat[idx][:, None] - sv[None, :]
+    return np.exp(-sw * sq - pw * di * di)
+
+
+def train_filter_streaming(channel, n_row_samples, n_col_samples, hx, hy,
+                           n_sinkhorn_iter, n_eigen_vectors, tile: int = 1 << 15,
+                           shard=(0, 1), allreduce=None, phi_dtype=np.float64):
+    """Same math as `train_filter` in NATURAL pixel order, tiled over pixels.
+
+    Follows src/filter.cpp:480-502 stage by stage; algebra used to avoid N x p / N x q
+    temporaries (all exact identities):
+      * phi_i = k_i^T V_A diag(1/lambda) for every non-sample pixel (:275); sample pixels
+        take their exact V_A row (:275, top block);
+      * Sinkhorn (:238-245) as t = Phi^T y, u = lambda o t, y_i = recip(phi_i . u);
+      * Wab Wab^T (:296) = M^T G M with G = sum_{i in B} c_i^2 phi_i phi_i^T,
+        M = diag(lambda) Phi_A^T diag(r_A);
+      * V_B (:327) = diag(c_B) Phi_B (M S Vq Sq^-1/2); V_A = Wa (S Vq Sq^-1/2).
+    The "A block" is the first q = r permuted rows = the first q samples (:247).
+
+    shard=(g, G): only pixel rows [g*H/G, (g+1)*H/G) are processed; `allreduce(x)` must
+    then return the sum of x over all G shards (fp64).  Returns (V_local, S) where
+    V_local covers this shard's pixels (natural order).
+    """
+    channel = np.asarray(channel, dtype=np.float64)
+    H, W = channel.shape
+    if n_row_samples > H or n_col_samples > W:
+        raise RuntimeError("Number of samples per row and col must be <= that of image.")
+    if allreduce is None:
+        allreduce = lambda x: x
+    g, G = shard
+    row0, row1 = slab_rows(H, g, G)
+    lo, hi = row0 * W, row1 * W
+    flat = channel.ravel()
+    sel_r, sel_c = sample_grid(H, W, n_row_samples, n_col_samples)
+    sr = np.repeat(sel_r, sel_c.size)
+    sc = np.tile(sel_c, sel_r.size)
+    sel = sr * W + sc  # row-major order == permuted order of the samples
+    sv = flat[sel]
+    sw, pw = 1.0 / (hx * hx), 1.0 / (hy * hy)
+    Ka = np.exp(_neg_weighted_distance(channel, sr, sc, sv, sr, sc, sv, sw, pw))
+    VA, lam = eigen_decomposition(Ka)
+    inv, nnz = inplace_reciprocal(lam)
+    VA, lam, inv = VA[:, :nnz], lam[:nnz], inv[:nnz]
+    r_ = lam.size
+    B = VA * inv[None, :]
+
+    # Phi for this shard (natural order), sample rows overwritten with exact V_A rows
+    nloc = hi - lo
+    phi = np.empty((nloc, r_), dtype=phi_dtype)
+    for s in range(lo, hi, tile):
+        idx = np.arange(s, min(s + tile, hi))
+        phi[s - lo:s - lo + idx.size] = _affinity_rows(flat, W, idx, sr, sc, sv, sw, pw) @ B
+    own = (sel >= lo) & (sel < hi)
+    phi[sel[own] - lo] = VA[own]
+
+    def pass_dot(u):
+        return np.concatenate([phi[s:s + tile].astype(np.float64) @ u
+                               for s in range(0, nloc, tile)]) if nloc else np.zeros(0)
+
+    def pass_tsum(y):
+        t = np.zeros(r_)
+        for s in range(0, nloc, tile):
+            t += phi[s:s + tile].astype(np.float64).T @ y[s:s + tile]
+        return allreduce(t)
+
+    t = pass_tsum(np.ones(nloc))
+    u_c = u_r = None
+    for _ in range(n_sinkhorn_iter):
+        u_c = lam * t
+        c, _ = inplace_reciprocal(pass_dot(u_c))
+        t = pass_tsum(c)
+        u_r = lam * t
+        rv, _ = inplace_reciprocal(pass_dot(u_r))
+        t = pass_tsum(rv)
+    if n_sinkhorn_iter == 0:
+        raise RuntimeError("streaming oracle needs nSinkhornIter >= 1")
+
+    q = r_
+    A = sel[:q]  # pixel indices of the A block
+    phiA = VA[:q]
+    cA, _ = inplace_reciprocal(phiA @ u_c)
+    rA, _ = inplace_reciprocal(phiA @ u_r)
+    left = rA[:, None] * (phiA * lam[None, :])
+    Wa = left @ (cA[:, None] * phiA).T
+    M = left.T  # r x q : diag(lam) PhiA^T diag(rA)
+
+    in_A = np.zeros(nloc, dtype=bool)
+    ownA = (A >= lo) & (A < hi)
+    in_A[A[ownA] - lo] = True
+    c_loc, _ = inplace_reciprocal(pass_dot(u_c))
+    c_loc[in_A] = 0.0
+    Gm = np.zeros((r_, r_))
+    for s in range(0, nloc, tile):
+        z = phi[s:s + tile].astype(np.float64) * c_loc[s:s + tile, None]
+        Gm += z.T @ z
+    Gm = allreduce(Gm)
+
+    U2, l2 = eigen_decomposition(Wa)
+    ir, _ = inplace_reciprocal(l2)
+    S = (U2 * np.sqrt(ir)[None, :]) @ U2.T
+    Q = Wa + S @ (M.T @ Gm @ M) @ S
+    Vq, Sq = eigen_decomposition(Q)
+    k = min(n_eigen_vectors, Vq.shape[1])
+    Vq, Sq = Vq[:, :k], Sq[:k]
+    irs, _ = inplace_reciprocal(Sq)
+    T2 = (S @ Vq) * np.sqrt(irs)[None, :]  # q x K
+    Cproj = M @ T2  # r x K
+    V = np.empty((nloc, k))
+    for s in range(0, nloc, tile):
+        V[s:s + tile] = (phi[s:s + tile].astype(np.float64) * c_loc[s:s + tile, None]) @ Cproj
+    V[A[ownA] - lo] = (Wa @ T2)[ownA]
+    return V, Sq
+
+
+def slab_rows(H: int, g: int, G: int):
+    """Image-row slab owned by shard g of G: rows [g*H//G, (g+1)*H//G)."""
+    return (g * H) // G, ((g + 1) * H) // G
+
+
+def apply_layers_streaming(V_local, eigvals, x_local, n_layers, allreduce=None):
+    """Sharded apply: t = allreduce(V_local^T x_local); y_j = V_local (resp_j o t)."""
+    if allreduce is None:
+        allreduce = lambda x: x
+    t = allreduce(V_local.T @ np.asarray(x_local, dtype=np.float64).ravel())
+    resp = layer_responses(eigvals, n_layers)
+    return np.stack([V_local @ (resp[j] * t) for j in range(n_layers)])
+
+
+# ------------------------------------------------------------------ synthetic input
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def synthetic_luminance(H: int, W: int, seed: int = 1234) -> np.ndarray:
+    """SURVEY.md section 8d synthetic input: integer-valued 0..255 (like 8-bit Lab L),
+    L = clip(round(128 + 70 s(r/H, c/W) + 40 (u - 1/2))),
+    s(a,b) = 1/2 sin(2 pi (1.5a + 0.5b)) + 1/2 cos(2 pi (0.7a - 2.2b)),
+    u = splitmix64((r*W+c) xor seed) mapped to [0,1)."""
+    r = np.arange(H, dtype=np.float64)[:, None] / H
+    c = np.arange(W, dtype=np.float64)[None, :] / W
+    s = 0.5 * np.sin(2 * np.pi * (1.5 * r + 0.5 * c)) + 0.5 * np.cos(2 * np.pi * (0.7 * r - 2.2 * c))
+    idx = (np.arange(H, dtype=np.uint64)[:, None] * np.uint64(W)
+           + np.arange(W, dtype=np.uint64)[None, :])
+    with np.errstate(over="ignore"):
+        h = _splitmix64(idx ^ np.uint64(seed))
+    u = (h >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    return np.clip(np.rint(128.0 + 70.0 * s + 40.0 * (u - 0.5)), 0, 255)
+
+
+# ------------------------------------------------------------------- colour wrapper
+def _srgb_to_linear(c):
+    return np.where(c <= 0.04045, c / 12.92, np.power((c + 0.055) / 1.055, 2.4))
+
+
+def _linear_to_srgb(c):
+    return np.where(c <= 0.0031308, 12.92 * c, 1.055 * np.power(np.maximum(c, 0), 1 / 2.4) - 0.055)
+
+
+_XN, _ZN = 0.950456, 1.088754
+_M = np.array([[0.412453, 0.357580, 0.180423],
+               [0.212671, 0.715160, 0.072169],
+               [0.019334, 0.119193, 0.950227]])
+
+
+def bgr_to_lab8(bgr: np.ndarray) -> np.ndarray:
+    """8-bit BGR -> 8-bit Lab as `cv::cvtColor(COLOR_BGR2Lab)` documents it
+    (src/filter.cpp:423,463): sRGB decode, XYZ (D65), L*a*b*, then L*255/100, a+128,
+    b+128, rounded.  OpenCV's own 8-bit path is a fixed-point table implementation whose
+    rounding is version dependent ("parity unpinned"): this float
+    restatement agrees to about one grey level."""
+    rgb = bgr[..., ::-1].astype(np.float64) / 255.0
+    lin = _srgb_to_linear(rgb)
+    xyz = lin @ _M.T
+    x, y, z = xyz[..., 0] / _XN, xyz[..., 1], xyz[..., 2] / _ZN
+    f = lambda t: np.where(t > 0.008856, np.cbrt(t), 7.787 * t + 16.0 / 116.0)
+    L = np.where(y > 0.008856, 116.0 * np.cbrt(y) - 16.0, 903.3 * y)
+    a = 500.0 * (f(x) - f(y))
+    b = 200.0 * (f(y) - f(z))
+    lab = np.stack([L * 255.0 / 100.0, a + 128.0, b + 128.0], axis=-1)
+    return np.clip(np.rint(lab), 0, 255).astype(np.uint8)
+
+
+def lab8_to_bgr(lab: np.ndarray) -> np.ndarray:
+    """Inverse of `bgr_to_lab8` (`COLOR_Lab2BGR`, src/filter.cpp:440)."""
+    L = lab[..., 0].astype(np.float64) * 100.0 / 255.0
+    a = lab[..., 1].astype(np.float64) - 128.0
+    b = lab[..., 2].astype(np.float64) - 128.0
+    fy = (L + 16.0) / 116.0
+    y = np.where(L > 7.9996248, fy ** 3, L / 903.3)
+    fy = np.where(L > 7.9996248, fy, 7.787 * y + 16.0 / 116.0)
+    fx = a / 500.0 + fy
+    fz = fy - b / 200.0
+    finv = lambda t: np.where(t > 0.206893, t ** 3, (t - 16.0 / 116.0) / 7.787)
+    xyz = np.stack([finv(fx) * _XN, y, finv(fz) * _ZN], axis=-1)
+    lin = xyz @ np.linalg.inv(_M).T
+    rgb = _linear_to_srgb(np.clip(lin, 0, 1))
+    return np.clip(np.rint(rgb[..., ::-1] * 255.0), 0, 255).astype(np.uint8)
+
+
+def enhance_image(bgr: np.ndarray, n_row_samples, n_col_samples, hx, hy,
+                  n_sinkhorn_iter, n_eigen_vectors, weights) -> np.ndarray:
+    """`trainForEnhancement` + `enhance`, src/filter.cpp:514-519, 412-443."""
+    if bgr.ndim != 3 or bgr.shape[2] != 3:
+        raise RuntimeError("Can only enhance RGB image.")  # :414-416
+    lab = bgr_to_lab8(bgr)
+    L = lab[..., 0].astype(np.float64)
+    V, S = train_filter(L, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter, n_eigen_vectors)
+    y = apply_filter(V, L, transform_eigenvalues(S, weights))
+    y = np.clip(y, 0, 255)  # :434-435
+    lab2 = lab.copy()
+    lab2[..., 0] = np.rint(y).astype(np.uint8)  # convertTo(CV_8U): round-half-even, :436
+    return lab8_to_bgr(lab2)
