@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: megapixels/s end-to-end enhance (BASELINE.json `metric`).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one synthetic luminance plane that is already
+resident in HBM: NLEFilter::trainFilter (affinity blocks -> Nystrom -> Sinkhorn -> orthogonalise)
+followed by the per-layer spectral recomposition (NLEFilter::apply, one output plane per layer),
+through the C ABI of libnle_hip.so.  Workload = BASELINE.json configs[3] ("cfg4": 4096x4096,
+20x10 = 200 samples, K = 50, T = 10, L = 4), the configuration the metric is quoted on.
+
+N > 1: the SAME image is sharded by image-row slabs over the ranks (strong scaling); the only
+exchange steps are the small fp64 all-reduces of the Sinkhorn column sums, the Gram partials and
+V^T x (torch.distributed "nccl" == RCCL over xGMI).
+
+The JSON line also carries
+  roofline      the dominant kernel of the timed region: algorithmic bytes (or flops) per launch
+                divided by its average launch duration, measured with HIP events recorded on the
+                stream the kernels run on (nle_ctx_profile), against the MI355X peak;
+  cpu_baseline  the fp64 numpy oracle (a port of the reference's algorithm) timed on this box's
+                host cores on a bounded sample (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
+
+
+def roofline_models(cfg, info, L):
+    """kernel name -> (bound, algorithmic units per launch, unit) from SURVEY.md section 8(d)
+    (fp32 storage, s = 4 B), per rank (n = pixels of this rank's slab)."""
+    n, r, p, K = info["n_local"], info["r"], info["p"], info["K"]
+    s = 4.0
+    return {
+        # B_C / (2T): one read of Phi (n x r) per half-iteration
+        "sinkhorn_pass": ("hbm", n * r * s, "B"),
+        # F_B = 2 N p r
+        "nystrom_extend": ("mfma", 2.0 * n * p * r, "FLOP"),
+        # F_D = 2 N r^2
+        "gram": ("mfma", 2.0 * n * r * r, "FLOP"),
+        # F_E = 2 N r K
+        "project": ("mfma", 2.0 * n * r * K, "FLOP"),
+        # B_F split over its two passes: read V + x ; read V, write L planes
+        "apply_reduce": ("hbm", n * s * (K + 1), "B"),
+        "apply_expand": ("hbm", n * s * (K + L), "B"),
+        # B_A = N s (1 + p)
+        "affinity": ("hbm", n * s * (1 + p), "B"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="side of the CPU-baseline sample image")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist = dist_mod
+
+    nle = entry.load_package()
+    from importlib import import_module  # noqa: F401
+    synth = entry._load("nle_amd_synthetic", os.path.join(entry.PKG_DIR, "synthetic.py"))
+    cfg = dict(synth.CONFIGS[args.config])
+    H, W, L = cfg["H"], cfg["W"], cfg["L"]
+
+    ctx = nle.Context(local_rank)
+    g = nle.sample_grid(H, W, cfg["n_row"], cfg["n_col"])
+    p = g["n_sel_rows"] * g["n_sel_cols"]
+    if world > 1:
+        ctx.set_shard(rank, world, p, lambda t: dist.all_reduce(t))
+
+    lum = torch.as_tensor(synth.synthetic_luminance(H, W).astype(np.float32), device=f"cuda:{local_rank}")
+    n_local = ctx.local_pixels(H, W)
+    out = torch.empty((L, n_local), dtype=torch.float32, device=lum.device)
+    flt = nle.NLEFilter(ctx)
+
+    def step():
+        flt.train_filter(lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"])
+        flt.apply_layers(lum, L, out=out)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    stats = ctx.kernel_stats()
+    ctx.profile(False)
+    info = flt.info()
+    stage_ms = flt.timings()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=lum.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = (H * W / 1e6) / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel (this rank's launches)
+    models = roofline_models(cfg, info, L)
+    per_kernel = {}
+    for name, (launches, total_ms) in stats.items():
+        if launches == 0:
+            continue
+        avg_ms = total_ms / launches
+        rec = {"launches_per_step": launches / args.steps, "avg_ms": avg_ms, "total_ms_per_step": total_ms / args.steps}
+        if name in models:
+            bound, units, _ = models[name]
+            if bound == "hbm":
+                ach, peak, unit = units / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+            else:
+                ach, peak, unit = units / (avg_ms * 1e-3) / 1e12, FP32_MFMA_PEAK_TF, "TFLOP/s"
+            rec.update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
+        per_kernel[name] = rec
+    dom = max((k for k in per_kernel if "bound" in per_kernel[k]), key=lambda k: per_kernel[k]["total_ms_per_step"])
+    d = per_kernel[dom]
+    roofline = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
+                "frac": d["frac"], "traffic": None, "avg_launch_ms": d["avg_ms"],
+                "launches_per_step": d["launches_per_step"]}
+
+    # ---- CPU baseline: the fp64 numpy oracle on a bounded sample (rank 0, N = 1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        oracle = entry.load_oracle()
+        Hs = Ws = args.cpu_sample
+        xs = synth.synthetic_luminance(Hs, Ws)
+        tc0 = time.perf_counter()
+        V_o, S_o = oracle.train_filter_streaming(xs, cfg["n_row"], cfg["n_col"], Ws / 4.0, cfg["hy"], cfg["T"], cfg["K"])
+        oracle.apply_layers_streaming(V_o, S_o, xs, L)
+        tc = time.perf_counter() - tc0
+        cpu = {"value": (Hs * Ws / 1e6) / tc, "unit": "MP/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": f"{Hs}x{Ws} synthetic, same samples/K/T/L as the workload, streaming fp64 numpy oracle "
+                         f"(OpenBLAS threads = all cores), {tc:.1f} s"}
+
+    if rank == 0:
+        line = {
+            "metric": "megapixels/sec end-to-end enhance (4K img, m=200, K=50)",
+            "value": value, "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {H}x{W} synthetic luminance, {cfg['n_row']}x{cfg['n_col']} samples "
+                                   f"(p={p}), K={cfg['K']}, T={cfg['T']}, L={L} layers; input resident in HBM",
+                       "parallelism": f"row-slab x{world}" if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": per_kernel,
+            "stage_ms_last_step": stage_ms,
+        }
+        print(json.dumps(line), flush=True)
+    flt.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -159,6 +159,25 @@ int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, 
 int nle_ld(int n);
 
 /* ---- measurement hooks (bench.py) --------------------------------------------------- */
+/* Kernel ids for the per-kernel HIP-event timing below. */
+enum {
+    NLE_K_AFFINITY = 0,      /* materialising affinity pass (stage API: computeKernel)   */
+    NLE_K_NYSTROM = 1,       /* affinity-fused Nystrom extension GEMM (Phi)              */
+    NLE_K_SINKHORN_PASS = 2, /* one Sinkhorn half-iteration over all local pixels        */
+    NLE_K_REDUCE = 3,        /* second-stage fp64 reduction of block partials            */
+    NLE_K_GRAM = 4,          /* Gram contraction                                         */
+    NLE_K_PROJECT = 5,       /* projection GEMM  V = diag(c) Phi C                       */
+    NLE_K_APPLY_REDUCE = 6,  /* t = V^T x                                                */
+    NLE_K_APPLY_EXPAND = 7,  /* y_l = V (g_l o t)                                        */
+    NLE_K_SMALL = 8,         /* everything p/r/K-sized on the device                     */
+    NLE_KERNEL_COUNT = 9
+};
+const char* nle_kernel_name(int kid);
+/* enable != 0: bracket every kernel launch of the ctx with HIP events recorded on the ctx's
+ * stream and accumulate per-kernel launch counts and durations (resolved whenever the
+ * pipeline synchronises the stream).  Resets the counters. */
+int nle_ctx_profile(nle_ctx* ctx, int enable);
+int nle_ctx_kernel_stats(nle_ctx* ctx, int kid, long long* launches, double* total_ms);
 /* Run `reps` launches of the materialising affinity kernel (the HBM-roofline pass of
  * computeKernel) and return the average launch duration in ms, measured with HIP events on
  * the ctx's stream. */

@@ -22,6 +22,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libnle_hip.so")
 
 NLE_OK, NLE_ERR_INVALID, NLE_ERR_HIP, NLE_ERR_NUMERIC, NLE_ERR_COMM = 0, 1, 2, 3, 4
 EPS = 1e-10
+KERNEL_COUNT = 9  # NLE_KERNEL_COUNT
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -61,6 +62,9 @@ _SIGNATURES = {
     "nle_apply_host": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "nle_apply_layers_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "nle_ld": (C.c_int, [C.c_int]),
+    "nle_kernel_name": (C.c_char_p, [C.c_int]),
+    "nle_ctx_profile": (C.c_int, [_P, C.c_int]),
+    "nle_ctx_kernel_stats": (C.c_int, [_P, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "nle_bench_affinity": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P, C.c_int,
                                      C.POINTER(C.c_double)]),
     "nle_bench_sinkhorn_pass": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -213,6 +217,19 @@ class Context:
 
     def synchronize(self):
         _check(lib().nle_ctx_synchronize(self._h), self._h)
+
+    def profile(self, enable: bool = True):
+        """Per-kernel HIP-event timing on the ctx's stream (resets the counters)."""
+        _check(lib().nle_ctx_profile(self._h, 1 if enable else 0), self._h)
+
+    def kernel_stats(self):
+        """{kernel name: (launches, total_ms)} accumulated since `profile(True)`."""
+        out = {}
+        for kid in range(KERNEL_COUNT):
+            n, ms = C.c_longlong(), C.c_double()
+            _check(lib().nle_ctx_kernel_stats(self._h, kid, C.byref(n), C.byref(ms)), self._h)
+            out[lib().nle_kernel_name(kid).decode()] = (n.value, ms.value)
+        return out
 
     def close(self):
         if self._h:

@@ -29,6 +29,17 @@ struct nle_ctx {
     double* d_comm = nullptr;
     size_t comm_len = 0;
     std::string err;
+    // per-kernel HIP-event timing (nle_ctx_profile): records are resolved at the next
+    // point where the stream is synchronised anyway
+    bool profiling = false;
+    struct ProfRec {
+        int kid;
+        hipEvent_t a, b;
+    };
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    long long prof_launches[NLE_KERNEL_COUNT] = {0};
+    double prof_ms[NLE_KERNEL_COUNT] = {0};
 };
 
 struct nle_filter {
@@ -107,6 +118,57 @@ struct Timer {
 
 inline int ld4(int n) { return (n + 3) & ~3; }
 
+// ---- per-kernel event timing (nle_ctx_profile) ----
+hipEvent_t prof_event(nle_ctx* c) {
+    if (!c->prof_pool.empty()) {
+        hipEvent_t e = c->prof_pool.back();
+        c->prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    HIP_OK(hipEventCreate(&e));
+    return e;
+}
+
+struct Prof {
+    nle_ctx* c;
+    int kid;
+    hipEvent_t a = nullptr, b = nullptr;
+    Prof(nle_ctx* c_, int kid_) : c(c_), kid(kid_) {
+        if (!c->profiling) return;
+        a = prof_event(c);
+        b = prof_event(c);
+        HIP_OK(hipEventRecord(a, c->stream));
+    }
+    void end() {
+        if (!a) return;
+        HIP_OK(hipEventRecord(b, c->stream));
+        c->prof_pending.push_back({kid, a, b});
+        a = nullptr;
+    }
+};
+
+#define PROFILED(ctx_, kid_, expr)  \
+    do {                            \
+        Prof pf_((ctx_), (kid_));   \
+        HIP_OK(expr);               \
+        pf_.end();                  \
+    } while (0)
+
+// resolve pending records; the caller has synchronised the stream
+void prof_flush(nle_ctx* c) {
+    for (auto& r : c->prof_pending) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            c->prof_ms[r.kid] += t;
+            c->prof_launches[r.kid] += 1;
+        }
+        c->prof_pool.push_back(r.a);
+        c->prof_pool.push_back(r.b);
+    }
+    c->prof_pending.clear();
+}
+
 bool make_grid(int H, int W, int nRow, int nCol, GridSpec* gs) {
     // samplePixels, reference src/filter.cpp:56-71, closed form
     if (H <= 0 || W <= 0 || nRow <= 0 || nCol <= 0 || nRow > H || nCol > W) return false;
@@ -163,7 +225,7 @@ SampleSet fetch_samples(nle_ctx* c, const float* d_lum, const GridSpec& gs) {
     s.gs = gs;
     s.p = gs.p();
     DevBuf<float> d_val(s.p);
-    HIP_OK(nlek::gather_samples(c->stream, d_lum, gs, d_val.p));
+    PROFILED(c, NLE_K_SMALL, nlek::gather_samples(c->stream, d_lum, gs, d_val.p));
     s.val.resize(s.p);
     HIP_OK(hipMemcpyAsync(s.val.data(), d_val.p, s.p * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
@@ -243,8 +305,8 @@ void build_phi(nle_ctx* c, const float* d_lum, const SampleSet& ss, const Nystro
     DevBuf<float> d_B(B.size());
     HIP_OK(hipMemcpyAsync(d_B.p, B.data(), B.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     const float sw = (float)(1.0 / (hx * hx)), pw = (float)(1.0 / (hy * hy));
-    HIP_OK(nlek::ts_gemm(c->stream, true, nullptr, 0, d_lum, ss.gs, d_samples.p, sw, pw, pix0, d_B.p,
-                         ny.ldr, p, d_phi, ny.ldr, M, nullptr, NLE_EPS));
+    PROFILED(c, NLE_K_NYSTROM, nlek::ts_gemm(c->stream, true, nullptr, 0, d_lum, ss.gs, d_samples.p, sw, pw, pix0,
+                                             d_B.p, ny.ldr, p, d_phi, ny.ldr, M, nullptr, NLE_EPS));
     // sample pixels carry their exact V_A row (top block of phi, reference :275)
     std::vector<float> rows;
     std::vector<long long> idx;
@@ -261,7 +323,7 @@ void build_phi(nle_ctx* c, const float* d_lum, const SampleSet& ss, const Nystro
     if (!idx.empty()) {
         HIP_OK(hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipMemcpyAsync(d_idx.p, idx.data(), idx.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-        HIP_OK(nlek::scatter_rows(c->stream, d_rows.p, d_idx.p, (int)idx.size(), ny.ldr, d_phi, M));
+        PROFILED(c, NLE_K_SMALL, nlek::scatter_rows(c->stream, d_rows.p, d_idx.p, (int)idx.size(), ny.ldr, d_phi, M));
     }
     HIP_OK(hipStreamSynchronize(c->stream));  // host staging vectors go out of scope
 }
@@ -279,9 +341,9 @@ void sinkhorn_passes(nle_ctx* c, const float* d_phi, long long M, int ld, int r,
     HIP_OK(hipMemcpyAsync(d_lam.p, lam_pad.data(), ld * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int nb = 0;
     // t_r(0) = Phi^T 1
-    HIP_OK(nlek::rowpass(c->stream, nlek::ROWPASS_COLSUM, d_phi, M, ld, nullptr, nullptr, nullptr, NLE_EPS,
-                         d_partial.p, &nb));
-    HIP_OK(nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t[0].p));
+    PROFILED(c, NLE_K_SINKHORN_PASS, nlek::rowpass(c->stream, nlek::ROWPASS_COLSUM, d_phi, M, ld, nullptr, nullptr,
+                                                   nullptr, NLE_EPS, d_partial.p, &nb));
+    PROFILED(c, NLE_K_REDUCE, nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t[0].p));
     all_reduce(c, d_t[0].p, ld);
     // cur = index of the t feeding the next pass
     int cur = 0;
@@ -290,9 +352,9 @@ void sinkhorn_passes(nle_ctx* c, const float* d_phi, long long M, int ld, int r,
         // c = recip(Phi (lam o t_r));  t_c = Phi^T c
         idx_c_in = cur;
         int nxt = (cur + 1) % 3;
-        HIP_OK(nlek::rowpass(c->stream, nlek::ROWPASS_RECIP, d_phi, M, ld, d_t[cur].p, d_lam.p, nullptr,
-                             NLE_EPS, d_partial.p, &nb));
-        HIP_OK(nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t[nxt].p));
+        PROFILED(c, NLE_K_SINKHORN_PASS, nlek::rowpass(c->stream, nlek::ROWPASS_RECIP, d_phi, M, ld, d_t[cur].p,
+                                                       d_lam.p, nullptr, NLE_EPS, d_partial.p, &nb));
+        PROFILED(c, NLE_K_REDUCE, nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t[nxt].p));
         all_reduce(c, d_t[nxt].p, ld);
         cur = nxt;
         idx_r_in = cur;
@@ -301,9 +363,9 @@ void sinkhorn_passes(nle_ctx* c, const float* d_phi, long long M, int ld, int r,
             // only u_r = lam o t_c enters the W blocks)
             nxt = (cur + 1) % 3;
             if (nxt == idx_c_in) nxt = (nxt + 1) % 3;
-            HIP_OK(nlek::rowpass(c->stream, nlek::ROWPASS_RECIP, d_phi, M, ld, d_t[cur].p, d_lam.p, nullptr,
-                                 NLE_EPS, d_partial.p, &nb));
-            HIP_OK(nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t[nxt].p));
+            PROFILED(c, NLE_K_SINKHORN_PASS, nlek::rowpass(c->stream, nlek::ROWPASS_RECIP, d_phi, M, ld, d_t[cur].p,
+                                                           d_lam.p, nullptr, NLE_EPS, d_partial.p, &nb));
+            PROFILED(c, NLE_K_REDUCE, nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t[nxt].p));
             all_reduce(c, d_t[nxt].p, ld);
             cur = nxt;
         }
@@ -311,7 +373,7 @@ void sinkhorn_passes(nle_ctx* c, const float* d_phi, long long M, int ld, int r,
     std::vector<double> tc(ld), tr(ld);
     HIP_OK(hipMemcpyAsync(tc.data(), d_t[idx_c_in].p, ld * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipMemcpyAsync(tr.data(), d_t[idx_r_in].p, ld * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (d_u_c_out) HIP_OK(nlek::scale_vec(c->stream, d_lam.p, d_t[idx_c_in].p, ld, d_u_c_out));
+    if (d_u_c_out) PROFILED(c, NLE_K_SMALL, nlek::scale_vec(c->stream, d_lam.p, d_t[idx_c_in].p, ld, d_u_c_out));
     HIP_OK(hipStreamSynchronize(c->stream));
     u_c->assign(r, 0.0);
     u_r->assign(r, 0.0);
@@ -327,7 +389,7 @@ std::vector<double> gram_all(nle_ctx* c, const float* d_phi, long long M, int ld
     DevBuf<double> d_partial(std::max<size_t>(nlek::gram_partial_elems(std::max<long long>(M, 1), ld), 1));
     DevBuf<double> d_tiles((size_t)ntiles * 1024);
     if (M > 0) {
-        HIP_OK(nlek::gram(c->stream, d_phi, M, ld, d_u, NLE_EPS, d_partial.p, d_tiles.p));
+        PROFILED(c, NLE_K_GRAM, nlek::gram(c->stream, d_phi, M, ld, d_u, NLE_EPS, d_partial.p, d_tiles.p));
     } else {
         HIP_OK(hipMemsetAsync(d_tiles.p, 0, (size_t)ntiles * 1024 * sizeof(double), c->stream));
     }
@@ -552,8 +614,8 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         DevBuf<float> d_Cp(Cp.size());
         HIP_OK(hipMemcpyAsync(d_Cp.p, Cp.data(), Cp.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
         DevBuf<float> d_V((size_t)std::max<long long>(M, 1) * f->ldv);
-        HIP_OK(nlek::ts_gemm(c->stream, false, d_phi.p, ny.ldr, nullptr, gs, nullptr, 0.f, 0.f, 0, d_Cp.p,
-                             f->ldv, ny.r, d_V.p, f->ldv, M, d_u_c.p, NLE_EPS));
+        PROFILED(c, NLE_K_PROJECT, nlek::ts_gemm(c->stream, false, d_phi.p, ny.ldr, nullptr, gs, nullptr, 0.f, 0.f, 0,
+                                                 d_Cp.p, f->ldv, ny.r, d_V.p, f->ldv, M, d_u_c.p, NLE_EPS));
         std::vector<float> rows;
         std::vector<long long> idx;
         for (int a = 0; a < o.q; ++a) {
@@ -569,10 +631,11 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         if (!idx.empty()) {
             HIP_OK(hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
             HIP_OK(hipMemcpyAsync(d_idx.p, idx.data(), idx.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-            HIP_OK(nlek::scatter_rows(c->stream, d_rows.p, d_idx.p, (int)idx.size(), f->ldv, d_V.p, M));
+            PROFILED(c, NLE_K_SMALL, nlek::scatter_rows(c->stream, d_rows.p, d_idx.p, (int)idx.size(), f->ldv, d_V.p, M));
         }
         tm_p.stop();
         HIP_OK(hipStreamSynchronize(c->stream));
+        prof_flush(c);
         f->d_V = d_V.take();
         f->ms[0] = tm_a.ms();
         f->ms[1] = tm_s.ms();
@@ -605,14 +668,15 @@ void apply_impl(nle_filter* f, const float* d_x, int H, int W, const double* h_g
         for (int k = 0; k < f->K; ++k) resp[(size_t)l * ld + k] = h_g[(size_t)l * f->K + k];
     HIP_OK(hipMemcpyAsync(d_resp.p, resp.data(), resp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int nb = 0;
-    HIP_OK(nlek::rowpass(c->stream, nlek::ROWPASS_XVEC, f->d_V, M, ld, nullptr, nullptr, d_x + pix0, NLE_EPS,
-                         d_partial.p, &nb));
-    HIP_OK(nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t.p));
+    PROFILED(c, NLE_K_APPLY_REDUCE, nlek::rowpass(c->stream, nlek::ROWPASS_XVEC, f->d_V, M, ld, nullptr, nullptr,
+                                                  d_x + pix0, NLE_EPS, d_partial.p, &nb));
+    PROFILED(c, NLE_K_REDUCE, nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t.p));
     all_reduce(c, d_t.p, ld);
     for (int l = 0; l < L; ++l)
-        HIP_OK(nlek::scale_vec(c->stream, d_resp.p + (size_t)l * ld, d_t.p, ld, d_g.p + (size_t)l * ld));
-    HIP_OK(nlek::apply_expand(c->stream, f->d_V, M, ld, d_g.p, L, d_y, M));
+        PROFILED(c, NLE_K_SMALL, nlek::scale_vec(c->stream, d_resp.p + (size_t)l * ld, d_t.p, ld, d_g.p + (size_t)l * ld));
+    PROFILED(c, NLE_K_APPLY_EXPAND, nlek::apply_expand(c->stream, f->d_V, M, ld, d_g.p, L, d_y, M));
     HIP_OK(hipStreamSynchronize(c->stream));
+    prof_flush(c);
 }
 
 void layer_resp(const double* ev, int K, int L, double* out) {
@@ -677,6 +741,11 @@ int nle_ctx_create(int device, void* stream, nle_ctx** out) {
 
 void nle_ctx_destroy(nle_ctx* ctx) {
     if (!ctx) return;
+    for (auto& r : ctx->prof_pending) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -764,9 +833,11 @@ int nle_compute_kernel(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row
             slab(H, ctx->rank, ctx->world, &row0, &row1);
             DevBuf<float4> d_samples(ss.p);
             HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), ss.p * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-            HIP_OK(nlek::affinity(ctx->stream, d_lum, gs, d_samples.p, ss.p, ld4(ss.p), (float)(1.0 / (hx * hx)),
-                                  (float)(1.0 / (hy * hy)), (long long)row0 * W, (long long)(row1 - row0) * W, d_kab));
+            PROFILED(ctx, NLE_K_AFFINITY,
+                     nlek::affinity(ctx->stream, d_lum, gs, d_samples.p, ss.p, ld4(ss.p), (float)(1.0 / (hx * hx)),
+                                    (float)(1.0 / (hy * hy)), (long long)row0 * W, (long long)(row1 - row0) * W, d_kab));
             HIP_OK(hipStreamSynchronize(ctx->stream));
+            prof_flush(ctx);
         }
     });
 }
@@ -952,6 +1023,35 @@ int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, 
         std::vector<double> resp((size_t)L * f->K);
         layer_resp(f->eigvals.data(), f->K, L, resp.data());
         apply_host_common(f, h_x, H, W, resp.data(), L, h_y);
+    });
+}
+
+static const char* const kKernelNames[NLE_KERNEL_COUNT] = {
+    "affinity", "nystrom_extend", "sinkhorn_pass", "reduce_partials", "gram",
+    "project",  "apply_reduce",   "apply_expand",  "small"};
+
+const char* nle_kernel_name(int kid) { return (kid >= 0 && kid < NLE_KERNEL_COUNT) ? kKernelNames[kid] : ""; }
+
+int nle_ctx_profile(nle_ctx* ctx, int enable) {
+    if (!ctx) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+        prof_flush(ctx);
+        ctx->profiling = enable != 0;
+        for (int k = 0; k < NLE_KERNEL_COUNT; ++k) {
+            ctx->prof_launches[k] = 0;
+            ctx->prof_ms[k] = 0.0;
+        }
+    });
+}
+
+int nle_ctx_kernel_stats(nle_ctx* ctx, int kid, long long* launches, double* total_ms) {
+    if (!ctx || kid < 0 || kid >= NLE_KERNEL_COUNT) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+        prof_flush(ctx);
+        if (launches) *launches = ctx->prof_launches[kid];
+        if (total_ms) *total_ms = ctx->prof_ms[kid];
     });
 }
 

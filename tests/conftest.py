@@ -11,6 +11,8 @@ import sys
 import numpy as np
 import pytest
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG_DIR = os.path.join(ROOT, "nonlocal-image-edit_amd")
 GOLDEN = os.path.join(ROOT, "tests", "golden")

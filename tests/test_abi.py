@@ -1,0 +1,141 @@
+"""The C-ABI library builds, loads, and exports every symbol include/nle.h declares; the
+host-only entry points work without a GPU; compute entry points fail loudly without one."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nle.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nle_[a-z_0-9]+)\s*\(", text)) - {"nle_allreduce_fn"})
+
+
+def test_every_declared_symbol_is_exported_and_bound(nle):
+    import ctypes
+    lib = nle.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/nle.h but not exported"
+        ctypes.cast(getattr(lib, name), ctypes.c_void_p)
+    assert sorted(nle.EXPORTED_SYMBOLS) == declared, "Python mirror and header disagree"
+
+
+def test_library_is_gfx950_native(nle):
+    """the shared object carries a gfx950 code object (hipcc --offload-arch=gfx950)"""
+    blob = open(nle.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for k in (b"k_affinity", b"k_rowpass", b"k_tsgemm", b"k_gram"):
+        assert k in blob, k
+
+
+# (H, W, nRow, nCol) -> expected selected rows / cols, from src/filter.cpp:56-71 evaluated by hand
+GRID_CASES = [
+    (267, 400, 10, 20, list(range(16, 267, 26))[:10], list(range(9, 400, 20))[:20]),
+    (512, 512, 10, 20, [26 + 51 * i for i in range(10)], [18 + 25 * i for i in range(20)]),
+    (4096, 4096, 20, 10, [109 + 204 * i for i in range(20)], [207 + 409 * i for i in range(10)]),
+    (8192, 8192, 30, 30, [137 + 273 * i for i in range(30)], [137 + 273 * i for i in range(30)]),
+]
+
+
+@pytest.mark.parametrize("H,W,nr,nc,rows,cols", GRID_CASES)
+def test_sample_grid_closed_form(nle, oracle, H, W, nr, nc, rows, cols):
+    g = nle.sample_grid(H, W, nr, nc)
+    got_r = [g["row_off"] + i * g["row_step"] for i in range(g["n_sel_rows"])]
+    got_c = [g["col_off"] + i * g["col_step"] for i in range(g["n_sel_cols"])]
+    assert got_r == rows and got_c == cols
+    sr, sc = oracle.sample_grid(H, W, nr, nc)
+    assert got_r == sr.tolist() and got_c == sc.tolist()
+
+
+def _brute_force_selected(H, W, nr, nc):
+    """literal double loop of samplePixels, src/filter.cpp:56-80"""
+    rs, cs = H // nr, W // nc
+    ro, co = (rs - 1 + (H - rs * nr)) // 2, (cs - 1 + (W - cs * nc)) // 2
+    sel = []
+    for r in range(H):
+        for c in range(W):
+            if r >= ro and c >= co and r <= H - ro and c <= W - co and (r - ro) % rs == 0 and (c - co) % cs == 0:
+                sel.append(r * W + c)
+    return sel
+
+
+@pytest.mark.parametrize("H,W,nr,nc", [(15, 20, 10, 7), (7, 9, 7, 9), (33, 47, 3, 4), (10, 10, 1, 1), (5, 64, 5, 3),
+                                        (12, 12, 5, 5), (9, 31, 4, 30)])
+def test_sample_grid_matches_literal_scan(nle, oracle, H, W, nr, nc):
+    """includes step == 1 cases where the realised count exceeds nRow*nCol"""
+    want = _brute_force_selected(H, W, nr, nc)
+    g = nle.sample_grid(H, W, nr, nc)
+    got = [(g["row_off"] + i * g["row_step"]) * W + g["col_off"] + j * g["col_step"]
+           for i in range(g["n_sel_rows"]) for j in range(g["n_sel_cols"])]
+    assert got == want
+    sel, rest = oracle.sample_pixels(H, W, nr, nc)
+    assert sel.tolist() == want and sel.size + rest.size == H * W
+
+
+def test_too_many_samples_is_an_error(nle, oracle):
+    with pytest.raises(nle.NLEError):
+        nle.sample_grid(10, 10, 11, 2)
+    with pytest.raises(RuntimeError, match="Number of samples per row and col must be <= that of image"):
+        oracle.compute_kernel(np.zeros((10, 10)), 11, 2, 1.0, 1.0)
+
+
+def test_slab_rows_cover_image(nle, oracle):
+    for H in (1, 7, 267, 4096):
+        for G in (1, 2, 3, 8):
+            prev = 0
+            for g in range(G):
+                r0, r1 = nle.slab_rows(H, g, G)
+                assert (r0, r1) == oracle.slab_rows(H, g, G)
+                assert r0 == prev and r1 >= r0
+                prev = r1
+            assert prev == H
+
+
+def test_eigensolver_against_lapack(nle):
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 17, 64, 200):
+        A = rng.standard_normal((n, n))
+        A = A @ A.T / n + 1e-3 * np.eye(n)
+        U, D = nle.eigen_decomposition(A)
+        w = np.linalg.eigvalsh(A)[::-1]
+        assert D.size == n and np.allclose(D, w, rtol=1e-12, atol=1e-13)
+        assert np.abs(U.T @ U - np.eye(n)).max() < 1e-12
+        assert np.abs(U @ np.diag(D) @ U.T - A).max() < 1e-12 * max(1.0, np.abs(A).max()) * n
+
+
+def test_compute_needs_a_gpu_and_says_so(nle):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nle.Context(0)
+    # straight through the C ABI: status NLE_ERR_HIP, never a silent CPU path
+    import ctypes as C
+    h = C.c_void_p()
+    st = nle.lib().nle_ctx_create(0, None, C.byref(h))
+    assert st == nle.NLE_ERR_HIP and not h.value
+    assert b"HIP" in nle.lib().nle_last_error(None) or b"hip" in nle.lib().nle_last_error(None)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "nonlocal-image-edit_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "nle_oracle" not in text and "oracle/" not in text.replace("Nothing here imports `oracle/`", ""), fn
+
+
+def test_synthetic_generator_matches_oracle(oracle):
+    import __graft_entry__ as entry
+    synth = entry._load("nle_amd_synthetic", os.path.join(entry.PKG_DIR, "synthetic.py"))
+    a = synth.synthetic_luminance(37, 53)
+    assert np.array_equal(a, oracle.synthetic_luminance(37, 53))
+    assert np.array_equal(synth.synthetic_luminance(37, 53, rows=(5, 20)), a[5:20])
+    assert a.min() >= 0 and a.max() <= 255 and np.array_equal(a, np.rint(a))

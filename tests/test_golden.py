@@ -1,0 +1,143 @@
+"""Committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py).
+CPU: the oracle still reproduces them (literal AND streaming/sharded forms).  GPU: the HIP path,
+through the C ABI, against the same vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_l2
+
+PER_LAYER_TOL = 1e-4  # BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def small():
+    return np.load(os.path.join(GOLDEN, "small_cases.npz"))
+
+
+@pytest.fixture(scope="module")
+def flower():
+    return np.load(os.path.join(GOLDEN, "flower_cfg1.npz"))
+
+
+def _cases(small):
+    return sorted({k.split("/")[0] for k in small.files})
+
+
+def _args(a):
+    H, W, nr, nc, hx, hy, T, K, L = a
+    return int(H), int(W), int(nr), int(nc), float(hx), float(hy), int(T), int(K), int(L)
+
+
+def test_oracle_literal_reproduces_golden(oracle, small):
+    for cid in _cases(small):
+        H, W, nr, nc, hx, hy, T, K, L = _args(small[f"{cid}/args"])
+        x = small[f"{cid}/x"].astype(np.float64)
+        assert np.array_equal(x, oracle.synthetic_luminance(H, W))
+        V, S, inter = oracle.train_filter(x, nr, nc, hx, hy, T, K, return_intermediates=True)
+        assert rel_l2(inter["lam"], small[f"{cid}/lam"]) < 1e-9
+        assert rel_l2(S, small[f"{cid}/S"]) < 1e-9
+        Y = oracle.apply_layers(V, S, x, L).reshape(L, -1)
+        for j in range(L):
+            assert rel_l2(Y[j], small[f"{cid}/Y"][j]) < 1e-7
+
+
+@pytest.mark.parametrize("G", [1, 2, 3])
+def test_oracle_streaming_sharded_reproduces_golden(oracle, small, G):
+    """the natural-order, tiled, row-slab-sharded decomposition the GPU path uses is the same math"""
+    for cid in _cases(small):
+        H, W, nr, nc, hx, hy, T, K, L = _args(small[f"{cid}/args"])
+        x = small[f"{cid}/x"].astype(np.float64)
+        # emulate the all-reduce: run every shard in lock step through generators
+        parts = [None] * G
+        V_parts, S_parts = _run_sharded(oracle, x, (nr, nc, hx, hy, T, K), G)
+        V = np.vstack(V_parts)
+        assert all(rel_l2(S, small[f"{cid}/S"]) < 1e-7 for S in S_parts)
+        t = sum(Vp.T @ x.ravel()[lo:hi] for Vp, (lo, hi) in zip(V_parts, _bounds(oracle, H, W, G)))
+        resp = oracle.layer_responses(S_parts[0], L)
+        for j in range(L):
+            assert rel_l2(V @ (resp[j] * t), small[f"{cid}/Y"][j]) < 1e-6, (cid, j)
+
+
+def _bounds(oracle, H, W, G):
+    return [(oracle.slab_rows(H, g, G)[0] * W, oracle.slab_rows(H, g, G)[1] * W) for g in range(G)]
+
+
+def _run_sharded(oracle, x, args, G):
+    """Run the G shards of train_filter_streaming in threads with a barrier-based all-reduce."""
+    import threading
+    nr, nc, hx, hy, T, K = args
+    barrier = threading.Barrier(G)
+    slots = [None] * G
+    results = [None] * G
+    errors = []
+
+    def make_allreduce(g):
+        def allreduce(v):
+            slots[g] = np.array(v, dtype=np.float64, copy=True)
+            barrier.wait()
+            total = sum(slots[k] for k in range(G))
+            barrier.wait()
+            return total
+        return allreduce
+
+    def work(g):
+        try:
+            results[g] = oracle.train_filter_streaming(x, nr, nc, hx, hy, T, K, tile=997, shard=(g, G),
+                                                       allreduce=make_allreduce(g))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=work, args=(g,)) for g in range(G)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    return [r[0] for r in results], [r[1] for r in results]
+
+
+def test_flower_golden_is_consistent_with_readme_pair(oracle, flower):
+    from PIL import Image
+    want = np.asarray(Image.open(os.path.join(GOLDEN, "flower-filtered.png")).convert("RGB"))[..., ::-1]
+    L_want = oracle.bgr_to_lab8(want)[..., 0].astype(np.float64)
+    assert np.abs(flower["L_out"].astype(np.float64) - L_want).mean() < 1.0
+    assert flower["lam"].size == 200 and flower["S"].size == 30
+    assert 0.999 < flower["S"][0] <= 1.0 + 1e-9
+
+
+# ------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_device_matches_small_goldens(nle, ctx, small):
+    for cid in _cases(small):
+        H, W, nr, nc, hx, hy, T, K, L = _args(small[f"{cid}/args"])
+        x = small[f"{cid}/x"].astype(np.float32)
+        f = nle.NLEFilter(ctx).train_filter(x, nr, nc, hx, hy, T, K)
+        assert f.info()["K"] == small[f"{cid}/S"].size
+        assert rel_l2(f.eigvals, small[f"{cid}/S"]) < 1e-5
+        Y = f.apply_layers(x, L).cpu().numpy().astype(np.float64)
+        for j in range(L):
+            assert rel_l2(Y[j], small[f"{cid}/Y"][j]) < PER_LAYER_TOL, (cid, j)
+        f.close()
+
+
+@pytest.mark.gpu
+def test_device_matches_flower_cfg1(nle, ctx, flower):
+    """BASELINE.json configs[0] on the device: per-layer norms, eigenvalues and the 8-bit L plane."""
+    Lp = flower["L_in"].astype(np.float32)
+    f = nle.NLEFilter(ctx).train_filter(Lp, 10, 20, 100.0, 30.0, 50, 30)
+    info = f.info()
+    assert info["p"] == 200 and info["r"] == 200 and info["K"] == 30
+    assert rel_l2(f.eigvals, flower["S"]) < 1e-5
+    Y = f.apply_layers(Lp, 4).cpu().numpy().astype(np.float64)
+    assert np.allclose(np.linalg.norm(Y, axis=1), flower["layer_norms"], rtol=1e-4)
+    for j in range(4):
+        # every 997th pixel of each layer; error relative to the layer's RMS level
+        got, want = Y[j, ::997], flower["Y_probe"][j]
+        rms = flower["layer_norms"][j] / np.sqrt(Y.shape[1])
+        assert np.abs(got - want).max() < 1e-3 * rms * 10, j
+    y = f.apply(Lp, nle.transform_eigenvalues(f.eigvals, [2.0, 3.0, 4.0, 1.0])).cpu().numpy()
+    L_out = np.rint(np.clip(y.astype(np.float64), 0, 255)).astype(np.uint8).reshape(Lp.shape)
+    diff = np.abs(L_out.astype(int) - flower["L_out"].astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3    # only round-half ties may flip
+    f.close()

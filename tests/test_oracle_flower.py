@@ -1,0 +1,60 @@
+"""End-to-end pin of the oracle on BASELINE.json configs[0]: the README pair
+data/flower-50.bmp -> data/flower-filtered.png produced by the reference's `enhance` binary with
+args `10 20 100 30 50 30 2 3 4 1` (README.md:74).  Both files are data fixtures copied from the
+reference's data/ directory.  The reference's 8-bit Lab conversion is OpenCV's (version unknown,
+fixed-point tables), so this is a LOOSE known-answer test: about one grey level."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+ARGS = dict(n_row=10, n_col=20, hx=100.0, hy=30.0, T=50, K=30, weights=[2.0, 3.0, 4.0, 1.0])
+
+
+def _load(name):
+    from PIL import Image
+    return np.asarray(Image.open(os.path.join(GOLDEN, name)).convert("RGB"))[..., ::-1].copy()  # BGR like cv::imread
+
+
+@pytest.fixture(scope="module")
+def flower(oracle):
+    src = _load("flower-50.bmp")
+    want = _load("flower-filtered.png")
+    got = oracle.enhance_image(src, ARGS["n_row"], ARGS["n_col"], ARGS["hx"], ARGS["hy"], ARGS["T"], ARGS["K"],
+                               ARGS["weights"])
+    return src, want, got
+
+
+def test_flower_matches_readme_output(oracle, flower):
+    src, want, got = flower
+    assert src.shape == (267, 400, 3) and want.shape == src.shape and got.shape == src.shape
+    L_src = oracle.bgr_to_lab8(src)[..., 0].astype(np.float64)
+    L_want = oracle.bgr_to_lab8(want)[..., 0].astype(np.float64)
+    L_got = oracle.bgr_to_lab8(got)[..., 0].astype(np.float64)
+    moved = np.abs(L_want - L_src).mean()
+    err = np.abs(L_got - L_want)
+    corr = np.corrcoef(L_got.ravel(), L_want.ravel())[0, 1]
+    print(f"filter moves L by {moved:.2f} levels on average; oracle vs README output: mean |dL| = {err.mean():.3f}, "
+          f"p99 = {np.percentile(err, 99):.1f}, corr = {corr:.5f}")
+    assert moved > 10.0                 # the edit is large ...
+    assert err.mean() < 1.0             # ... and the oracle reproduces it to < 1 grey level on average
+    assert np.percentile(err, 99) <= 8.0
+    assert corr > 0.999
+    # colour planes: a, b are passed through unchanged by `enhance` (src/filter.cpp:431-440)
+    d_bgr = np.abs(got.astype(int) - want.astype(int))
+    assert d_bgr.mean() < 2.0
+
+
+def test_flower_sampling_and_rank(oracle):
+    src = _load("flower-50.bmp")
+    L = oracle.bgr_to_lab8(src)[..., 0].astype(np.float64)
+    sr, sc = oracle.sample_grid(267, 400, 10, 20)
+    assert sr.tolist() == list(range(16, 251, 26)) and sc.tolist() == list(range(9, 390, 20))
+    perm, Ka, Kab = oracle.compute_kernel(L, 10, 20, 100.0, 30.0)
+    assert Ka.shape == (200, 200) and Kab.shape == (200, 106800 - 200)
+    lam, phi = oracle.nystrom_approximation(Ka, Kab)
+    assert lam.size == 200 and lam[-1] > 1e-8        # full rank, cut not borderline
+    # K ~= phi diag(lam) phi^T on the sample block (exact there)
+    assert np.abs(phi[:200] @ np.diag(lam) @ phi[:200].T - Ka).max() < 1e-10
