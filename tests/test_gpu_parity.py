@@ -168,20 +168,25 @@ def test_train_apply_layers_match_oracle(nle, oracle, ctx, case):
 
 
 def test_rank_truncated_Ka(nle, oracle, ctx):
-    """Ka numerically rank deficient: r < p, the A block is the first r samples (src/filter.cpp:247)."""
+    """Ka numerically rank deficient with a clear gap at the 1e-10 cut (4 grey levels, spatial
+    bandwidth so wide that pixels of one level are near duplicates): r = 4 < p = 30, and the
+    A block of sinkhorn/orthogonalize is the first r samples (src/filter.cpp:247)."""
     H, W = 40, 52
-    x = np.round(60 + 0.5 * np.arange(H)[:, None] + 0.25 * np.arange(W)[None, :])  # very smooth
-    nr, nc, hx, hy, T, K, L = 5, 6, 400.0, 200.0, 6, 5, 3
+    levels = np.array([60.0, 120.0, 200.0, 90.0])
+    x = levels[np.random.default_rng(5).integers(0, 4, size=(H, W))]
+    nr, nc, hx, hy, T, K, L = 5, 6, 1e8, 50.0, 6, 5, 3
     V_o, S_o, inter = oracle.train_filter(x, nr, nc, hx, hy, T, K, return_intermediates=True)
     p, r = inter["Ka"].shape[0], inter["lam"].size
-    assert r < p, "test input must truncate"
-    gap = inter["lam"][-1] / 1e-10
-    assert gap > 10, "cut must not be borderline"
+    assert p == 30 and r == 4, "test input must truncate"
+    w_all = np.linalg.eigvalsh(inter["Ka"])[::-1]
+    assert inter["lam"][-1] > 1e-2 and abs(w_all[r]) < 1e-11, "cut must not be borderline"
+    assert S_o.size == 4  # K' = min(K, kept) = 4 < K
     Y_o = oracle.apply_layers(V_o, S_o, x, L).reshape(L, -1)
     f, Y = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
-    assert f.info()["r"] == r and f.info()["p"] == p
+    assert f.info()["r"] == r and f.info()["p"] == p and f.info()["K"] == 4
+    assert rel_l2(f.eigvals, S_o) < 1e-5
     for j in range(L):
-        assert rel_l2(Y[j], Y_o[j]) < 1e-3, f"layer {j}"  # ill-conditioned on purpose: looser
+        assert rel_l2(Y[j], Y_o[j]) < PER_LAYER_TOL, f"layer {j}"
 
 
 def test_errors_mirror_reference(nle, oracle, ctx):
