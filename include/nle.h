@@ -51,6 +51,16 @@ void nle_ctx_destroy(nle_ctx* ctx);
 const char* nle_last_error(const nle_ctx* ctx); /* ctx may be NULL: last create error */
 int nle_ctx_synchronize(nle_ctx* ctx);
 
+/* Which formulation nle_train uses for the N-sized passes (results agree to rounding):
+ *   NLE_MODE_AUTO          Phi-free when it applies (<= 256 samples, <= 128 eigenvectors, at least
+ *                          64 pixels per sample), else materialised
+ *   NLE_MODE_MATERIALISED  Phi = K_AB^T V_A Lambda^-1 is written once (N x r fp32) and streamed
+ *   NLE_MODE_PHI_FREE      every pass regenerates its affinity rows in registers */
+#define NLE_MODE_AUTO 0
+#define NLE_MODE_MATERIALISED 1
+#define NLE_MODE_PHI_FREE 2
+int nle_ctx_set_mode(nle_ctx* ctx, int mode);
+
 /* Multi-GPU (one process per GPU).  Rank `rank` of `world` owns image rows
  * [rank*H/world, (rank+1)*H/world).  `allreduce(user, d_buf, count)` must sum, in place
  * and stream-ordered with the ctx's stream, `count` doubles at DEVICE pointer d_buf over
@@ -139,8 +149,8 @@ int nle_filter_eigvals(const nle_filter* f, double* h_eigvals /* K */);
 int nle_filter_eigvecs(const nle_filter* f, const float** d_V, int* ld);
 /* copy V (n_local x ld floats) into a caller-owned DEVICE buffer */
 int nle_filter_copy_eigvecs(const nle_filter* f, float* d_out);
-/* per-stage milliseconds of the last train (HIP events): affinity+nystrom, sinkhorn, gram,
- * project, host eigensolves, total; h_ms[6] */
+/* per-stage milliseconds of the last train: sample fetch + Ka eigensolve, sinkhorn (incl. building
+ * Phi in the materialised mode), gram, project (HIP events); host algebra; wall total.  h_ms[6] */
 int nle_filter_timings(const nle_filter* f, double* h_ms);
 
 /* NLEFilter::apply, src/filter.cpp:445-458: y = V diag(fS) V^T x for this rank's slab.

@@ -33,6 +33,7 @@ _SIGNATURES = {
     "nle_ctx_destroy": (None, [_P]),
     "nle_last_error": (C.c_char_p, [_P]),
     "nle_ctx_synchronize": (C.c_int, [_P]),
+    "nle_ctx_set_mode": (C.c_int, [_P, C.c_int]),
     "nle_ctx_set_shard": (C.c_int, [_P, C.c_int, C.c_int, ALLREDUCE_FN, _P, _P, C.c_size_t]),
     "nle_comm_len": (C.c_size_t, [C.c_int]),
     "nle_sample_grid": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int)] * 6),
@@ -217,6 +218,10 @@ class Context:
 
     def synchronize(self):
         _check(lib().nle_ctx_synchronize(self._h), self._h)
+
+    def set_mode(self, mode: int):
+        """0 auto, 1 materialised Phi, 2 Phi-free (NLE_MODE_* in include/nle.h)."""
+        _check(lib().nle_ctx_set_mode(self._h, int(mode)), self._h)
 
     def profile(self, enable: bool = True):
         """Per-kernel HIP-event timing on the ctx's stream (resets the counters)."""
@@ -404,7 +409,7 @@ class NLEFilter:
     def timings(self):
         ms = np.zeros(6)
         _check(lib().nle_filter_timings(self._f, _np_ptr(ms)))
-        return dict(zip(("affinity_nystrom", "sinkhorn", "gram", "project", "host", "total"), ms.tolist()))
+        return dict(zip(("setup", "sinkhorn", "gram", "project", "host", "total"), ms.tolist()))
 
     def apply(self, x, f_s, out=None):
         """`NLEFilter::apply` (src/filter.cpp:445-458): y = V diag(fS) V^T x (local slab)."""

@@ -1,0 +1,550 @@
+// Phi-free ("sample space") kernels of the fused train path for gfx950.
+//
+// Identity used (all exact): with B = V_A diag(1/lambda) (p x r), the Nystrom row of a
+// non-sample pixel i is phi_i = B^T k_i, k_i[s] = exp(negDist(pixel i, sample s))
+// (reference src/filter.cpp:139-145,275).  Hence
+//     phi_i . u          = k_i . (B u)                         (Sinkhorn row product, :239,243)
+//     Phi^T y            = B^T (sum_i k_i y_i)                 (Sinkhorn column sums)
+//     sum c_i^2 phi phi^T = B^T (sum_i c_i^2 k_i k_i^T) B       (Gram of :296)
+//     c_i phi_i C        = c_i k_i^T (B C)                     (projection :327)
+// so every N-sized pass can regenerate its affinity row in registers (12 B/pixel of HBM
+// traffic) instead of streaming an N x r matrix: the passes become ALU-bound at ~1/4 of
+// the time it takes to read Phi once at HBM speed, and Phi is never allocated.
+// Sample pixels (whose rows are the exact V_A rows, :275 top block) are skipped by the
+// N-sized kernels and handled in fp64 by k_sink_update / the host.
+#include "kernels.h"
+
+#include <algorithm>
+
+namespace nlek {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ double recip_or_zero_d(double s, double eps) {
+    return (fabs(s) >= eps) ? 1.0 / s : 0.0;  // inplaceReciprocal, src/filter.cpp:42-54
+}
+
+// ------------------------------------------------------------------ wave transpose-reduce
+// v[N] per lane (N % 64 == 0).  On return out[j] of lane l = sum over the 64 lanes of
+// v[64 j + l].  log2(64) levels; level with lane bit b halves the array: the lane keeps the
+// half selected by its bit b and adds the partner lane's (l ^ (1 << b)) copy of that half.
+template <int MASK>
+__device__ __forceinline__ void fold_level(float& a, float& b, int lane) {
+    // a <- (lane & MASK ? b : a) summed over the lane pair {l, l ^ MASK}
+    if constexpr (MASK == 32) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (MASK == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else {
+        const bool hi = (lane & MASK) != 0;
+        const float keep = hi ? b : a, give = hi ? a : b;
+        a = keep + __shfl_xor(give, MASK);
+    }
+}
+
+template <int N, int LEN, int W>
+__device__ __forceinline__ void fold_all(float (&v)[N], int lane) {
+    // entries [0, LEN) are live, laid out [j][t] with t < W
+    if constexpr (W > 1) {
+        constexpr int H = W / 2;
+#pragma unroll
+        for (int j = 0; j < LEN / W; ++j)
+#pragma unroll
+            for (int t = 0; t < H; ++t) {
+                float a = v[j * W + t], b = v[j * W + t + H];
+                fold_level<H>(a, b, lane);
+                v[j * H + t] = a;  // compacts to [j][t] at width H; j*H+t is never read again
+            }
+        fold_all<N, LEN / 2, H>(v, lane);
+    }
+}
+
+// ------------------------------------------------------------------ Sinkhorn half-iteration
+// One pass over the local pixels (no N x r matrix): per non-sample pixel i
+//     k_i[s] = exp2(nsw*(dr^2+dc^2) + npw*dv^2),  d_i = k_i . w  (fp64),
+//     y_i = 1 (COLSUM) or recip(d_i),  z[s] += k_i[s] * y_i.
+// One wave owns 64 consecutive pixels at a time (lane = pixel); the p affinities of a
+// pixel stay in registers between the dot product and the accumulation, sample data and w
+// are wave-uniform (scalar loads).  The 64-lane sum of k[s]*y is a transpose-reduce after
+// which lane l owns samples {l, l+64, ...}; partials are fp64 per wave, summed by
+// k_reduce_partials in a fixed order.
+template <int PP>
+__global__ __launch_bounds__(256) void k_sink_pass(int mode, const float* __restrict__ lum, GridSpec gs,
+                                                   const Sample4* __restrict__ samples,
+                                                   const double* __restrict__ w, float nsw, float npw,
+                                                   unsigned pix0, long long M, double eps,
+                                                   double* __restrict__ ybuf, double* __restrict__ partial) {
+    constexpr int P64 = (PP + 63) & ~63;
+    constexpr int NJ = P64 / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long nwaves = (long long)gridDim.x * 4;
+    const long long wv = (long long)blockIdx.x * 4 + wave;
+    const long long ntiles = (M + 63) >> 6;
+    double acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = 0.0;
+
+    for (long long tile = wv; tile < ntiles; tile += nwaves) {
+        const long long li = tile * 64 + lane;
+        const bool valid = li < M;
+        const unsigned gi = pix0 + (unsigned)(valid ? li : M - 1);
+        const unsigned row = gi / (unsigned)gs.W, col = gi - row * (unsigned)gs.W;
+        const float pr = (float)row, pc = (float)col, px = lum[gi];
+        const bool live = valid && !is_sample_pixel(gs, (int)row, (int)col);
+
+        // The sample table and w are wave-uniform and loop-invariant; an opaque zero offset per
+        // tile keeps hipcc from hoisting all 6*PP scalar loads out of the tile loop (which spills
+        // ~900 SGPRs and re-reads them with v_readlane every iteration).
+        int zoff;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
+        const Sample4* __restrict__ sp = samples + zoff;
+        const double* __restrict__ wp = w + zoff;
+        float k[P64];
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+        for (int s = 0; s < PP; ++s) {
+            const Sample4 sm = sp[s];
+            const float kv = affinity_value(pr, pc, px, sm, nsw, npw);
+            k[s] = kv;
+            const double t = (double)kv * wp[s];
+            if ((s & 3) == 0) d0 += t;
+            else if ((s & 3) == 1) d1 += t;
+            else if ((s & 3) == 2) d2 += t;
+            else d3 += t;
+        }
+#pragma unroll
+        for (int s = PP; s < P64; ++s) k[s] = 0.f;
+        double y = 1.0;
+        if (mode != ROWPASS_COLSUM) y = recip_or_zero_d((d0 + d1) + (d2 + d3), eps);
+        if (!live) y = 0.0;
+        if (ybuf != nullptr && valid) ybuf[li] = y;
+        const float yf = (float)y;
+#pragma unroll
+        for (int s = 0; s < PP; ++s) k[s] *= yf;
+        fold_all<P64, P64, 64>(k, lane);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] += (double)k[j];
+    }
+    // combine the block's 4 waves (fixed order), one partial row per block
+    __shared__ double sacc[3][P64];
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) sacc[wave - 1][64 * j + lane] = acc[j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            partial[(size_t)blockIdx.x * P64 + 64 * j + lane] =
+                (acc[j] + sacc[0][64 * j + lane]) + (sacc[1][64 * j + lane] + sacc[2][64 * j + lane]);
+    }
+}
+
+int sink_pass_ld(int p) { return (p + 63) & ~63; }
+int sink_pass_max_p() { return 256; }
+
+static int sink_grid(long long M) {
+    const long long ntiles = (M + 63) / 64;
+    long long g = (ntiles + 3) / 4;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+int sink_pass_rows(long long M) { return sink_grid(M); }
+
+hipError_t sink_pass(hipStream_t s, int mode, const float* d_lum, GridSpec gs, const Sample4* d_samples,
+                     int p, const double* d_w, float nsw, float npw, long long pix0, long long M, double eps,
+                     double* d_ybuf, double* d_partial) {
+    const int pp = (p + 15) & ~15;
+    const int grid = sink_grid(M);
+#define NLE_SP_CASE(PPV)                                                                                  \
+    case PPV:                                                                                             \
+        hipLaunchKernelGGL((k_sink_pass<PPV>), dim3(grid), dim3(256), 0, s, mode, d_lum, gs, d_samples,  \
+                           d_w, nsw, npw, (unsigned)pix0, M, eps, d_ybuf, d_partial);                     \
+        break;
+    switch (pp) {
+        NLE_SP_CASE(16)
+        NLE_SP_CASE(32)
+        NLE_SP_CASE(48)
+        NLE_SP_CASE(64)
+        NLE_SP_CASE(80)
+        NLE_SP_CASE(96)
+        NLE_SP_CASE(112)
+        NLE_SP_CASE(128)
+        NLE_SP_CASE(144)
+        NLE_SP_CASE(160)
+        NLE_SP_CASE(176)
+        NLE_SP_CASE(192)
+        NLE_SP_CASE(208)
+        NLE_SP_CASE(224)
+        NLE_SP_CASE(240)
+        NLE_SP_CASE(256)
+        default:
+            return hipErrorInvalidValue;
+    }
+#undef NLE_SP_CASE
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ Sinkhorn update (p-, r-sized)
+// After the pass with scaling vector u (and w = B u):  y_a = 1 or recip(V_A[a] . u) for the
+// p sample pixels (exact fp64 rows, :275 top block), t = B^T z + V_A^T y_A, u' = lambda o t,
+// w' = B u'.  One workgroup; B, V_A are p x r column-major fp64.
+__global__ __launch_bounds__(1024) void k_sink_update(int mode, int p, int r, const double* __restrict__ Bm,
+                                                      const double* __restrict__ VA,
+                                                      const double* __restrict__ lam,
+                                                      const double* __restrict__ z, int zrows, int zld,
+                                                      const double* __restrict__ u_cur, double eps,
+                                                      double* __restrict__ u_next, double* __restrict__ w_next,
+                                                      int w_len) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* sz = reinterpret_cast<double*>(smem_raw);  // [p]
+    double* sy = sz + p;                               // [p]
+    double* su = sy + p;                               // [r]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    for (int k = tid; k < r; k += blockDim.x) su[k] = (mode == ROWPASS_COLSUM) ? 0.0 : u_cur[k];
+    for (int a = tid; a < p; a += blockDim.x) {
+        double t = 0.0;
+        for (int q = 0; q < zrows; ++q) t += z[(size_t)q * zld + a];  // fixed order
+        sz[a] = t;
+    }
+    __syncthreads();
+    for (int a = tid; a < p; a += blockDim.x) {
+        double y = 1.0;
+        if (mode != ROWPASS_COLSUM) {
+            double s = 0.0;
+            for (int k = 0; k < r; ++k) s += VA[(size_t)k * p + a] * su[k];
+            y = recip_or_zero_d(s, eps);
+        }
+        sy[a] = y;
+    }
+    __syncthreads();
+    for (int k = wave; k < r; k += nw) {
+        double s = 0.0;
+        for (int a = lane; a < p; a += 64) s += Bm[(size_t)k * p + a] * sz[a] + VA[(size_t)k * p + a] * sy[a];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) {
+            const double uk = lam[k] * s;
+            u_next[k] = uk;
+            su[k] = uk;  // su is not read between the two barriers around this loop by other waves
+        }
+    }
+    __syncthreads();
+    for (int a = tid; a < w_len; a += blockDim.x) {
+        double s = 0.0;
+        if (a < p)
+            for (int k = 0; k < r; ++k) s += Bm[(size_t)k * p + a] * su[k];
+        w_next[a] = s;
+    }
+}
+
+hipError_t sink_update(hipStream_t s, int mode, int p, int r, const double* d_B, const double* d_VA,
+                       const double* d_lam, const double* d_z, int zrows, int zld, const double* d_u_cur,
+                       double eps, double* d_u_next, double* d_w_next, int w_len) {
+    const size_t shm = (size_t)(2 * p + r) * sizeof(double);
+    hipLaunchKernelGGL(k_sink_update, dim3(1), dim3(1024), shm, s, mode, p, r, d_B, d_VA, d_lam, d_z, zrows, zld,
+                       d_u_cur, eps, d_u_next, d_w_next, w_len);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ Gram in sample space (fp64 MFMA)
+// Gk = sum over the local NON-sample pixels of c_i^2 k_i k_i^T (p x p), the N-sized part of
+// Wab*Wab^T (:296).  In sample space this matrix needs ~1e-9 relative accuracy (DESIGN.md
+// "Numerics"): products and sums run on v_mfma_f64_16x16x4_f64 (fp64 in, fp64 accumulate).
+// grid.x = row chunks, grid.y = groups of 4*kG64TilesPerWave upper-triangular 16x16 tiles.
+// Each stage the block generates 32 rows z_i = c_i k_i (fp64) into LDS: one wave per row, lane
+// = sample, so the ds_write_b64 are contiguous; every lane keeps its <= 4 samples in registers.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kG64Rows = 32;
+
+int gram64_ld(int p) { return (p + 15) & ~15; }
+int gram64_num_tiles(int p) {
+    const int nt = gram64_ld(p) / 16;
+    return nt * (nt + 1) / 2;
+}
+static int gram64_chunk_rows(long long M) {
+    long long fl = (M + 511) / 512;
+    fl = ((fl + kG64Rows - 1) / kG64Rows) * kG64Rows;
+    return (int)std::max<long long>(fl, kG64Rows);
+}
+static long long gram64_num_chunks(long long M) {
+    const int fl = gram64_chunk_rows(M);
+    return (M + fl - 1) / fl;
+}
+size_t gram64_partial_elems(long long M, int p) {
+    return (size_t)gram64_num_chunks(M) * gram64_num_tiles(p) * 256;
+}
+
+template <int TPW>
+__global__ __launch_bounds__(256) void k_gram64(const float* __restrict__ lum, GridSpec gs,
+                                                const Sample4* __restrict__ samples, int p, int ld16, int ldz,
+                                                float nsw, float npw, unsigned pix0, long long M,
+                                                const double* __restrict__ cvec, int chunk_rows, int ntiles,
+                                                double* __restrict__ partial) {
+    constexpr int RB = kG64Rows, RW = RB / 4;  // rows per stage, rows generated per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* sZ = reinterpret_cast<double*>(smem_raw);  // [RB][ldz]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int nt = ld16 >> 4;
+
+    // tile j of this wave: byte offsets of its A / B column inside an LDS row.  Slots past the
+    // tile list alias tile 0 (computed, never stored) so that the MFMA loop is branch-free.
+    int offA[TPW], offB[TPW];
+    const int tbase = (blockIdx.y * 4 + wave) * TPW;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        int t = tbase + j, ti = 0;
+        if (t >= ntiles) t = 0;
+        while (t >= nt - ti) {
+            t -= nt - ti;
+            ++ti;
+        }
+        offA[j] = (ti * 16 + l15) * 8;
+        offB[j] = ((ti + t) * 16 + l15) * 8;
+    }
+    f64x4 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[j] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    // this lane's samples: s = lane + 64 m
+    Sample4 ms[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int sidx = lane + 64 * m;
+        ms[m] = (sidx < p) ? samples[sidx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    const long long c0 = (long long)blockIdx.x * chunk_rows;
+    const long long c1 = min(M, c0 + (long long)chunk_rows);
+    // lanes 0..RW-1 fetch (row, col, lum, c) of the RW rows this wave generates in a stage; the
+    // fetch for stage n+1 is issued before the MFMA loop of stage n
+    auto fetch = [&](long long rb, float& fr, float& fc, float& fx, double& fcf) {
+        const long long li = rb + wave * RW + (lane & (RW - 1));
+        const bool valid = li < c1;
+        const unsigned gi = pix0 + (unsigned)(valid ? li : c1 - 1);
+        const unsigned row = gi / (unsigned)gs.W, col = gi - row * (unsigned)gs.W;
+        fr = (float)row;
+        fc = (float)col;
+        fx = lum[gi];
+        fcf = (valid && !is_sample_pixel(gs, (int)row, (int)col)) ? cvec[li] : 0.0;
+    };
+    float q_r, q_c, q_x;
+    double q_cf;
+    fetch(c0, q_r, q_c, q_x, q_cf);
+    for (long long rb = c0; rb < c1; rb += RB) {
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const float pr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q_r), rr));
+            const float pc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q_c), rr));
+            const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q_x), rr));
+            const int clo = __builtin_amdgcn_readlane((int)(__double_as_longlong(q_cf) & 0xffffffffll), rr);
+            const int chi = __builtin_amdgcn_readlane((int)(__double_as_longlong(q_cf) >> 32), rr);
+            const double cf = __longlong_as_double(((long long)chi << 32) | (unsigned)clo);
+            double* zrow = sZ + (size_t)(wave * RW + rr) * ldz;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int sidx = lane + 64 * m;
+                if (sidx < ld16)
+                    zrow[sidx] = (sidx < p) ? cf * (double)affinity_value(pr, pc, px, ms[m], nsw, npw) : 0.0;
+            }
+        }
+        if (rb + RB < c1) fetch(rb + RB, q_r, q_c, q_x, q_cf);
+        __syncthreads();
+        const char* zbase = reinterpret_cast<const char*>(sZ) + (size_t)kq * ldz * 8;
+#pragma unroll
+        for (int kk = 0; kk < RB; kk += 4) {
+            const char* zr = zbase + (size_t)kk * ldz * 8;
+            // all operand reads of the k-step first (2*TPW LDS reads in flight), then the MFMAs
+            double av[TPW], bv[TPW];
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                av[j] = *reinterpret_cast<const double*>(zr + offA[j]);
+                bv[j] = *reinterpret_cast<const double*>(zr + offB[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], bv[j], acc[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        if (tbase + j < ntiles) {
+            double* out = partial + ((size_t)blockIdx.x * ntiles + (tbase + j)) * 256;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[(kq + 4 * e) * 16 + l15] = acc[j][e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gram64_reduce(const double* __restrict__ partial, int nchunks, int ntiles,
+                                                       double* __restrict__ tiles) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)ntiles * 256;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int c = 0;
+    for (; c + 3 < nchunks; c += 4) {
+        s0 += partial[(size_t)c * stride + e];
+        s1 += partial[(size_t)(c + 1) * stride + e];
+        s2 += partial[(size_t)(c + 2) * stride + e];
+        s3 += partial[(size_t)(c + 3) * stride + e];
+    }
+    for (; c < nchunks; ++c) s0 += partial[(size_t)c * stride + e];
+    tiles[e] = (s0 + s1) + (s2 + s3);
+}
+
+template <int TPW>
+static hipError_t launch_gram64(hipStream_t s, dim3 grid, size_t shm, const float* d_lum, GridSpec gs,
+                                const Sample4* d_samples, int p, int ld16, int ldz, float nsw, float npw,
+                                long long pix0, long long M, const double* d_c, int fl, int ntiles,
+                                double* d_partial) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram64<TPW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_gram64<TPW>), grid, dim3(256), shm, s, d_lum, gs, d_samples, p, ld16, ldz, nsw, npw,
+                       (unsigned)pix0, M, d_c, fl, ntiles, d_partial);
+    return hipGetLastError();
+}
+
+hipError_t gram64(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples, int p, float nsw,
+                  float npw, long long pix0, long long M, const double* d_c, double* d_partial, double* d_tiles) {
+    if (p > 256) return hipErrorInvalidValue;
+    const int ld16 = gram64_ld(p);
+    const int ldz = ld16 + ((ld16 % 32 == 16) ? 0 : 16);  // row stride == 16 (mod 32) doubles: conflict-free b64 reads
+    const int ntiles = gram64_num_tiles(p);
+    const int fl = gram64_chunk_rows(M);
+    const long long nchunks = gram64_num_chunks(M);
+    const size_t shm = (size_t)kG64Rows * ldz * sizeof(double);
+    // tiles per wave: the smallest of {4, 8, 12, 16, 20, 23} that covers the list with one group
+    static const int kTpw[6] = {4, 8, 12, 16, 20, kG64TilesPerWave};
+    int tpw = kG64TilesPerWave;
+    for (int i = 0; i < 6; ++i)
+        if (4 * kTpw[i] >= ntiles) {
+            tpw = kTpw[i];
+            break;
+        }
+    const int groups = (ntiles + 4 * tpw - 1) / (4 * tpw);
+    const dim3 grid((unsigned)nchunks, (unsigned)groups);
+    hipError_t e;
+#define NLE_G64(T) e = launch_gram64<T>(s, grid, shm, d_lum, gs, d_samples, p, ld16, ldz, nsw, npw, pix0, M, d_c, fl, ntiles, d_partial)
+    switch (tpw) {
+        case 4: NLE_G64(4); break;
+        case 8: NLE_G64(8); break;
+        case 12: NLE_G64(12); break;
+        case 16: NLE_G64(16); break;
+        case 20: NLE_G64(20); break;
+        default: NLE_G64(kG64TilesPerWave); break;
+    }
+#undef NLE_G64
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gram64_reduce, dim3((unsigned)ntiles), dim3(256), 0, s, d_partial, (int)nchunks, ntiles,
+                       d_tiles);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ projection in sample space (fp64 MFMA)
+// V_i = c_i k_i^T D  (D = P[:, :q] R_A T2, p x K', reference :327 in sample space): the Nystrom
+// extension of the K' retained eigenvectors to every pixel.  D has entries of both signs up to
+// ~1e3 that cancel in the product, so D stays fp64 and the contraction runs on
+// v_mfma_f64_16x16x4_f64; the A operand (lane: pixel l&15, sample k0 + (l>>4)) is the affinity
+// generated in registers.  Block = 4 waves x 32 pixels; D is staged through LDS in 32-sample chunks.
+template <int NT>
+__global__ __launch_bounds__(256) void k_project64(const float* __restrict__ lum, GridSpec gs,
+                                                   const Sample4* __restrict__ samples, int p, float nsw,
+                                                   float npw, unsigned pix0, long long M,
+                                                   const double* __restrict__ Dm, int ldd,
+                                                   const double* __restrict__ cvec, float* __restrict__ V, int ldv) {
+    constexpr int KB = 32;
+    constexpr int LDB = NT * 16 + ((NT & 1) ? 0 : 16);
+    __shared__ __attribute__((aligned(16))) double sB[KB][LDB];
+    __shared__ Sample4 sS[KB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const long long m0 = (long long)blockIdx.x * 128 + wave * 32;
+
+    float pr[2], pc[2], px[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        long long li = m0 + mt * 16 + l15;
+        if (li >= M) li = M - 1;
+        const unsigned gi = pix0 + (unsigned)li;
+        const unsigned row = gi / (unsigned)gs.W;
+        pr[mt] = (float)row;
+        pc[mt] = (float)(gi - row * (unsigned)gs.W);
+        px[mt] = lum[gi];
+    }
+    f64x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[mt][n] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    for (int k0 = 0; k0 < p; k0 += KB) {
+        __syncthreads();
+        for (int idx = tid; idx < KB * NT * 16; idx += 256) {
+            const int kk = idx / (NT * 16), cc = idx % (NT * 16);
+            sB[kk][cc] = (k0 + kk < p && cc < ldd) ? Dm[(size_t)(k0 + kk) * ldd + cc] : 0.0;
+        }
+        if (tid < KB) sS[tid] = (k0 + tid < p) ? samples[k0 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+#pragma unroll 2
+        for (int kk = 0; kk < KB; kk += 4) {
+            const Sample4 sm = sS[kk + kq];
+            const double a0 = (double)affinity_value(pr[0], pc[0], px[0], sm, nsw, npw);
+            const double a1 = (double)affinity_value(pr[1], pc[1], px[1], sm, nsw, npw);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const double bv = sB[kk + kq][n * 16 + l15];
+                acc[0][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1][n], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long long li = m0 + mt * 16 + kq + 4 * e;
+            if (li < M) {
+                const double cf = cvec[li];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int col = n * 16 + l15;
+                    if (col < ldv) V[(size_t)li * ldv + col] = (float)(cf * acc[mt][n][e]);
+                }
+            }
+        }
+}
+
+int project64_ld(int K) { return (K + 15) & ~15; }
+
+hipError_t project64(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples, int p, float nsw,
+                     float npw, long long pix0, long long M, const double* d_D, int K, const double* d_c, float* d_V,
+                     int ldv) {
+    if (M <= 0) return hipSuccess;
+    const int ldd = project64_ld(K);
+    const int nt = ldd / 16;
+    const dim3 grid((unsigned)((M + 127) / 128)), block(256);
+#define NLE_PJ_CASE(NTV)                                                                                   \
+    case NTV:                                                                                              \
+        hipLaunchKernelGGL((k_project64<NTV>), grid, block, 0, s, d_lum, gs, d_samples, p, nsw, npw,      \
+                           (unsigned)pix0, M, d_D, ldd, d_c, d_V, ldv);                                    \
+        break;
+    switch (nt) {
+        NLE_PJ_CASE(1)
+        NLE_PJ_CASE(2)
+        NLE_PJ_CASE(3)
+        NLE_PJ_CASE(4)
+        NLE_PJ_CASE(5)
+        NLE_PJ_CASE(6)
+        NLE_PJ_CASE(7)
+        NLE_PJ_CASE(8)
+        default:
+            return hipErrorInvalidValue;
+    }
+#undef NLE_PJ_CASE
+    return hipGetLastError();
+}
+
+}  // namespace nlek

@@ -15,6 +15,23 @@ struct GridSpec {
 // {row, col, luminance, 0} of one sample, fp32 (coordinates are exact in fp32)
 typedef float4 Sample4;  // x = row, y = col, z = luminance, w = 0
 
+#if defined(__HIPCC__)
+// K(i, s) = exp(negativeWeightedDistance) (reference src/filter.cpp:104-112,144-145) in base 2:
+// nsw = -log2(e)/hx^2, npw = -log2(e)/hy^2, one v_exp_f32.  The spatial term is exact in fp32
+// (integer coordinates, H*W < 2^24 keeps dr^2+dc^2 < 2^25; it is rounded once above that).
+__device__ __forceinline__ float affinity_value(float pr, float pc, float px, Sample4 s, float nsw, float npw) {
+    const float dr = pr - s.x, dc = pc - s.y, dv = px - s.z;
+    return __builtin_amdgcn_exp2f(nsw * (dr * dr + dc * dc) + npw * (dv * dv));
+}
+// closed form of the selection predicate of samplePixels (src/filter.cpp:68-70)
+__device__ __forceinline__ bool is_sample_pixel(const GridSpec& gs, int row, int col) {
+    const int dr = row - gs.rowOff, dc = col - gs.colOff;
+    if (dr < 0 || dc < 0) return false;
+    const int qr = dr / gs.rowStep, qc = dc / gs.colStep;
+    return (qr * gs.rowStep == dr) && (qc * gs.colStep == dc) && qr < gs.nSelRows && qc < gs.nSelCols;
+}
+#endif
+
 constexpr int kRowpassMaxBlocks = 1024;
 constexpr int kGramTilesPerWave = 7;
 constexpr int kGramRowsPerStage = 32;
@@ -24,18 +41,19 @@ enum RowpassMode { ROWPASS_COLSUM = 0, ROWPASS_RECIP = 1, ROWPASS_XVEC = 2 };
 // out[k] = lum[sel_index(k)] for the p samples
 hipError_t gather_samples(hipStream_t s, const float* d_lum, GridSpec gs, float* d_out);
 
-// K_AB rows, natural order: kab[i][s] = exp(-(sw*d2 + pw*dv^2)), i in [pix0, pix0+M)
+// K_AB rows, natural order: kab[i][s] = exp2(nsw*d2 + npw*dv^2), i in [pix0, pix0+M)
 hipError_t affinity(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples,
-                    int p, int ld, float sw, float pw, long long pix0, long long M,
+                    int p, int ld, float nsw, float npw, long long pix0, long long M,
                     float* d_kab);
 
 // C (M x ldc) = rowscale o (A x B).  B: kd x ldb fp32 row-major (zero padded to ldc cols).
 // fused != 0: A rows are affinities computed on the fly from (lum, samples); else A is
-// read from d_A (M x lda).  d_u != null (non-fused): rowscale_i = recip(A_i . u).
+// read from d_A (M x lda).  d_u != null (non-fused): rowscale_i = recip(A_i . u);
+// d_c != null (fused): rowscale_i = c_i.
 hipError_t ts_gemm(hipStream_t s, bool fused, const float* d_A, int lda, const float* d_lum,
-                   GridSpec gs, const Sample4* d_samples, float sw, float pw, long long pix0,
+                   GridSpec gs, const Sample4* d_samples, float nsw, float npw, long long pix0,
                    const float* d_B, int ldb, int kd, float* d_C, int ldc, long long M,
-                   const double* d_u, double eps);
+                   const double* d_u, double eps, const float* d_c = nullptr);
 
 // One pass over X (M x ld): partial[b][j] = sum_{rows of block b} X[i][j] * y_i,
 //   mode COLSUM: y=1; RECIP: y_i = recip(X_i . (lam o t_in)); XVEC: y_i = xvec[i].
@@ -43,9 +61,10 @@ hipError_t ts_gemm(hipStream_t s, bool fused, const float* d_A, int lda, const f
 hipError_t rowpass(hipStream_t s, int mode, const float* d_X, long long M, int ld,
                    const double* d_t_in, const double* d_lam, const float* d_xvec, double eps,
                    double* d_partial, int* nblocks);
-// t_out[j] = sum_b partial[b][j], j < ld
+// t_out[sl][j] = sum over the sl-th slice of blocks of partial[b][j], j < ld (nslices rows out;
+// nslices == 1: the full column sums)
 hipError_t reduce_partials(hipStream_t s, const double* d_partial, int nblocks, int ld,
-                           double* d_t_out);
+                           double* d_t_out, int nslices = 1);
 // u[j] = lam[j] * t[j]
 hipError_t scale_vec(hipStream_t s, const double* d_lam, const double* d_t, int n, double* d_u);
 // out[i] = recip(X_i . u)
@@ -60,6 +79,36 @@ int gram_chunk_rows(long long M);
 size_t gram_partial_elems(long long M, int ld);
 hipError_t gram(hipStream_t s, const float* d_X, long long M, int ld, const double* d_u,
                 double eps, double* d_partial, double* d_tiles);
+hipError_t gram_reduce(hipStream_t s, const double* d_partial, int nchunks, int ntiles, double* d_tiles);
+
+// ---- Phi-free ("sample space") passes, fused.hip ----
+// Sinkhorn half-iteration without Phi: z[s] = sum_i k_i[s] y_i over non-sample local pixels,
+// y_i = 1 (COLSUM) or recip(k_i . w); partial: [sink_pass_rows(M)][sink_pass_ld(p)] doubles.
+// d_ybuf (optional): y_i per local pixel, fp64 (0 at sample pixels).  p <= sink_pass_max_p().
+int sink_pass_ld(int p);
+int sink_pass_rows(long long M);
+int sink_pass_max_p();
+hipError_t sink_pass(hipStream_t s, int mode, const float* d_lum, GridSpec gs, const Sample4* d_samples,
+                     int p, const double* d_w, float nsw, float npw, long long pix0, long long M, double eps,
+                     double* d_ybuf, double* d_partial);
+// p/r-sized update between passes (one workgroup): see fused.hip
+// d_z: zrows x zld partial column sums, added in row order
+hipError_t sink_update(hipStream_t s, int mode, int p, int r, const double* d_B, const double* d_VA,
+                       const double* d_lam, const double* d_z, int zrows, int zld, const double* d_u_cur,
+                       double eps, double* d_u_next, double* d_w_next, int w_len);
+// Gk = sum over non-sample local pixels of c_i^2 k_i k_i^T on the fp64 MFMA; upper-triangular
+// 16x16 tiles (row-major 256 doubles each), p <= 256.
+constexpr int kG64TilesPerWave = 23;
+int gram64_ld(int p);
+int gram64_num_tiles(int p);
+size_t gram64_partial_elems(long long M, int p);
+hipError_t gram64(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples, int p, float nsw,
+                  float npw, long long pix0, long long M, const double* d_c, double* d_partial, double* d_tiles);
+// V (M x ldv fp32) = diag(c) K D on the fp64 MFMA; D: p x project64_ld(K) fp64 row-major, K <= 128
+int project64_ld(int K);
+hipError_t project64(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples, int p, float nsw,
+                     float npw, long long pix0, long long M, const double* d_D, int K, const double* d_c, float* d_V,
+                     int ldv);
 
 // Y[l][i] = sum_k V[i][k] * g[l][k]   (g: L x ld doubles, device)
 hipError_t apply_expand(hipStream_t s, const float* d_V, long long M, int ld, const double* d_g,

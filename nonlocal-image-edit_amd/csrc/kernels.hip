@@ -25,14 +25,6 @@ __device__ __forceinline__ double recip_or_zero(double s, double eps) {
     return (fabs(s) >= eps) ? 1.0 / s : 0.0;
 }
 
-__device__ __forceinline__ float affinity_value(float pr, float pc, float px, Sample4 s, float sw,
-                                                float pw) {
-    // negativeWeightedDistance (src/filter.cpp:104-112) then exp (:144-145)
-    const float dr = pr - s.x, dc = pc - s.y, dv = px - s.z;
-    const float e = -(sw * (dr * dr + dc * dc) + pw * (dv * dv));
-    return __expf(e);
-}
-
 // ------------------------------------------------------------------ gather samples
 __global__ void k_gather_samples(const float* __restrict__ lum, GridSpec gs, float* __restrict__ out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -56,7 +48,7 @@ constexpr int kAffPix = 128;
 
 __global__ __launch_bounds__(256) void k_affinity(const float* __restrict__ lum, GridSpec gs,
                                                   const Sample4* __restrict__ samples, int p,
-                                                  int ld, float sw, float pw, unsigned pix0,
+                                                  int ld, float nsw, float npw, unsigned pix0,
                                                   long long M, float* __restrict__ kab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Sample4* ss = reinterpret_cast<Sample4*>(smem_raw);
@@ -82,22 +74,22 @@ __global__ __launch_bounds__(256) void k_affinity(const float* __restrict__ lum,
             const float px = lum[gi];
             float4 o;
             const unsigned s0 = 4 * q;
-            o.x = (s0 + 0 < (unsigned)p) ? affinity_value(pr, pc, px, ss[s0 + 0], sw, pw) : 0.f;
-            o.y = (s0 + 1 < (unsigned)p) ? affinity_value(pr, pc, px, ss[s0 + 1], sw, pw) : 0.f;
-            o.z = (s0 + 2 < (unsigned)p) ? affinity_value(pr, pc, px, ss[s0 + 2], sw, pw) : 0.f;
-            o.w = (s0 + 3 < (unsigned)p) ? affinity_value(pr, pc, px, ss[s0 + 3], sw, pw) : 0.f;
+            o.x = (s0 + 0 < (unsigned)p) ? affinity_value(pr, pc, px, ss[s0 + 0], nsw, npw) : 0.f;
+            o.y = (s0 + 1 < (unsigned)p) ? affinity_value(pr, pc, px, ss[s0 + 1], nsw, npw) : 0.f;
+            o.z = (s0 + 2 < (unsigned)p) ? affinity_value(pr, pc, px, ss[s0 + 2], nsw, npw) : 0.f;
+            o.w = (s0 + 3 < (unsigned)p) ? affinity_value(pr, pc, px, ss[s0 + 3], nsw, npw) : 0.f;
             *reinterpret_cast<float4*>(out + (size_t)f * 4) = o;
         }
     }
 }
 
 hipError_t affinity(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples,
-                    int p, int ld, float sw, float pw, long long pix0, long long M, float* d_kab) {
+                    int p, int ld, float nsw, float npw, long long pix0, long long M, float* d_kab) {
     if (M <= 0) return hipSuccess;
     const long long ngroups = (M + kAffPix - 1) / kAffPix;
     const int grid = (int)min(ngroups, (long long)8192);
     hipLaunchKernelGGL(k_affinity, dim3(grid), dim3(256), (size_t)ld * sizeof(Sample4), s, d_lum, gs,
-                       d_samples, p, ld, sw, pw, (unsigned)pix0, M, d_kab);
+                       d_samples, p, ld, nsw, npw, (unsigned)pix0, M, d_kab);
     return hipGetLastError();
 }
 
@@ -113,7 +105,7 @@ struct TsArgs {
     const float* lum;
     GridSpec gs;
     const Sample4* samples;
-    float sw, pw;
+    float nsw, npw;
     unsigned pix0;
     const float* B;
     int ldb;
@@ -123,6 +115,7 @@ struct TsArgs {
     long long M;
     const double* u;
     double eps;
+    const float* cvec;
 };
 
 template <int NT, bool FUSED>
@@ -197,7 +190,7 @@ __global__ __launch_bounds__(256) void k_tsgemm(TsArgs a) {
             const int kl = kk + half;
             float av;
             if constexpr (FUSED) {
-                av = affinity_value(pr, pc, px, sS[kl], a.sw, a.pw);
+                av = affinity_value(pr, pc, px, sS[kl], a.nsw, a.npw);
             } else {
                 av = sA[wave * 32 + l31][kl];
             }
@@ -209,6 +202,10 @@ __global__ __launch_bounds__(256) void k_tsgemm(TsArgs a) {
         }
     }
 
+    if constexpr (FUSED) {
+        if (a.cvec != nullptr && tid < 128) sScale[tid] = (m0 + tid < a.M) ? a.cvec[m0 + tid] : 0.f;
+    }
+    const bool rowscale = scale || (FUSED && a.cvec != nullptr);
     if (scale) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -229,7 +226,7 @@ __global__ __launch_bounds__(256) void k_tsgemm(TsArgs a) {
             const long long grow = m0 + rl;
             if (grow < a.M && col < a.ldc) {
                 float v = acc[n][e];
-                if (scale) v *= sScale[rl];
+                if (rowscale) v *= sScale[rl];
                 a.C[(size_t)grow * a.ldc + col] = v;
             }
         }
@@ -263,9 +260,9 @@ static hipError_t launch_tsgemm(hipStream_t s, const TsArgs& a) {
 }
 
 hipError_t ts_gemm(hipStream_t s, bool fused, const float* d_A, int lda, const float* d_lum,
-                   GridSpec gs, const Sample4* d_samples, float sw, float pw, long long pix0,
+                   GridSpec gs, const Sample4* d_samples, float nsw, float npw, long long pix0,
                    const float* d_B, int ldb, int kd, float* d_C, int ldc, long long M,
-                   const double* d_u, double eps) {
+                   const double* d_u, double eps, const float* d_c) {
     if (M <= 0) return hipSuccess;
     TsArgs a;
     a.A = d_A;
@@ -273,8 +270,8 @@ hipError_t ts_gemm(hipStream_t s, bool fused, const float* d_A, int lda, const f
     a.lum = d_lum;
     a.gs = gs;
     a.samples = d_samples;
-    a.sw = sw;
-    a.pw = pw;
+    a.nsw = nsw;
+    a.npw = npw;
     a.pix0 = (unsigned)pix0;
     a.B = d_B;
     a.ldb = ldb;
@@ -284,6 +281,7 @@ hipError_t ts_gemm(hipStream_t s, bool fused, const float* d_A, int lda, const f
     a.M = M;
     a.u = d_u;
     a.eps = eps;
+    a.cvec = d_c;
     return fused ? launch_tsgemm<true>(s, a) : launch_tsgemm<false>(s, a);
 }
 
@@ -425,28 +423,31 @@ hipError_t rowpass(hipStream_t s, int mode, const float* d_X, long long M, int l
     return hipGetLastError();
 }
 
-// partial [nb][ld] -> t_out[ld]; block = 32 columns x 8 slices of the block range
+// partial [nb][ld] -> t_out[nslices][ld]; block (x, y) = 32 columns x the y-th contiguous slice of
+// the rows, 8 threads per column each summing every 8th row of the slice (fixed order)
 __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partial, int nb,
                                                          int ld, double* __restrict__ t_out) {
     __shared__ double sm[8][32];
     const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int col = blockIdx.x * 32 + c;
+    const int per = (nb + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(nb, b0 + per);
     double s = 0.0;
     if (col < ld)
-        for (int b = sl; b < nb; b += 8) s += partial[(size_t)b * ld + col];
+        for (int b = b0 + sl; b < b1; b += 8) s += partial[(size_t)b * ld + col];
     sm[sl][c] = s;
     __syncthreads();
     if (sl == 0 && col < ld) {
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += sm[k][c];
-        t_out[col] = t;
+        t_out[(size_t)blockIdx.y * ld + col] = t;
     }
 }
 
 hipError_t reduce_partials(hipStream_t s, const double* d_partial, int nblocks, int ld,
-                           double* d_t_out) {
-    hipLaunchKernelGGL(k_reduce_partials, dim3((ld + 31) / 32), dim3(256), 0, s, d_partial, nblocks, ld,
+                           double* d_t_out, int nslices) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3((ld + 31) / 32, nslices), dim3(256), 0, s, d_partial, nblocks, ld,
                        d_t_out);
     return hipGetLastError();
 }
@@ -667,8 +668,12 @@ hipError_t gram(hipStream_t s, const float* d_X, long long M, int ld, const doub
                        eps, fl, ntiles, d_partial);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ntiles, 4), dim3(256), 0, s, d_partial, (int)nchunks,
-                       ntiles, d_tiles);
+    return gram_reduce(s, d_partial, (int)nchunks, ntiles, d_tiles);
+}
+
+hipError_t gram_reduce(hipStream_t s, const double* d_partial, int nchunks, int ntiles, double* d_tiles) {
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ntiles, 4), dim3(256), 0, s, d_partial, nchunks, ntiles,
+                       d_tiles);
     return hipGetLastError();
 }
 

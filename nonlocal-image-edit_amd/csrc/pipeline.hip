@@ -31,6 +31,7 @@ struct nle_ctx {
     std::string err;
     // per-kernel HIP-event timing (nle_ctx_profile): records are resolved at the next
     // point where the stream is synchronised anyway
+    int mode = 0;  // nle_ctx_set_mode: 0 auto, 1 materialised Phi, 2 Phi-free
     bool profiling = false;
     struct ProfRec {
         int kid;
@@ -117,6 +118,10 @@ struct Timer {
 };
 
 inline int ld4(int n) { return (n + 3) & ~3; }
+
+// exp(-d2/hx^2 - dv^2/hy^2) = exp2(nsw*d2 + npw*dv^2)  (reference src/filter.cpp:128-129,144-145)
+constexpr double kLog2e = 1.4426950408889634074;
+inline float nsw_of(double h) { return (float)(-kLog2e / (h * h)); }
 
 // ---- per-kernel event timing (nle_ctx_profile) ----
 hipEvent_t prof_event(nle_ctx* c) {
@@ -304,7 +309,7 @@ void build_phi(nle_ctx* c, const float* d_lum, const SampleSet& ss, const Nystro
     std::vector<float> B = build_B(ny, p);
     DevBuf<float> d_B(B.size());
     HIP_OK(hipMemcpyAsync(d_B.p, B.data(), B.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    const float sw = (float)(1.0 / (hx * hx)), pw = (float)(1.0 / (hy * hy));
+    const float sw = nsw_of(hx), pw = nsw_of(hy);
     PROFILED(c, NLE_K_NYSTROM, nlek::ts_gemm(c->stream, true, nullptr, 0, d_lum, ss.gs, d_samples.p, sw, pw, pix0,
                                              d_B.p, ny.ldr, p, d_phi, ny.ldr, M, nullptr, NLE_EPS));
     // sample pixels carry their exact V_A row (top block of phi, reference :275)
@@ -547,6 +552,296 @@ Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_
     return o;
 }
 
+// ---- orthogonalisation in sample space (Phi-free path) ----
+// Inputs: V_A (p x r), lambda, the two final Sinkhorn scaling vectors and
+//   Gk = sum over NON-sample pixels of c_i^2 k_i k_i^T  (p x p, from k_gram_fused).
+// With P = V_r V_r^T (projector on range(Ka); I when r == p) and Kr = V_r L V_r^T:
+//   phi_a L phi_j^T = (P k_j)[a]  for a sample a and a pixel j, so (reference :247-250, q = r)
+//   Wa  = R_A Kr[:q,:q] C_A,   Wab Wab^T = R_A (P Gk' P)[:q,:q] R_A,
+//   Gk' = Gk + sum_{samples a >= q} c_a^2 Kr[:,a] Kr[:,a]^T   (samples that fall in the B block),
+//   V_j = c_j k_j^T D,  D = P[:, :q] R_A T2,  T2 = S Vq Sq^-1/2   (:327), V_A rows = Wa T2.
+// No 1/lambda factor appears anywhere: the ill-conditioned B = V_A / lambda is only used for
+// the r-vectors of the Sinkhorn update.
+struct OrthoSS {
+    int q = 0, K = 0;
+    std::vector<double> Sq, D, Vrows;  // D: p x K, Vrows: p x K (col-major)
+};
+
+OrthoSS orthogonalize_sample_space(const Nystrom& ny, int p, const std::vector<double>& u_c,
+                                   const std::vector<double>& u_r, std::vector<double> Gk, int n_eig) {
+    const int r = ny.r, q = ny.r;
+    std::vector<double> cA(p), rA(p);
+    for (int a = 0; a < p; ++a) {
+        double sc = 0.0, sr = 0.0;
+        for (int k = 0; k < r; ++k) {
+            const double v = ny.VA[(size_t)k * p + a];
+            sc += v * u_c[k];
+            sr += v * u_r[k];
+        }
+        cA[a] = recip0(sc);
+        rA[a] = recip0(sr);
+    }
+    std::vector<double> VL((size_t)p * r), Kr((size_t)p * p);
+    for (int k = 0; k < r; ++k)
+        for (int a = 0; a < p; ++a) VL[(size_t)k * p + a] = ny.VA[(size_t)k * p + a] * ny.lam[k];
+    mm_nt(VL.data(), ny.VA.data(), Kr.data(), p, r, p);
+    for (int a = q; a < p; ++a) {  // B-block samples
+        const double c2 = cA[a] * cA[a];
+        const double* ka = Kr.data() + (size_t)a * p;
+        for (int j = 0; j < p; ++j) {
+            const double vj = c2 * ka[j];
+            for (int i = 0; i < p; ++i) Gk[(size_t)j * p + i] += ka[i] * vj;
+        }
+    }
+    std::vector<double> P;
+    if (r < p) {
+        P.resize((size_t)p * p);
+        mm_nt(ny.VA.data(), ny.VA.data(), P.data(), p, r, p);
+        std::vector<double> T((size_t)p * p);
+        mm(P.data(), Gk.data(), T.data(), p, p, p);
+        mm(T.data(), P.data(), Gk.data(), p, p, p);
+    }
+    OrthoSS o;
+    o.q = q;
+    std::vector<double> Wa((size_t)q * q), WW((size_t)q * q);
+    for (int b = 0; b < q; ++b)
+        for (int a = 0; a < q; ++a) {
+            Wa[(size_t)b * q + a] = rA[a] * Kr[(size_t)b * p + a] * cA[b];   // :249
+            WW[(size_t)b * q + a] = rA[a] * Gk[(size_t)b * p + a] * rA[b];   // Wab Wab^T, :296
+        }
+    std::vector<double> U2((size_t)q * q), l2(q);
+    int r2 = 0;
+    if (!nleh::eigen_decomposition(Wa.data(), q, NLE_EPS, U2.data(), l2.data(), &r2))
+        throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Wa"};
+    std::vector<double> Us((size_t)q * std::max(r2, 1)), S((size_t)q * q);
+    for (int k = 0; k < r2; ++k) {
+        const double sv = std::sqrt(recip0(l2[k]));
+        for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * sv;
+    }
+    mm_nt(Us.data(), U2.data(), S.data(), q, r2, q);  // :287-292
+    std::vector<double> T1((size_t)q * q), Qm((size_t)q * q);
+    mm(S.data(), WW.data(), T1.data(), q, q, q);
+    mm(T1.data(), S.data(), Qm.data(), q, q, q);
+    for (size_t i = 0; i < Qm.size(); ++i) Qm[i] += Wa[i];  // :296
+    std::vector<double> Vq((size_t)q * q), Sq(q);
+    int rq = 0;
+    if (!nleh::eigen_decomposition(Qm.data(), q, NLE_EPS, Vq.data(), Sq.data(), &rq))
+        throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Q"};
+    const int K = std::min(n_eig, rq);  // :314
+    if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
+    o.K = K;
+    o.Sq.assign(Sq.begin(), Sq.begin() + K);
+    std::vector<double> T2((size_t)q * K), RT2((size_t)q * K);
+    mm(S.data(), Vq.data(), T2.data(), q, q, K);
+    for (int k = 0; k < K; ++k) {
+        const double sv = std::sqrt(recip0(Sq[k]));  // :319-321
+        for (int i = 0; i < q; ++i) {
+            T2[(size_t)k * q + i] *= sv;
+            RT2[(size_t)k * q + i] = rA[i] * T2[(size_t)k * q + i];
+        }
+    }
+    o.D.resize((size_t)p * K);
+    if (r < p) {
+        mm(P.data(), RT2.data(), o.D.data(), p, q, K);  // first q columns of P
+    } else {
+        o.D = RT2;
+    }
+    o.Vrows.assign((size_t)p * K, 0.0);
+    std::vector<double> WT((size_t)q * K);
+    mm(Wa.data(), T2.data(), WT.data(), q, q, K);  // top block of :327
+    for (int k = 0; k < K; ++k) {
+        for (int a = 0; a < q; ++a) o.Vrows[(size_t)k * p + a] = WT[(size_t)k * q + a];
+        for (int a = q; a < p; ++a) {
+            double sv = 0.0;
+            for (int j = 0; j < p; ++j) sv += Kr[(size_t)a * p + j] * o.D[(size_t)k * p + j];
+            o.Vrows[(size_t)k * p + a] = cA[a] * sv;
+        }
+    }
+    return o;
+}
+
+// unpack the upper-triangular 32x32 tile list of gram()/gram_fused() into a symmetric n x n matrix
+std::vector<double> unpack_tiles(const std::vector<double>& tiles, int ld, int n, int ts) {
+    std::vector<double> G((size_t)n * n, 0.0);
+    const int nt = (ld + ts - 1) / ts;
+    int t = 0;
+    for (int ti = 0; ti < nt; ++ti)
+        for (int tj = ti; tj < nt; ++tj, ++t) {
+            const double* tl = tiles.data() + (size_t)t * ts * ts;
+            for (int a = 0; a < ts; ++a)
+                for (int b = 0; b < ts; ++b) {
+                    const int i = ti * ts + a, j = tj * ts + b;
+                    if (i >= n || j >= n) continue;
+                    if (ti == tj && j < i) continue;  // diagonal tiles: take the upper half
+                    const double v = tl[a * ts + b];
+                    G[(size_t)j * n + i] = v;
+                    G[(size_t)i * n + j] = v;
+                }
+        }
+    return G;
+}
+
+void scatter_sample_rows(nle_ctx* c, const SampleSet& ss, int nrows, const std::vector<double>& rows_cm, int ldrows,
+                         int K, int ldv, long long pix0, long long M, float* d_V) {
+    std::vector<float> rows;
+    std::vector<long long> idx;
+    for (int a = 0; a < nrows; ++a) {
+        const long long loc = ss.pix[a] - pix0;
+        if (loc < 0 || loc >= M) continue;
+        idx.push_back(loc);
+        const size_t off = rows.size();
+        rows.resize(off + ldv, 0.f);
+        for (int k = 0; k < K; ++k) rows[off + k] = (float)rows_cm[(size_t)k * ldrows + a];
+    }
+    if (idx.empty()) return;
+    DevBuf<float> d_rows(rows.size());
+    DevBuf<long long> d_idx(idx.size());
+    HIP_OK(hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(d_idx.p, idx.data(), idx.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    PROFILED(c, NLE_K_SMALL, nlek::scatter_rows(c->stream, d_rows.p, d_idx.p, (int)idx.size(), ldv, d_V, M));
+    HIP_OK(hipStreamSynchronize(c->stream));  // staging vectors go out of scope
+}
+
+// ---- the two train paths; both fill f->K, ldv, eigvals, d_V ----
+struct StageMs {
+    double sinkhorn = 0, gram = 0, project = 0, host = 0;
+};
+
+// (1) materialised Phi: Phi = K_AB^T B written once (N x r fp32), streamed by every later pass
+void train_materialised(nle_ctx* c, nle_filter* f, const float* d_lum, const SampleSet& ss, const Nystrom& ny,
+                        double hx, double hy, int T, int n_eig, long long pix0, long long M, StageMs* ms) {
+    Timer tm_s(c->stream), tm_g(c->stream), tm_p(c->stream);
+    tm_s.start();
+    DevBuf<float> d_phi((size_t)std::max<long long>(M, 1) * ny.ldr);
+    build_phi(c, d_lum, ss, ny, hx, hy, pix0, M, d_phi.p);
+    std::vector<double> u_c, u_r;
+    DevBuf<double> d_u_c(ny.ldr);
+    sinkhorn_passes(c, d_phi.p, M, ny.ldr, ny.r, ny.lam, T, &u_c, &u_r, d_u_c.p);
+    tm_s.stop();
+    tm_g.start();
+    std::vector<double> G = gram_all(c, d_phi.p, M, ny.ldr, ny.r, d_u_c.p);
+    tm_g.stop();
+    double h0 = now_ms();
+    Ortho o = orthogonalize_host(ny, ss.p, u_c, u_r, std::move(G), n_eig);
+    ms->host += now_ms() - h0;
+    f->K = o.K;
+    f->ldv = ld4(o.K);
+    f->eigvals = o.Sq;
+    tm_p.start();
+    std::vector<float> Cp((size_t)ny.r * f->ldv, 0.f);
+    for (int k = 0; k < o.K; ++k)
+        for (int j = 0; j < ny.r; ++j) Cp[(size_t)j * f->ldv + k] = (float)o.Cproj[(size_t)k * ny.r + j];
+    DevBuf<float> d_Cp(Cp.size());
+    HIP_OK(hipMemcpyAsync(d_Cp.p, Cp.data(), Cp.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    DevBuf<float> d_V((size_t)std::max<long long>(M, 1) * f->ldv);
+    PROFILED(c, NLE_K_PROJECT, nlek::ts_gemm(c->stream, false, d_phi.p, ny.ldr, nullptr, ss.gs, nullptr, 0.f, 0.f, 0,
+                                             d_Cp.p, f->ldv, ny.r, d_V.p, f->ldv, M, d_u_c.p, NLE_EPS));
+    scatter_sample_rows(c, ss, o.q, o.VArows, o.q, o.K, f->ldv, pix0, M, d_V.p);
+    tm_p.stop();
+    HIP_OK(hipStreamSynchronize(c->stream));
+    f->d_V = d_V.take();
+    ms->sinkhorn = tm_s.ms();
+    ms->gram = tm_g.ms();
+    ms->project = tm_p.ms();
+}
+
+// (2) Phi-free: every N-sized pass regenerates its affinity rows (fused.hip)
+void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const SampleSet& ss, const Nystrom& ny,
+                        double hx, double hy, int T, int n_eig, long long pix0, long long M, StageMs* ms) {
+    const int p = ss.p, r = ny.r;
+    const int P64 = nlek::sink_pass_ld(p);
+    const float nsw = nsw_of(hx), npw = nsw_of(hy);
+    Timer tm_s(c->stream), tm_g(c->stream), tm_p(c->stream);
+    tm_s.start();
+    // the pass kernel reads the sample table up to the next multiple of 16: pad with zeros (their
+    // w entries are zero, so they only have to be finite)
+    DevBuf<float4> d_samples(P64);
+    HIP_OK(hipMemsetAsync(d_samples.p, 0, P64 * sizeof(float4), c->stream));
+    HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), p * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    std::vector<double> Bh((size_t)p * r);
+    for (int k = 0; k < r; ++k) {
+        const double inv = recip0(ny.lam[k]);  // :265-268
+        for (int a = 0; a < p; ++a) Bh[(size_t)k * p + a] = ny.VA[(size_t)k * p + a] * inv;
+    }
+    constexpr int kZS = 8;  // slices of the block partials, summed by k_sink_update
+    DevBuf<double> d_B(Bh.size()), d_VA(Bh.size()), d_lam(r), d_z((size_t)kZS * P64), d_w(P64), d_uh((size_t)2 * T * r),
+        d_partial((size_t)nlek::sink_pass_rows(std::max<long long>(M, 1)) * P64);
+    DevBuf<double> d_cbuf((size_t)std::max<long long>(M, 1));
+    HIP_OK(hipMemcpyAsync(d_B.p, Bh.data(), Bh.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(d_VA.p, ny.VA.data(), Bh.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemsetAsync(d_w.p, 0, P64 * sizeof(double), c->stream));
+    const int nrows = nlek::sink_pass_rows(std::max<long long>(M, 1));
+    // pass n uses u = uh[n-1] (w = B u) and produces uh[n]; pass 0 is the column sum Phi^T 1 (:234,239)
+    auto one_pass = [&](int n, int mode, double* ybuf) {
+        if (M > 0) {
+            PROFILED(c, NLE_K_SINKHORN_PASS, nlek::sink_pass(c->stream, mode, d_lum, ss.gs, d_samples.p, p, d_w.p, nsw,
+                                                             npw, pix0, M, NLE_EPS, ybuf, d_partial.p));
+            PROFILED(c, NLE_K_REDUCE, nlek::reduce_partials(c->stream, d_partial.p, nrows, P64, d_z.p, kZS));
+        } else {
+            HIP_OK(hipMemsetAsync(d_z.p, 0, (size_t)kZS * P64 * sizeof(double), c->stream));
+        }
+        all_reduce(c, d_z.p, (size_t)kZS * P64);
+        PROFILED(c, NLE_K_SMALL,
+                 nlek::sink_update(c->stream, mode, p, r, d_B.p, d_VA.p, d_lam.p, d_z.p, kZS, P64,
+                                   n > 0 ? d_uh.p + (size_t)(n - 1) * r : nullptr, NLE_EPS, d_uh.p + (size_t)n * r,
+                                   d_w.p, P64));
+    };
+    one_pass(0, nlek::ROWPASS_COLSUM, nullptr);
+    for (int n = 1; n < 2 * T; ++n) one_pass(n, nlek::ROWPASS_RECIP, n == 2 * T - 1 ? d_cbuf.p : nullptr);
+    // u_c = scaling that defines the final c (input of the last pass), u_r = output of the last pass
+    std::vector<double> u_c(r), u_r(r);
+    HIP_OK(hipMemcpyAsync(u_c.data(), d_uh.p + (size_t)(2 * T - 2) * r, r * sizeof(double), hipMemcpyDeviceToHost,
+                          c->stream));
+    HIP_OK(hipMemcpyAsync(u_r.data(), d_uh.p + (size_t)(2 * T - 1) * r, r * sizeof(double), hipMemcpyDeviceToHost,
+                          c->stream));
+    tm_s.stop();
+
+    // Gram in sample space (fp64 MFMA)
+    tm_g.start();
+    const int ntiles = nlek::gram64_num_tiles(p);
+    DevBuf<double> d_gpart(std::max<size_t>(nlek::gram64_partial_elems(std::max<long long>(M, 1), p), 1));
+    DevBuf<double> d_tiles((size_t)ntiles * 256);
+    if (M > 0) {
+        PROFILED(c, NLE_K_GRAM, nlek::gram64(c->stream, d_lum, ss.gs, d_samples.p, p, nsw, npw, pix0, M, d_cbuf.p,
+                                             d_gpart.p, d_tiles.p));
+    } else {
+        HIP_OK(hipMemsetAsync(d_tiles.p, 0, (size_t)ntiles * 256 * sizeof(double), c->stream));
+    }
+    all_reduce(c, d_tiles.p, (size_t)ntiles * 256);
+    std::vector<double> tiles((size_t)ntiles * 256);
+    HIP_OK(hipMemcpyAsync(tiles.data(), d_tiles.p, tiles.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    tm_g.stop();
+
+    double h0 = now_ms();
+    OrthoSS o = orthogonalize_sample_space(ny, p, u_c, u_r, unpack_tiles(tiles, nlek::gram64_ld(p), p, 16), n_eig);
+    ms->host += now_ms() - h0;
+    f->K = o.K;
+    f->ldv = ld4(o.K);
+    f->eigvals = o.Sq;
+
+    // V = diag(c) K_AB^T D: the Nystrom extension of the K' retained eigenvectors, affinity fused
+    tm_p.start();
+    if (o.K > 128) throw Fail{NLE_ERR_INVALID, "Phi-free path supports at most 128 eigenvectors"};
+    const int ldd = nlek::project64_ld(o.K);
+    std::vector<double> Dp((size_t)p * ldd, 0.0);
+    for (int k = 0; k < o.K; ++k)
+        for (int a = 0; a < p; ++a) Dp[(size_t)a * ldd + k] = o.D[(size_t)k * p + a];
+    DevBuf<double> d_D(Dp.size());
+    HIP_OK(hipMemcpyAsync(d_D.p, Dp.data(), Dp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    DevBuf<float> d_V((size_t)std::max<long long>(M, 1) * f->ldv);
+    PROFILED(c, NLE_K_PROJECT, nlek::project64(c->stream, d_lum, ss.gs, d_samples.p, p, nsw, npw, pix0, M, d_D.p, o.K,
+                                               d_cbuf.p, d_V.p, f->ldv));
+    scatter_sample_rows(c, ss, p, o.Vrows, p, o.K, f->ldv, pix0, M, d_V.p);
+    tm_p.stop();
+    HIP_OK(hipStreamSynchronize(c->stream));
+    f->d_V = d_V.take();
+    ms->sinkhorn = tm_s.ms();
+    ms->gram = tm_g.ms();
+    ms->project = tm_p.ms();
+}
+
 nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, int nCol, double hx,
                        double hy, int T, int n_eig) {
     check_image_size(H, W);
@@ -558,6 +853,12 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
     if (n_eig < 1) throw Fail{NLE_ERR_INVALID, "nEigenVectors must be >= 1"};
     if (!(hx > 0) || !(hy > 0)) throw Fail{NLE_ERR_INVALID, "hx and hy must be > 0"};
     if (gs.p() > 2048) throw Fail{NLE_ERR_INVALID, "more than 2048 samples is not supported"};
+    const bool can_fuse = gs.p() <= nlek::sink_pass_max_p() && n_eig <= 128;
+    if (c->mode == 2 && !can_fuse)
+        throw Fail{NLE_ERR_INVALID, "Phi-free path supports at most 256 samples and 128 eigenvectors"};
+    // auto: Phi-free needs enough non-sample pixels per sample for its column sums to average
+    // their fp32 rounding (DESIGN.md "Numerics"); tiny images cost nothing either way
+    const bool fuse = (c->mode == 2) || (c->mode == 0 && can_fuse && (long long)H * W >= 64ll * gs.p());
     HIP_OK(hipSetDevice(c->device));
 
     auto f = new nle_filter();
@@ -570,78 +871,28 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         const long long M = (long long)(f->row1 - f->row0) * W;
         f->n_local = M;
         const double t_begin = now_ms();
-        Timer tm_a(c->stream), tm_s(c->stream), tm_g(c->stream), tm_p(c->stream);
-        double host_ms = 0.0;
-
-        // --- affinity blocks + Nystrom (:486-491)
+        StageMs sm;
+        // --- sample set, Ka and its eigenpairs (:486-491, host fp64)
+        Timer tm_a(c->stream);
         tm_a.start();
         SampleSet ss = fetch_samples(c, d_lum, gs);
         f->p = ss.p;
         double h0 = now_ms();
         std::vector<double> Ka = build_Ka(ss, hx, hy);
         Nystrom ny = solve_Ka(Ka, ss.p);
-        host_ms += now_ms() - h0;
+        sm.host += now_ms() - h0;
         f->r = ny.r;
-        DevBuf<float> d_phi((size_t)std::max<long long>(M, 1) * ny.ldr);
-        build_phi(c, d_lum, ss, ny, hx, hy, pix0, M, d_phi.p);
         tm_a.stop();
-
-        // --- Sinkhorn (:495)
-        tm_s.start();
-        std::vector<double> u_c, u_r;
-        DevBuf<double> d_u_c(ny.ldr);
-        sinkhorn_passes(c, d_phi.p, M, ny.ldr, ny.r, ny.lam, T, &u_c, &u_r, d_u_c.p);
-        tm_s.stop();
-
-        // --- Gram (the N-sized part of :296)
-        tm_g.start();
-        std::vector<double> G = gram_all(c, d_phi.p, M, ny.ldr, ny.r, d_u_c.p);
-        tm_g.stop();
-
-        // --- orthogonalize on the host (:499)
-        h0 = now_ms();
-        Ortho o = orthogonalize_host(ny, ss.p, u_c, u_r, std::move(G), n_eig);
-        host_ms += now_ms() - h0;
-        f->K = o.K;
-        f->ldv = ld4(o.K);
-        f->eigvals = o.Sq;
-
-        // --- V = diag(c) Phi Cproj, A rows = Wa T2, already in pixel order (:327, :502)
-        tm_p.start();
-        std::vector<float> Cp((size_t)ny.r * f->ldv, 0.f);
-        for (int k = 0; k < o.K; ++k)
-            for (int j = 0; j < ny.r; ++j) Cp[(size_t)j * f->ldv + k] = (float)o.Cproj[(size_t)k * ny.r + j];
-        DevBuf<float> d_Cp(Cp.size());
-        HIP_OK(hipMemcpyAsync(d_Cp.p, Cp.data(), Cp.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        DevBuf<float> d_V((size_t)std::max<long long>(M, 1) * f->ldv);
-        PROFILED(c, NLE_K_PROJECT, nlek::ts_gemm(c->stream, false, d_phi.p, ny.ldr, nullptr, gs, nullptr, 0.f, 0.f, 0,
-                                                 d_Cp.p, f->ldv, ny.r, d_V.p, f->ldv, M, d_u_c.p, NLE_EPS));
-        std::vector<float> rows;
-        std::vector<long long> idx;
-        for (int a = 0; a < o.q; ++a) {
-            const long long loc = ss.pix[a] - pix0;
-            if (loc < 0 || loc >= M) continue;
-            idx.push_back(loc);
-            const size_t off = rows.size();
-            rows.resize(off + f->ldv, 0.f);
-            for (int k = 0; k < o.K; ++k) rows[off + k] = (float)o.VArows[(size_t)k * o.q + a];
-        }
-        DevBuf<float> d_rows(rows.size());
-        DevBuf<long long> d_idx(idx.size());
-        if (!idx.empty()) {
-            HIP_OK(hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-            HIP_OK(hipMemcpyAsync(d_idx.p, idx.data(), idx.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-            PROFILED(c, NLE_K_SMALL, nlek::scatter_rows(c->stream, d_rows.p, d_idx.p, (int)idx.size(), f->ldv, d_V.p, M));
-        }
-        tm_p.stop();
-        HIP_OK(hipStreamSynchronize(c->stream));
+        if (fuse)
+            train_sample_space(c, f, d_lum, ss, ny, hx, hy, T, n_eig, pix0, M, &sm);
+        else
+            train_materialised(c, f, d_lum, ss, ny, hx, hy, T, n_eig, pix0, M, &sm);
         prof_flush(c);
-        f->d_V = d_V.take();
         f->ms[0] = tm_a.ms();
-        f->ms[1] = tm_s.ms();
-        f->ms[2] = tm_g.ms();
-        f->ms[3] = tm_p.ms();
-        f->ms[4] = host_ms;
+        f->ms[1] = sm.sinkhorn;
+        f->ms[2] = sm.gram;
+        f->ms[3] = sm.project;
+        f->ms[4] = sm.host;
         f->ms[5] = now_ms() - t_begin;
     } catch (...) {
         delete f;
@@ -711,7 +962,8 @@ int nle_ld(int n) { return ld4(n); }
 
 size_t nle_comm_len(int n_samples) {
     const int ld = ld4(n_samples);
-    return (size_t)nlek::gram_num_tiles(ld) * 1024 + (size_t)ld;
+    return std::max((size_t)nlek::gram_num_tiles(ld) * 1024, (size_t)nlek::gram64_num_tiles(n_samples) * 256) +
+           8 * (size_t)nlek::sink_pass_ld(n_samples);
 }
 
 int nle_ctx_create(int device, void* stream, nle_ctx** out) {
@@ -755,6 +1007,12 @@ const char* nle_last_error(const nle_ctx* ctx) { return ctx ? ctx->err.c_str() :
 int nle_ctx_synchronize(nle_ctx* ctx) {
     if (!ctx) return NLE_ERR_INVALID;
     return guard(ctx, [&] { HIP_OK(hipStreamSynchronize(ctx->stream)); });
+}
+
+int nle_ctx_set_mode(nle_ctx* ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 2) return NLE_ERR_INVALID;
+    ctx->mode = mode;
+    return NLE_OK;
 }
 
 int nle_ctx_set_shard(nle_ctx* ctx, int rank, int world, nle_allreduce_fn allreduce, void* user,
@@ -834,8 +1092,8 @@ int nle_compute_kernel(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row
             DevBuf<float4> d_samples(ss.p);
             HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), ss.p * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
             PROFILED(ctx, NLE_K_AFFINITY,
-                     nlek::affinity(ctx->stream, d_lum, gs, d_samples.p, ss.p, ld4(ss.p), (float)(1.0 / (hx * hx)),
-                                    (float)(1.0 / (hy * hy)), (long long)row0 * W, (long long)(row1 - row0) * W, d_kab));
+                     nlek::affinity(ctx->stream, d_lum, gs, d_samples.p, ss.p, ld4(ss.p), nsw_of(hx), nsw_of(hy),
+                                    (long long)row0 * W, (long long)(row1 - row0) * W, d_kab));
             HIP_OK(hipStreamSynchronize(ctx->stream));
             prof_flush(ctx);
         }
@@ -1068,7 +1326,7 @@ int nle_bench_affinity(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row
         slab(H, ctx->rank, ctx->world, &row0, &row1);
         DevBuf<float4> d_samples(ss.p);
         HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), ss.p * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-        const float sw = (float)(1.0 / (hx * hx)), pw = (float)(1.0 / (hy * hy));
+        const float sw = nsw_of(hx), pw = nsw_of(hy);
         const long long pix0 = (long long)row0 * W, M = (long long)(row1 - row0) * W;
         HIP_OK(nlek::affinity(ctx->stream, d_lum, gs, d_samples.p, ss.p, ld4(ss.p), sw, pw, pix0, M, d_kab));
         Timer tm(ctx->stream);

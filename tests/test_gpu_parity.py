@@ -145,8 +145,16 @@ def _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L):
     return f, Y
 
 
+@pytest.fixture(params=[1, 2], ids=["materialised", "phi_free"])
+def mode(request, ctx):
+    """run the test under both formulations of the N-sized passes (NLE_MODE_* in include/nle.h)"""
+    ctx.set_mode(request.param)
+    yield request.param
+    ctx.set_mode(0)
+
+
 @pytest.mark.parametrize("case", SMALL_CASES)
-def test_train_apply_layers_match_oracle(nle, oracle, ctx, case):
+def test_train_apply_layers_match_oracle(nle, oracle, ctx, mode, case):
     H, W, nr, nc, hx, hy, T, K, L = case
     x = oracle.synthetic_luminance(H, W)
     V_o, S_o = oracle.train_filter(x, nr, nc, hx, hy, T, K)
@@ -154,9 +162,14 @@ def test_train_apply_layers_match_oracle(nle, oracle, ctx, case):
     f, Y = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
     info = f.info()
     assert info["K"] == S_o.size and info["n_local"] == H * W
-    assert rel_l2(f.eigvals, S_o) < 1e-5
+    # 15x20 with 96 samples (a third of the pixels are samples, lambda_min(Ka) = 2e-5) is outside
+    # what the Phi-free formulation is selected for in auto mode (< 64 pixels per sample); forced, it
+    # still lands within 5e-4
+    forced_tiny = mode == 2 and H * W < 64 * nle.sample_grid(H, W, nr, nc)["n_sel_rows"] * nle.sample_grid(H, W, nr, nc)["n_sel_cols"]
+    tol = 5e-4 if forced_tiny else PER_LAYER_TOL
+    assert rel_l2(f.eigvals, S_o) < (5e-5 if forced_tiny else 1e-5)
     for j in range(L):
-        assert rel_l2(Y[j], Y_o[j]) < PER_LAYER_TOL, f"layer {j}"
+        assert rel_l2(Y[j], Y_o[j]) < tol, f"layer {j}"
     # V itself, up to per-column sign
     V = f.eigvecs().cpu().numpy()[:, :S_o.size].astype(np.float64)
     assert rel_l2(_align_signs(V, V_o), V_o) < 1e-3
@@ -164,10 +177,10 @@ def test_train_apply_layers_match_oracle(nle, oracle, ctx, case):
     w = [2.0, 3.0, 4.0, 1.0, 0.5][:L]
     y = f.apply(x.astype(np.float32), nle.transform_eigenvalues(f.eigvals, w)).cpu().numpy()
     y_o = oracle.apply_filter(V_o, x, oracle.transform_eigenvalues(S_o, w)).ravel()
-    assert rel_l2(y, y_o) < PER_LAYER_TOL
+    assert rel_l2(y, y_o) < tol
 
 
-def test_rank_truncated_Ka(nle, oracle, ctx):
+def test_rank_truncated_Ka(nle, oracle, ctx, mode):
     """Ka numerically rank deficient with a clear gap at the 1e-10 cut (4 grey levels, spatial
     bandwidth so wide that pixels of one level are near duplicates): r = 4 < p = 30, and the
     A block of sinkhorn/orthogonalize is the first r samples (src/filter.cpp:247)."""
@@ -202,7 +215,7 @@ def test_errors_mirror_reference(nle, oracle, ctx):
         nle.NLEFilter(ctx).train_filter(x, 4, 5, 10, 30, 0, 5)
 
 
-def test_apply_properties_small(nle, oracle, ctx):
+def test_apply_properties_small(nle, oracle, ctx, mode):
     """apply is linear; with fS = 1 it is the orthogonal projector onto span(V) (idempotent)."""
     H, W = 64, 80
     x = oracle.synthetic_luminance(H, W).astype(np.float32)
@@ -219,3 +232,22 @@ def test_apply_properties_small(nle, oracle, ctx):
     lhs = f.apply(2.0 * x - 3.0 * z, fs).cpu().numpy()
     rhs = 2.0 * f.apply(x, fs).cpu().numpy() - 3.0 * f.apply(z, fs).cpu().numpy()
     assert rel_l2(lhs, rhs) < 1e-5
+
+
+def test_cfg2_both_modes_match_oracle(nle, oracle, ctx):
+    """BASELINE.json configs[1]: 512x512, 10x20 samples, K=10, 4 layers, fp32 -- full size against the
+    streaming oracle (validated against the literal one in tests/test_golden.py)."""
+    H = W = 512
+    x = oracle.synthetic_luminance(H, W)
+    V_o, S_o = oracle.train_filter_streaming(x, 10, 20, W / 4.0, 30.0, 10, 10)
+    Y_o = oracle.apply_layers_streaming(V_o, S_o, x, 4)
+    for m in (1, 2):
+        ctx.set_mode(m)
+        try:
+            f, Y = _run_device(nle, ctx, x, 10, 20, W / 4.0, 30.0, 10, 10, 4)
+        finally:
+            ctx.set_mode(0)
+        assert f.info()["r"] == 200
+        assert rel_l2(f.eigvals, S_o) < 1e-5
+        for j in range(4):
+            assert rel_l2(Y[j], Y_o[j]) < PER_LAYER_TOL, (m, j)
