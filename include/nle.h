@@ -51,6 +51,14 @@ void nle_ctx_destroy(nle_ctx* ctx);
 const char* nle_last_error(const nle_ctx* ctx); /* ctx may be NULL: last create error */
 int nle_ctx_synchronize(nle_ctx* ctx);
 
+/* Device memory helpers for hosts that do not link the HIP runtime themselves (the C++ surface in
+ * include/nle/filter.hpp, a cgo/JNI/ctypes binding): plain hipMalloc / hipFree / hipMemcpy on
+ * the ctx's device, synchronous with respect to the ctx's stream. */
+int nle_dev_alloc(nle_ctx* ctx, size_t bytes, void** d_ptr);
+void nle_dev_free(nle_ctx* ctx, void* d_ptr);
+int nle_dev_upload(nle_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
 /* Which formulation nle_train uses for the N-sized passes (results agree to rounding):
  *   NLE_MODE_AUTO          Phi-free when it applies (<= 256 samples, <= 128 eigenvectors, at least
  *                          64 pixels per sample), else materialised
@@ -119,7 +127,8 @@ int nle_sinkhorn_scalings(nle_ctx* ctx, const float* d_phi, long long M, int ld,
                           const double* h_eigvals, int max_iter, double* h_u_c,
                           double* h_u_r);
 /* Gram matrix of the scaled rows, the N-sized half of `Wab*Wab^T` (src/filter.cpp:296):
- * h_G (r x r col-major) = sum_i c_i^2 phi_i phi_i^T, c_i = recip(phi_i . h_u) (all rows). */
+ * h_G (r x r col-major) = sum_i c_i^2 phi_i phi_i^T, c_i = recip(phi_i . h_u) (all rows);
+ * h_u == NULL: c_i = 1 (plain X^T X, used for `Wab*Wab^T` on a caller-supplied Wab). */
 int nle_gram(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r, const double* h_u,
              double* h_G);
 /* per-row scalings c_i = recip(phi_i . h_u) (inplaceReciprocal, src/filter.cpp:42-54) */

@@ -33,6 +33,10 @@ _SIGNATURES = {
     "nle_ctx_destroy": (None, [_P]),
     "nle_last_error": (C.c_char_p, [_P]),
     "nle_ctx_synchronize": (C.c_int, [_P]),
+    "nle_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "nle_dev_free": (None, [_P, _P]),
+    "nle_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "nle_dev_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "nle_ctx_set_mode": (C.c_int, [_P, C.c_int]),
     "nle_ctx_set_shard": (C.c_int, [_P, C.c_int, C.c_int, ALLREDUCE_FN, _P, _P, C.c_size_t]),
     "nle_comm_len": (C.c_size_t, [C.c_int]),

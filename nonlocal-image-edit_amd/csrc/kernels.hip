@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void k_gram(const float* __restrict__ X, long 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
-    for (int j = tid; j < ld; j += 256) su[j] = uvec[j];
+    for (int j = tid; j < ld; j += 256) su[j] = uvec ? uvec[j] : 0.0;
 
     const long long c0 = (long long)blockIdx.x * chunk_rows;
     const long long c1 = min(M, c0 + (long long)chunk_rows);
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void k_gram(const float* __restrict__ X, long 
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
-        const float cf = valid ? (float)recip_or_zero(s, eps) : 0.f;
+        const float cf = valid ? (uvec ? (float)recip_or_zero(s, eps) : 1.f) : 0.f;
         for (int q = lg; q < nq; q += 8) {
             float4* pz = reinterpret_cast<float4*>(zrow + 4 * q);
             float4 v = *pz;

@@ -1009,6 +1009,40 @@ int nle_ctx_synchronize(nle_ctx* ctx) {
     return guard(ctx, [&] { HIP_OK(hipStreamSynchronize(ctx->stream)); });
 }
 
+int nle_dev_alloc(nle_ctx* ctx, size_t bytes, void** d_ptr) {
+    if (!ctx || !d_ptr) return NLE_ERR_INVALID;
+    *d_ptr = nullptr;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        HIP_OK(hipMalloc(d_ptr, bytes ? bytes : 1));
+    });
+}
+
+void nle_dev_free(nle_ctx* ctx, void* d_ptr) {
+    if (!ctx || !d_ptr) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_ptr);
+}
+
+int nle_dev_upload(nle_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !h_src))) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        HIP_OK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!ctx || (bytes && (!h_dst || !d_src))) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        HIP_OK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
 int nle_ctx_set_mode(nle_ctx* ctx, int mode) {
     if (!ctx || mode < 0 || mode > 2) return NLE_ERR_INVALID;
     ctx->mode = mode;
@@ -1151,13 +1185,16 @@ int nle_sinkhorn_scalings(nle_ctx* ctx, const float* d_phi, long long M, int ld,
 }
 
 int nle_gram(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r, const double* h_u, double* h_G) {
-    if (!ctx || !d_phi || !h_u || !h_G || M < 0 || r < 1 || ld < r || (ld & 3)) return NLE_ERR_INVALID;
+    if (!ctx || !d_phi || !h_G || M < 0 || r < 1 || ld < r || (ld & 3)) return NLE_ERR_INVALID;
     return guard(ctx, [&] {
         HIP_OK(hipSetDevice(ctx->device));
-        std::vector<double> u(ld, 0.0);
-        std::copy(h_u, h_u + r, u.begin());
-        DevBuf<double> d_u(ld);
-        HIP_OK(hipMemcpyAsync(d_u.p, u.data(), ld * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        DevBuf<double> d_u;
+        if (h_u) {
+            std::vector<double> u(ld, 0.0);
+            std::copy(h_u, h_u + r, u.begin());
+            d_u.alloc(ld);
+            HIP_OK(hipMemcpy(d_u.p, u.data(), ld * sizeof(double), hipMemcpyHostToDevice));
+        }
         std::vector<double> G = gram_all(ctx, d_phi, M, ld, r, d_u.p);
         std::copy(G.begin(), G.end(), h_G);
     });

@@ -1,0 +1,488 @@
+// Host side of the C++ drop-in surface (include/nle/filter.hpp) over the C ABI (include/nle.h).
+// Mirrors the reference's src/filter.cpp function by function; every N-sized product runs in
+// libnle_hip.so on the GPU (fp32 storage, fp64 reductions), the p x p algebra stays here in fp64.
+#include "nle/filter.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+
+#include "nle.h"
+
+namespace nle {
+
+namespace {
+
+// one context per process, created on first use (the reference keeps no global state; this one
+// only holds the HIP stream)
+nle_ctx* shared_ctx() {
+    static nle_ctx* ctx = nullptr;
+    if (!ctx) {
+        int dev = 0;
+        if (const char* e = std::getenv("NLE_DEVICE")) dev = std::atoi(e);
+        if (nle_ctx_create(dev, nullptr, &ctx) != NLE_OK)
+            throw std::runtime_error(std::string("nle: cannot create GPU context: ") + nle_last_error(nullptr));
+        if (const char* m = std::getenv("NLE_MODE")) nle_ctx_set_mode(ctx, std::atoi(m));
+    }
+    return ctx;
+}
+
+void check(int status, nle_ctx* ctx) {
+    if (status != NLE_OK) throw std::runtime_error(nle_last_error(ctx));
+}
+
+// RAII device buffer through the ABI helpers
+struct Dev {
+    nle_ctx* c;
+    void* p = nullptr;
+    Dev(nle_ctx* ctx, size_t bytes) : c(ctx) { check(nle_dev_alloc(c, bytes, &p), c); }
+    ~Dev() { nle_dev_free(c, p); }
+    Dev(const Dev&) = delete;
+    Dev& operator=(const Dev&) = delete;
+    float* f() { return static_cast<float*>(p); }
+    double* d() { return static_cast<double*>(p); }
+};
+
+inline double recip0(double v, double eps = EPS) { return std::fabs(v) >= eps ? 1.0 / v : 0.0; }  // :42-54
+
+std::vector<float> plane_f32(const Image& m) {
+    if (m.channels() != 1 || m.depth() != NLE_64F) throw std::runtime_error("expected a 1-channel CV_64F matrix");
+    std::vector<float> v(m.total());
+    const double* s = m.ptr<double>();
+    for (size_t i = 0; i < v.size(); ++i) v[i] = (float)s[i];
+    return v;
+}
+
+// rows of a column-major p x n fp64 matrix's TRANSPOSE as fp32 row-per-pixel (n x ld), i.e. the
+// reference's `Kab` / `Wab` seen as one row per pixel
+std::vector<float> cols_as_rows_f32(const Mat& m, int ld) {
+    std::vector<float> v((size_t)m.cols() * ld, 0.f);
+    for (int j = 0; j < m.cols(); ++j)
+        for (int i = 0; i < m.rows(); ++i) v[(size_t)j * ld + i] = (float)m(i, j);
+    return v;
+}
+
+}  // namespace
+
+Mat operator*(const Mat& a, const Mat& b) {
+    if (a.cols() != b.rows()) throw std::runtime_error("matrix product: shape mismatch");
+    Mat c(a.rows(), b.cols());
+    for (int j = 0; j < b.cols(); ++j)
+        for (int k = 0; k < a.cols(); ++k) {
+            const double bv = b(k, j);
+            for (int i = 0; i < a.rows(); ++i) c(i, j) += a(i, k) * bv;
+        }
+    return c;
+}
+
+Image eigen2opencv(const Vec& v, int nrows, int ncols) {  // include/utils.hpp:21-26 (clone)
+    Image m(nrows, ncols, NLE_64F, 1);
+    std::copy(v.data(), v.data() + (size_t)nrows * ncols, m.ptr<double>());
+    return m;
+}
+
+Vec opencv2eigen(const Image& mat) {  // include/utils.hpp:28-41, row-major flatten
+    Vec lv((int)mat.total());
+    int k = 0;
+    for (int i = 0; i < mat.rows; i++)
+        for (int j = 0; j < mat.cols; j++) lv(k++) = mat.at<double>(i, j);
+    return lv;
+}
+
+// ------------------------------------------------------------------ computeKernel, :114-167
+std::tuple<Permutation, Mat, Mat> computeKernel(const Image& mat, int nRowSamples, int nColSamples, DType hx,
+                                                DType hy) {
+    if (nRowSamples > mat.rows || nColSamples > mat.cols)
+        throw std::runtime_error("Number of samples per row and col must be <= that of image.");
+    nle_ctx* c = shared_ctx();
+    const int H = mat.rows, W = mat.cols;
+    const long long N = (long long)H * W;
+    int rs, ro, nr, cs, co, nc;
+    if (nle_sample_grid(H, W, nRowSamples, nColSamples, &rs, &ro, &nr, &cs, &co, &nc) != NLE_OK)
+        throw std::runtime_error("Number of samples per row and col must be <= that of image.");
+    const int p = nr * nc, ld = nle_ld(p);
+    std::vector<float> lum = plane_f32(mat);
+    Dev d_lum(c, (size_t)N * 4), d_kab(c, (size_t)N * ld * 4);
+    check(nle_dev_upload(c, d_lum.p, lum.data(), (size_t)N * 4), c);
+    Mat Ka(p, p);
+    check(nle_compute_kernel(c, d_lum.f(), H, W, nRowSamples, nColSamples, hx, hy, Ka.data(), d_kab.f()), c);
+    std::vector<float> kab((size_t)N * ld);
+    check(nle_dev_download(c, kab.data(), d_kab.p, kab.size() * 4), c);
+    // [selected; rest] order, both in row-major scan order (:56-80, :156-164)
+    Permutation P;
+    P.idx.resize((size_t)N);
+    std::vector<char> sel((size_t)N, 0);
+    int k = 0;
+    for (int i = 0; i < nr; ++i)
+        for (int j = 0; j < nc; ++j) {
+            const int pix = to1DIndex(ro + i * rs, co + j * cs, W);
+            P.idx[(size_t)k++] = pix;
+            sel[(size_t)pix] = 1;
+        }
+    Mat Kab(p, (int)(N - p));
+    int jrest = 0;
+    for (long long pix = 0; pix < N; ++pix) {
+        if (sel[(size_t)pix]) continue;
+        P.idx[(size_t)(p + jrest)] = (int)pix;
+        const float* row = kab.data() + (size_t)pix * ld;
+        for (int i = 0; i < p; ++i) Kab(i, jrest) = row[i];
+        ++jrest;
+    }
+    return std::make_tuple(P, Ka, Kab);
+}
+
+// ------------------------------------------------------------------ eigenDecomposition, :204-228
+std::pair<Mat, Vec> eigenDecomposition(const Mat& M, DType eps) {
+    const int n = M.rows();
+    if (n == 0 || M.cols() != n) throw std::runtime_error("eigenDecomposition: square matrix expected");
+    Mat U(n, n);
+    Vec D(n);
+    int r = 0;
+    if (nle_eigen_decomposition(M.data(), n, eps, U.data(), D.data(), &r) != NLE_OK)
+        throw std::runtime_error("eigenDecomposition: no convergence");
+    return std::make_pair(U.leftCols(r), D.head(r));
+}
+
+// ------------------------------------------------------------------ nystromApproximation, :257-280
+std::pair<Vec, Mat> nystromApproximation(const Mat& Ka, const Mat& Kab) {
+    nle_ctx* c = shared_ctx();
+    Mat eigvecs;
+    Vec eigvals;
+    std::tie(eigvecs, eigvals) = eigenDecomposition(Ka);
+    int nnz = 0;
+    for (int i = 0; i < eigvals.size(); ++i)
+        if (std::fabs(eigvals(i)) >= EPS) ++nnz;  // :265-266
+    eigvecs = eigvecs.leftCols(nnz);
+    eigvals = eigvals.head(nnz);
+    const int p = Ka.rows(), r = nnz, n_rest = Kab.cols(), n = p + n_rest;
+    Mat B(p, r);  // eigvecs * invEigVals
+    for (int k = 0; k < r; ++k)
+        for (int s = 0; s < p; ++s) B(s, k) = eigvecs(s, k) * recip0(eigvals(k));
+    Mat phi(n, r);
+    for (int k = 0; k < r; ++k)
+        for (int s = 0; s < p; ++s) phi(s, k) = eigvecs(s, k);
+    if (n_rest > 0 && r > 0) {
+        const int lda = nle_ld(p), ldc = nle_ld(r);
+        std::vector<float> rows = cols_as_rows_f32(Kab, lda);
+        Dev d_A(c, rows.size() * 4), d_C(c, (size_t)n_rest * ldc * 4);
+        check(nle_dev_upload(c, d_A.p, rows.data(), rows.size() * 4), c);
+        check(nle_ts_gemm(c, d_A.f(), n_rest, lda, p, B.data(), r, d_C.f()), c);  // Kab^T * B, :275
+        std::vector<float> out((size_t)n_rest * ldc);
+        check(nle_dev_download(c, out.data(), d_C.p, out.size() * 4), c);
+        for (int j = 0; j < n_rest; ++j)
+            for (int k = 0; k < r; ++k) phi(p + j, k) = out[(size_t)j * ldc + k];
+    }
+    return std::make_pair(eigvals, phi);
+}
+
+// ------------------------------------------------------------------ sinkhorn, :230-254
+std::pair<Mat, Mat> sinkhorn(const Mat& phi, const Vec& eigvals, int maxIter) {
+    nle_ctx* c = shared_ctx();
+    const int n = phi.rows(), r = phi.cols();
+    if (r == 0 || n == 0) throw std::runtime_error("sinkhorn: empty phi");
+    if (maxIter < 1) throw std::runtime_error("sinkhorn: maxIter must be >= 1");
+    const int ld = nle_ld(r);
+    std::vector<float> rows((size_t)n * ld, 0.f);
+    for (int k = 0; k < r; ++k)
+        for (int i = 0; i < n; ++i) rows[(size_t)i * ld + k] = (float)phi(i, k);
+    Dev d_phi(c, rows.size() * 4), d_c(c, (size_t)n * 8);
+    check(nle_dev_upload(c, d_phi.p, rows.data(), rows.size() * 4), c);
+    std::vector<double> u_c(r), u_r(r);
+    check(nle_sinkhorn_scalings(c, d_phi.f(), n, ld, r, eigvals.data(), maxIter, u_c.data(), u_r.data()), c);
+    check(nle_row_scalings(c, d_phi.f(), n, ld, r, u_c.data(), d_c.d()), c);
+    std::vector<double> cv((size_t)n);
+    check(nle_dev_download(c, cv.data(), d_c.p, cv.size() * 8), c);
+    const int q = r;  // :247  p = phi.cols()
+    if (q > n) throw std::runtime_error("sinkhorn: phi has more columns than rows");
+    // left = R * (phi_top * D); the device holds float(phi), use the same values here
+    Mat left(q, r), right(q, r);
+    for (int a = 0; a < q; ++a) {
+        double sr = 0.0;
+        for (int k = 0; k < r; ++k) sr += (double)rows[(size_t)a * ld + k] * u_r[k];
+        const double ra = recip0(sr);
+        for (int k = 0; k < r; ++k) {
+            const double v = rows[(size_t)a * ld + k];
+            left(a, k) = ra * v * eigvals(k);
+            right(a, k) = cv[(size_t)a] * v;
+        }
+    }
+    Mat Wa = left * right.transpose();  // :249
+    Mat Wab(q, n - q);
+    if (n > q) {
+        const int ldq = nle_ld(q);
+        Mat lt = left.transpose();  // r x q
+        Dev d_out(c, (size_t)(n - q) * ldq * 4);
+        check(nle_ts_gemm(c, d_phi.f() + (size_t)q * ld, n - q, ld, r, lt.data(), q, d_out.f()), c);
+        std::vector<float> out((size_t)(n - q) * ldq);
+        check(nle_dev_download(c, out.data(), d_out.p, out.size() * 4), c);
+        for (int j = 0; j < n - q; ++j)
+            for (int a = 0; a < q; ++a) Wab(a, j) = (double)out[(size_t)j * ldq + a] * cv[(size_t)(q + j)];  // :250
+    }
+    return std::make_pair(Wa, Wab);
+}
+
+// ------------------------------------------------------------------ orthogonalize, :282-331
+std::pair<Mat, Vec> orthogonalize(const Mat& Wa, const Mat& Wab, int nEigVectors, DType eps) {
+    nle_ctx* c = shared_ctx();
+    const int q = Wa.rows(), nb = Wab.cols();
+    Mat eigvecs;
+    Vec eigvals;
+    std::tie(eigvecs, eigvals) = eigenDecomposition(Wa, eps);
+    const int r2 = eigvals.size();
+    Mat Us(q, r2);
+    for (int k = 0; k < r2; ++k) {
+        const double s = std::sqrt(recip0(eigvals(k), eps));
+        for (int i = 0; i < q; ++i) Us(i, k) = eigvecs(i, k) * s;
+    }
+    Mat invRootWa = Us * eigvecs.transpose();  // :292
+    Mat G(q, q);
+    const int ldq = nle_ld(q);
+    std::vector<float> rows = cols_as_rows_f32(Wab, ldq);  // Wab^T, one row per pixel
+    Dev d_X(c, std::max<size_t>(rows.size(), 1) * 4);
+    if (nb > 0) {
+        check(nle_dev_upload(c, d_X.p, rows.data(), rows.size() * 4), c);
+        check(nle_gram(c, d_X.f(), nb, ldq, q, nullptr, G.data()), c);  // Wab * Wab^T, :296
+    }
+    Mat Q = invRootWa * G * invRootWa;
+    for (int j = 0; j < q; ++j)
+        for (int i = 0; i < q; ++i) Q(i, j) += Wa(i, j);
+    Mat Vq;
+    Vec Sq;
+    std::tie(Vq, Sq) = eigenDecomposition(Q, eps);  // :313
+    const int k = std::min(nEigVectors, Vq.cols());
+    Vq = Vq.leftCols(k);
+    Sq = Sq.head(k);
+    Mat C = invRootWa * Vq;  // q x k
+    for (int j = 0; j < k; ++j) {
+        const double s = std::sqrt(recip0(Sq(j), eps));  // :319-321
+        for (int i = 0; i < q; ++i) C(i, j) *= s;
+    }
+    Mat V(q + nb, k);
+    Mat top = Wa * C;
+    for (int j = 0; j < k; ++j)
+        for (int i = 0; i < q; ++i) V(i, j) = top(i, j);
+    if (nb > 0 && k > 0) {
+        const int ldk = nle_ld(k);
+        Dev d_out(c, (size_t)nb * ldk * 4);
+        check(nle_ts_gemm(c, d_X.f(), nb, ldq, q, C.data(), k, d_out.f()), c);  // Wab^T * C, :327
+        std::vector<float> out((size_t)nb * ldk);
+        check(nle_dev_download(c, out.data(), d_out.p, out.size() * 4), c);
+        for (int i = 0; i < nb; ++i)
+            for (int j = 0; j < k; ++j) V(q + i, j) = out[(size_t)i * ldk + j];
+    }
+    return std::make_pair(V, Sq);
+}
+
+// ------------------------------------------------------------------ transformEigenValues, :334-347
+Vec transformEigenValues(const Vec& eigvals, const std::vector<DType>& weights) {
+    if (weights.empty()) throw std::runtime_error("transformEigenValues: at least one weight is required");
+    Vec fS(eigvals.size());
+    if (nle_transform_eigenvalues(eigvals.data(), eigvals.size(), weights.data(), (int)weights.size(), fS.data()) !=
+        NLE_OK)
+        throw std::runtime_error("transformEigenValues: bad arguments");
+    return fS;
+}
+
+// ------------------------------------------------------------------ colour wrapper (host)
+namespace {
+// cv::cvtColor COLOR_BGR2Lab for 8-bit images as documented: sRGB decode, XYZ (D65), L*a*b*, then
+// L*255/100, a+128, b+128.  OpenCV's own 8-bit path is fixed-point and version dependent: this
+// float restatement agrees with it to about one grey level ("unpinned").
+const double kXn = 0.950456, kZn = 1.088754;
+const double kM[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
+const double kMi[3][3] = {{3.240479, -1.53715, -0.498535}, {-0.969256, 1.875991, 0.041556}, {0.055648, -0.204043, 1.057311}};
+inline double srgb2lin(double v) { return v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4); }
+inline double lin2srgb(double v) { return v <= 0.0031308 ? 12.92 * v : 1.055 * std::pow(std::max(v, 0.0), 1 / 2.4) - 0.055; }
+inline double labf(double t) { return t > 0.008856 ? std::cbrt(t) : 7.787 * t + 16.0 / 116.0; }
+inline unsigned char sat8(double v) { return (unsigned char)std::min(255.0, std::max(0.0, std::nearbyint(v))); }
+}  // namespace
+
+Image bgr2lab8(const Image& bgr) {
+    if (bgr.channels() != 3 || bgr.depth() != NLE_8U) throw std::runtime_error("bgr2lab8: 8UC3 image expected");
+    double lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = srgb2lin(i / 255.0);
+    Image lab(bgr.rows, bgr.cols, NLE_8U, 3);
+    const unsigned char* s = bgr.ptr<unsigned char>();
+    unsigned char* d = lab.ptr<unsigned char>();
+    for (size_t i = 0; i < bgr.total(); ++i, s += 3, d += 3) {
+        const double b = lut[s[0]], g = lut[s[1]], r = lut[s[2]];
+        const double x = (kM[0][0] * r + kM[0][1] * g + kM[0][2] * b) / kXn;
+        const double y = kM[1][0] * r + kM[1][1] * g + kM[1][2] * b;
+        const double z = (kM[2][0] * r + kM[2][1] * g + kM[2][2] * b) / kZn;
+        const double L = y > 0.008856 ? 116.0 * std::cbrt(y) - 16.0 : 903.3 * y;
+        d[0] = sat8(L * 255.0 / 100.0);
+        d[1] = sat8(500.0 * (labf(x) - labf(y)) + 128.0);
+        d[2] = sat8(200.0 * (labf(y) - labf(z)) + 128.0);
+    }
+    return lab;
+}
+
+Image lab2bgr8(const Image& lab) {
+    if (lab.channels() != 3 || lab.depth() != NLE_8U) throw std::runtime_error("lab2bgr8: 8UC3 image expected");
+    Image bgr(lab.rows, lab.cols, NLE_8U, 3);
+    const unsigned char* s = lab.ptr<unsigned char>();
+    unsigned char* d = bgr.ptr<unsigned char>();
+    auto finv = [](double t) { return t > 0.206893 ? t * t * t : (t - 16.0 / 116.0) / 7.787; };
+    for (size_t i = 0; i < lab.total(); ++i, s += 3, d += 3) {
+        const double L = s[0] * 100.0 / 255.0, a = s[1] - 128.0, b = s[2] - 128.0;
+        double fy = (L + 16.0) / 116.0, y;
+        if (L > 7.9996248) {
+            y = fy * fy * fy;
+        } else {
+            y = L / 903.3;
+            fy = 7.787 * y + 16.0 / 116.0;
+        }
+        const double x = finv(a / 500.0 + fy) * kXn, z = finv(fy - b / 200.0) * kZn;
+        const double r = kMi[0][0] * x + kMi[0][1] * y + kMi[0][2] * z;
+        const double g = kMi[1][0] * x + kMi[1][1] * y + kMi[1][2] * z;
+        const double bl = kMi[2][0] * x + kMi[2][1] * y + kMi[2][2] * z;
+        d[0] = sat8(lin2srgb(std::min(1.0, std::max(0.0, bl))) * 255.0);
+        d[1] = sat8(lin2srgb(std::min(1.0, std::max(0.0, g))) * 255.0);
+        d[2] = sat8(lin2srgb(std::min(1.0, std::max(0.0, r))) * 255.0);
+    }
+    return bgr;
+}
+
+namespace {
+Image luminance_plane(const Image& lab) {  // split + convertTo(CV_64F), :460-469
+    Image L(lab.rows, lab.cols, NLE_64F, 1);
+    const unsigned char* s = lab.ptr<unsigned char>();
+    double* d = L.ptr<double>();
+    for (size_t i = 0; i < lab.total(); ++i) d[i] = s[3 * i];
+    return L;
+}
+}  // namespace
+
+// ------------------------------------------------------------------ NLEFilter
+NLEFilter::NLEFilter() = default;
+NLEFilter::~NLEFilter() {
+    if (f_) nle_filter_destroy(f_);
+}
+NLEFilter::NLEFilter(NLEFilter&& o) noexcept : verbose(o.verbose), ctx_(o.ctx_), f_(o.f_), rows_(o.rows_), cols_(o.cols_) {
+    o.f_ = nullptr;
+}
+
+void NLEFilter::trainFilter(const Image& channel, int nRowSamples, int nColSamples, DType hx, DType hy,
+                            int nSinkhornIter, int nEigenVectors) {  // :480-512
+    if (nRowSamples > channel.rows || nColSamples > channel.cols)
+        throw std::runtime_error("Number of samples per row and col must be <= that of image.");
+    ctx_ = shared_ctx();
+    if (f_) {
+        nle_filter_destroy(f_);
+        f_ = nullptr;
+    }
+    std::vector<float> lum = plane_f32(channel);
+    if (verbose) {
+        // the four stages run as one fused GPU pipeline; the banners keep the reference's stdout (:483-498)
+        std::cout << "Computing kernel" << std::endl;
+        std::cout << "Nystrom approximation" << std::endl;
+        std::cout << "Sinkhorn" << std::endl;
+        std::cout << "Orthogonalize" << std::endl;
+    }
+    check(nle_train_host(ctx_, lum.data(), channel.rows, channel.cols, nRowSamples, nColSamples, hx, hy, nSinkhornIter,
+                         nEigenVectors, &f_), ctx_);
+    rows_ = channel.rows;
+    cols_ = channel.cols;
+    if (verbose) {
+        Vec ev = eigvals();
+        Mat V = eigvecs();
+        for (int i = 0; i < std::min(std::min(nEigenVectors, 5), ev.size()); i++) {  // :504-506 (imshow dropped)
+            double mn = V(0, i), mx = V(0, i);
+            for (int r = 1; r < V.rows(); ++r) {
+                mn = std::min(mn, V(r, i));
+                mx = std::max(mx, V(r, i));
+            }
+            std::cout << "Eigvec " << i << " eigval: " << ev(i) << " minCoeff: " << mn << " maxCoeff: " << mx << std::endl;
+        }
+    }
+}
+
+void NLEFilter::trainForEnhancement(const Image& image, int nRowSamples, int nColSamples, DType hx, DType hy,
+                                    int nSinkhornIter, int nEigenVectors) {  // :514-519
+    Image luminance = luminance_plane(bgr2lab8(image));
+    trainFilter(luminance, nRowSamples, nColSamples, hx, hy, nSinkhornIter, nEigenVectors);
+}
+
+Image NLEFilter::apply(const Image& channel, const Vec& transformedEigVals) const {  // :445-458
+    long long n = 0;
+    if (f_) nle_filter_info(f_, &n, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (!f_ || (long long)channel.total() != n)
+        throw std::runtime_error("Number of values in channel must match that of training image.");
+    int K = 0;
+    nle_filter_info(f_, nullptr, &K, nullptr, nullptr, nullptr, nullptr);
+    if (transformedEigVals.size() != K) throw std::runtime_error("apply: one transformed eigenvalue per eigenvector expected");
+    std::vector<float> x = plane_f32(channel), y(channel.total());
+    check(nle_apply_host(f_, x.data(), channel.rows, channel.cols, transformedEigVals.data(), y.data()), ctx_);
+    Image out(channel.rows, channel.cols, NLE_64F, 1);
+    double* d = out.ptr<double>();
+    for (size_t i = 0; i < y.size(); ++i) d[i] = y[i];
+    return out;
+}
+
+std::vector<Image> NLEFilter::applyLayers(const Image& channel, int nLayers) const {
+    long long n = 0;
+    if (f_) nle_filter_info(f_, &n, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (!f_ || (long long)channel.total() != n)
+        throw std::runtime_error("Number of values in channel must match that of training image.");
+    std::vector<float> x = plane_f32(channel), y((size_t)nLayers * channel.total());
+    check(nle_apply_layers_host(f_, x.data(), channel.rows, channel.cols, nLayers, y.data()), ctx_);
+    std::vector<Image> out;
+    for (int l = 0; l < nLayers; ++l) {
+        Image m(channel.rows, channel.cols, NLE_64F, 1);
+        double* d = m.ptr<double>();
+        for (size_t i = 0; i < channel.total(); ++i) d[i] = y[(size_t)l * channel.total() + i];
+        out.push_back(std::move(m));
+    }
+    return out;
+}
+
+Image NLEFilter::enhance(const Image& image, const std::vector<DType>& weights) const {  // :412-443
+    if (image.channels() != 3) throw std::runtime_error("Can only enhance RGB image.");
+    long long n = 0;
+    if (f_) nle_filter_info(f_, &n, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (!f_ || (long long)image.total() != n)
+        throw std::runtime_error(
+            "Cannot apply filter on image with different size from the image filter was trained on.");
+    Image lab = bgr2lab8(image);
+    Image L = luminance_plane(lab);
+    Vec fS = transformEigenValues(eigvals(), weights);
+    Image Lf = apply(L, fS);
+    unsigned char* d = lab.ptr<unsigned char>();
+    const double* s = Lf.ptr<double>();
+    for (size_t i = 0; i < lab.total(); ++i)  // max(0), min(255), convertTo(CV_8U): round half to even, :434-436
+        d[3 * i] = sat8(std::min(255.0, std::max(0.0, s[i])));
+    return lab2bgr8(lab);  // a, b unchanged, :438-440
+}
+
+Vec NLEFilter::eigvals() const {
+    if (!f_) return Vec();
+    int K = 0;
+    nle_filter_info(f_, nullptr, &K, nullptr, nullptr, nullptr, nullptr);
+    Vec v(K);
+    nle_filter_eigvals(f_, v.data());
+    return v;
+}
+
+Mat NLEFilter::eigvecs() const {
+    if (!f_) return Mat();
+    long long n = 0;
+    int K = 0;
+    nle_filter_info(f_, &n, &K, nullptr, nullptr, nullptr, nullptr);
+    const float* d_V = nullptr;
+    int ld = 0;
+    nle_filter_eigvecs(f_, &d_V, &ld);
+    std::vector<float> h((size_t)n * ld);
+    check(nle_dev_download(ctx_, h.data(), d_V, h.size() * 4), ctx_);
+    Mat V((int)n, K);
+    for (int k = 0; k < K; ++k)
+        for (long long i = 0; i < n; ++i) V((int)i, k) = h[(size_t)i * ld + k];
+    return V;
+}
+
+void NLEFilter::timings(double ms[6]) const {
+    if (f_) nle_filter_timings(f_, ms);
+}
+
+}  // namespace nle

@@ -1,0 +1,85 @@
+"""The C++ drop-in surface (include/nle/filter.hpp, nonlocal-image-edit_amd/host/*.cpp) and the
+`enhance` CLI (reference src/enhance.cpp): argv, stdout, exit codes, and -- on the GPU -- the
+reference's unit tests through the C++ surface plus BASELINE.json configs[0] end to end through the
+CLI against the README output image."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+BIN = os.path.join(ROOT, "nonlocal-image-edit_amd", "bin")
+ENHANCE = os.path.join(BIN, "enhance")
+TEST_FILTER = os.path.join(BIN, "test_filter")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not (os.path.exists(ENHANCE) and os.path.exists(TEST_FILTER)):
+        import __graft_entry__ as entry
+        entry.build()
+    assert os.path.exists(ENHANCE) and os.path.exists(TEST_FILTER)
+
+
+def test_cli_usage_goes_to_stderr_and_exits_zero():
+    """src/enhance.cpp:15-18: fewer than 9 arguments -> usage on stderr, return 0"""
+    r = subprocess.run([ENHANCE, "a.bmp", "b.bmp", "10", "20"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0
+    assert r.stderr.startswith("Usage: ") and "<# sinkhorn iterations>" in r.stderr
+    assert r.stdout == ""
+
+
+def test_cli_unreadable_image_exits_zero(tmp_path):
+    """src/enhance.cpp:34-37: imread failure -> message on stderr, return 0, nothing written"""
+    out = tmp_path / "o.bmp"
+    r = subprocess.run([ENHANCE, str(tmp_path / "missing.bmp"), str(out), "10", "20", "100", "30", "50", "30", "2", "3",
+                        "4", "1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0
+    assert "Failed to read file from" in r.stderr
+    assert not out.exists()
+
+
+def test_cli_garbage_number_throws_like_stoi():
+    """std::stoi on garbage throws std::invalid_argument -> abnormal termination, like the reference"""
+    r = subprocess.run([ENHANCE, "a.bmp", "b.bmp", "ten", "20", "100", "30", "50", "30", "2", "3", "4", "1"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
+
+
+@pytest.mark.gpu
+def test_reference_unit_tests_through_cpp_surface():
+    r = subprocess.run([TEST_FILTER], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "0 failed" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ext", ["png", "bmp"])
+def test_enhance_cli_flower_matches_readme_pair(oracle, tmp_path, ext):
+    """BASELINE.json configs[0]: enhance flower-50.bmp <out> 10 20 100 30 50 30 2 3 4 1 (README.md:74)"""
+    from PIL import Image
+    out = tmp_path / f"flower-out.{ext}"
+    r = subprocess.run([ENHANCE, os.path.join(GOLDEN, "flower-50.bmp"), str(out), "10", "20", "100", "30", "50", "30",
+                        "2", "3", "4", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[:4] == ["Computing kernel", "Nystrom approximation", "Sinkhorn", "Orthogonalize"]  # :483-498
+    assert sum(l.startswith("Eigvec ") and "minCoeff" in l for l in lines) == 5                      # :506
+    assert lines[-1].startswith("Done.")
+    got = np.asarray(Image.open(out).convert("RGB"))[..., ::-1]
+    want = np.asarray(Image.open(os.path.join(GOLDEN, "flower-filtered.png")).convert("RGB"))[..., ::-1]
+    assert got.shape == want.shape == (267, 400, 3)
+    L_got = oracle.bgr_to_lab8(got)[..., 0].astype(np.float64)
+    L_want = oracle.bgr_to_lab8(want)[..., 0].astype(np.float64)
+    err = np.abs(L_got - L_want)
+    print(f"CLI vs README output: mean |dL| = {err.mean():.3f}, p99 = {np.percentile(err, 99):.1f}")
+    assert err.mean() < 1.0 and np.percentile(err, 99) <= 8.0
+    # and against the oracle's own 8-bit L plane for config 1 (same Lab restatement on both sides)
+    gold = np.load(os.path.join(GOLDEN, "flower_cfg1.npz"))
+    src = np.asarray(Image.open(os.path.join(GOLDEN, "flower-50.bmp")).convert("RGB"))[..., ::-1]
+    assert np.array_equal(oracle.bgr_to_lab8(src)[..., 0], gold["L_in"])
+    d = np.abs(L_got - gold["L_out"].astype(np.float64))
+    assert d.mean() < 0.6   # Lab -> BGR -> Lab round trip of the 8-bit image costs a fraction of a level

@@ -1,0 +1,77 @@
+"""Row-slab sharding on the real kernels: 2 and 3 ranks share cuda:0 (one process each, `gloo`
+all-reduce of the CUDA fp64 buffers -- RCCL cannot put two ranks on one device) and must
+reproduce the single-rank result: only the order of the fp64 partial sums differs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, args, mode, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    nle = entry.load_package()
+    synth = entry._load("nle_amd_synthetic", os.path.join(entry.PKG_DIR, "synthetic.py"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, W, nr, nc, hx, hy, T, K, L = args
+        x = synth.synthetic_luminance(H, W).astype(np.float32)
+        ctx = nle.Context(0)
+        ctx.set_mode(mode)
+        g = nle.sample_grid(H, W, nr, nc)
+        ctx.set_shard(rank, world, g["n_sel_rows"] * g["n_sel_cols"], lambda t: dist.all_reduce(t))
+        f = nle.NLEFilter(ctx).train_filter(x, nr, nc, hx, hy, T, K)
+        Y = f.apply_layers(x, L).cpu().numpy()
+        info = f.info()
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), Y=Y, S=f.eigvals, rows=np.array([info["row0"], info["row1"]]))
+        f.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mode", [1, 2], ids=["materialised", "phi_free"])
+def test_sharded_ranks_match_single_rank(nle, oracle, ctx, tmp_path, world, mode):
+    import torch.multiprocessing as mp
+    args = (96, 128, 6, 8, 32.0, 30.0, 10, 10, 4)
+    H, W, nr, nc, hx, hy, T, K, L = args
+    mp.spawn(_worker, args=(world, _free_port(), args, mode, str(tmp_path)), nprocs=world, join=True)
+    x = oracle.synthetic_luminance(H, W)
+    ctx.set_mode(mode)
+    try:
+        f = nle.NLEFilter(ctx).train_filter(x.astype(np.float32), nr, nc, hx, hy, T, K)
+        Y1 = f.apply_layers(x.astype(np.float32), L).cpu().numpy().astype(np.float64)
+        S1 = f.eigvals
+    finally:
+        ctx.set_mode(0)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert parts[0]["rows"][0] == 0 and parts[-1]["rows"][1] == H
+    for a, b in zip(parts[:-1], parts[1:]):
+        assert a["rows"][1] == b["rows"][0]
+    Y = np.concatenate([p["Y"] for p in parts], axis=1).astype(np.float64)
+    for p in parts:
+        assert rel_l2(p["S"], S1) < 1e-9
+    for j in range(L):
+        assert rel_l2(Y[j], Y1[j]) < 1e-6, j     # G = 1 vs G > 1 within 1e-6
+    V_o, S_o = oracle.train_filter(x, nr, nc, hx, hy, T, K)
+    Y_o = oracle.apply_layers(V_o, S_o, x, L).reshape(L, -1)
+    for j in range(L):
+        assert rel_l2(Y[j], Y_o[j]) < 1e-4, j
