@@ -36,29 +36,36 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
-FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
+FP32_PEAK_TF = 157.3        # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
+FP64_MFMA_PEAK_TF = 78.6    # MI355X FP64 matrix peak (spec; SURVEY.md section 8d quotes ~79 TFLOP/s fp64)
 
 
-def roofline_models(cfg, info, L):
-    """kernel name -> (bound, algorithmic units per launch, unit) from SURVEY.md section 8(d)
-    (fp32 storage, s = 4 B), per rank (n = pixels of this rank's slab)."""
+def roofline_models(info, L, phi_free):
+    """kernel name -> (bound, algorithmic units per launch, peak) from SURVEY.md section 8(d) (fp32 storage,
+    s = 4 B), per rank (n = pixels of this rank's slab).
+
+    Phi-free mode: the Sinkhorn pass regenerates the affinities (section 8d: ~8 flop + 1 exp per element) and does
+    the 4 flop per element of the pass itself; it moves ~12 B/pixel and uses no MFMA, so its roof is the
+    fp32 vector pipe ("valu", same 157.3 TFLOP/s figure as the fp32 MFMA).  `hbm_equivalent` is what the
+    canonical streaming form (B_C/(2T) = n*r*4 bytes per pass) would have needed.  Gram and projection run
+    on the fp64 MFMA there."""
     n, r, p, K = info["n_local"], info["r"], info["p"], info["K"]
     s = 4.0
-    return {
-        # B_C / (2T): one read of Phi (n x r) per half-iteration
-        "sinkhorn_pass": ("hbm", n * r * s, "B"),
-        # F_B = 2 N p r
-        "nystrom_extend": ("mfma", 2.0 * n * p * r, "FLOP"),
-        # F_D = 2 N r^2
-        "gram": ("mfma", 2.0 * n * r * r, "FLOP"),
-        # F_E = 2 N r K
-        "project": ("mfma", 2.0 * n * r * K, "FLOP"),
-        # B_F split over its two passes: read V + x ; read V, write L planes
-        "apply_reduce": ("hbm", n * s * (K + 1), "B"),
-        "apply_expand": ("hbm", n * s * (K + L), "B"),
-        # B_A = N s (1 + p)
-        "affinity": ("hbm", n * s * (1 + p), "B"),
+    m = {
+        "affinity": ("hbm", n * s * (1 + p), HBM_PEAK_GBS),              # B_A = N s (1 + p)
+        "apply_reduce": ("hbm", n * s * (K + 1), HBM_PEAK_GBS),          # B_F, first pass: V and x
+        "apply_expand": ("hbm", n * s * (K + L), HBM_PEAK_GBS),          # B_F, second pass: V in, L planes out
     }
+    if phi_free:
+        m["sinkhorn_pass"] = ("valu", n * p * (8.0 + 1.0 + 4.0), FP32_PEAK_TF)
+        m["gram"] = ("mfma", 2.0 * n * p * p, FP64_MFMA_PEAK_TF)         # F_D with r -> p (sample space)
+        m["project"] = ("mfma", 2.0 * n * p * K, FP64_MFMA_PEAK_TF)      # F_E with r -> p
+    else:
+        m["nystrom_extend"] = ("mfma", 2.0 * n * p * r, FP32_PEAK_TF)    # F_B = 2 N p r
+        m["sinkhorn_pass"] = ("hbm", n * r * s, HBM_PEAK_GBS)            # B_C / (2T)
+        m["gram"] = ("mfma", 2.0 * n * r * r, FP32_PEAK_TF)              # F_D = 2 N r^2
+        m["project"] = ("mfma", 2.0 * n * r * K, FP32_PEAK_TF)           # F_E = 2 N r K
+    return m
 
 
 def main():
@@ -68,6 +75,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 materialised Phi, 2 Phi-free (NLE_MODE_*)")
     ap.add_argument("--cpu-sample", type=int, default=768, help="side of the CPU-baseline sample image")
     ap.add_argument("--cpu-threads", type=int, default=16, help="BLAS threads for the CPU baseline (<= visible cores)")
     args = ap.parse_args()
@@ -95,6 +103,7 @@ def main():
     H, W, L = cfg["H"], cfg["W"], cfg["L"]
 
     ctx = nle.Context(local_rank)
+    ctx.set_mode(args.mode)
     g = nle.sample_grid(H, W, cfg["n_row"], cfg["n_col"])
     p = g["n_sel_rows"] * g["n_sel_cols"]
     if world > 1:
@@ -137,7 +146,8 @@ def main():
     value = (H * W / 1e6) / (elapsed / args.steps)
 
     # ---- roofline of the dominant kernel (this rank's launches)
-    models = roofline_models(cfg, info, L)
+    phi_free = "nystrom_extend" not in {k for k, v in stats.items() if v[0] > 0}
+    models = roofline_models(info, L, phi_free)
     per_kernel = {}
     for name, (launches, total_ms) in stats.items():
         if launches == 0:
@@ -145,18 +155,22 @@ def main():
         avg_ms = total_ms / launches
         rec = {"launches_per_step": launches / args.steps, "avg_ms": avg_ms, "total_ms_per_step": total_ms / args.steps}
         if name in models:
-            bound, units, _ = models[name]
+            bound, units, peak = models[name]
             if bound == "hbm":
-                ach, peak, unit = units / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+                ach, unit = units / (avg_ms * 1e-3) / 1e9, "GB/s"
             else:
-                ach, peak, unit = units / (avg_ms * 1e-3) / 1e12, FP32_MFMA_PEAK_TF, "TFLOP/s"
+                ach, unit = units / (avg_ms * 1e-3) / 1e12, "TFLOP/s"
             rec.update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
+            if name == "sinkhorn_pass" and phi_free:
+                rec["hbm_equivalent_GBs"] = info["n_local"] * info["r"] * 4.0 / (avg_ms * 1e-3) / 1e9
         per_kernel[name] = rec
     dom = max((k for k in per_kernel if "bound" in per_kernel[k]), key=lambda k: per_kernel[k]["total_ms_per_step"])
     d = per_kernel[dom]
     roofline = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
                 "frac": d["frac"], "traffic": None, "avg_launch_ms": d["avg_ms"],
                 "launches_per_step": d["launches_per_step"]}
+    if "hbm_equivalent_GBs" in d:
+        roofline["hbm_equivalent_GBs"] = d["hbm_equivalent_GBs"]
 
     # ---- CPU baseline: the fp64 numpy oracle on a bounded sample (rank 0, N = 1 only)
     cpu = None
@@ -188,7 +202,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {H}x{W} synthetic luminance, {cfg['n_row']}x{cfg['n_col']} samples "
                                    f"(p={p}), K={cfg['K']}, T={cfg['T']}, L={L} layers; input resident in HBM",
-                       "parallelism": f"row-slab x{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"row-slab x{world}" if world > 1 else "single GPU",
+                       "formulation": "phi_free" if phi_free else "materialised_phi"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": per_kernel,
