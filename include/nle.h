@@ -63,10 +63,15 @@ int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
  *   NLE_MODE_AUTO          Phi-free when it applies (<= 256 samples, <= 128 eigenvectors, at least
  *                          64 pixels per sample), else materialised
  *   NLE_MODE_MATERIALISED  Phi = K_AB^T V_A Lambda^-1 is written once (N x r fp32) and streamed
- *   NLE_MODE_PHI_FREE      every pass regenerates its affinity rows in registers */
+ *   NLE_MODE_PHI_FREE      every pass regenerates its affinity rows in registers; when the luminance
+ *                          plane is integer valued in [0, 255] (the L channel of 8-bit Lab, what the
+ *                          reference always feeds, src/filter.cpp:460-469) the Sinkhorn passes use
+ *                          fp64 look-up tables instead of exponentials
+ *   NLE_MODE_PHI_FREE_EXP  Phi-free without the look-up-table specialisation */
 #define NLE_MODE_AUTO 0
 #define NLE_MODE_MATERIALISED 1
 #define NLE_MODE_PHI_FREE 2
+#define NLE_MODE_PHI_FREE_EXP 3
 int nle_ctx_set_mode(nle_ctx* ctx, int mode);
 
 /* Multi-GPU (one process per GPU).  Rank `rank` of `world` owns image rows

@@ -547,4 +547,164 @@ hipError_t project64(hipStream_t s, const float* d_lum, GridSpec gs, const Sampl
     return hipGetLastError();
 }
 
+
+// ==================================================================== quantised-luminance fast path
+// When the luminance plane is integer valued in [0, 255] -- it always is in the reference's
+// pipeline, where it is the L channel of an 8-bit Lab image (src/filter.cpp:460-469) -- and
+// because the sample set is a Cartesian grid (samplePixels, :56-80: sample s = (a, b), row a of
+// nR, column b of nC), the affinity factorises into three table look-ups
+//     k_i[s] = er[row_i][a] * ec[col_i][b] * Ep[x_i][s],
+//     er[r][a] = exp(-(r - row_a)^2/hx^2), ec[c][b] = exp(-(c - col_b)^2/hx^2), Ep[x][s] = exp(-(x - y_s)^2/hy^2)
+// (all fp64, exact integer arguments).  A Sinkhorn half-iteration for one image row r becomes
+//     g[x][b]   = sum_a er[r][a] w[a,b] Ep[x][a,b]                       (256 x nC table, LDS)
+//     d_i       = sum_b ec[c_i][b] g[x_i][b],  y_i = recip(d_i)          (nC fma per pixel)
+//     h[x][b]  += ec[c_i][b] y_i                                          (LDS histogram)
+//     z[a,b]   += er[r][a] sum_x Ep[x][a,b] h[x][b]
+// i.e. 2 nC multiply-adds per pixel instead of p exponentials and 2p fp64 fma, in fp64 throughout.
+namespace {
+constexpr int kLevels = 256;
+}
+
+int sink_hist_max_cols() { return 36; }  // 2 * 256 * nC doubles of LDS
+
+__global__ __launch_bounds__(256) void k_check_levels(const float* __restrict__ lum, long long n,
+                                                      int* __restrict__ flag) {
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = lum[i];
+        bad = bad || !(v >= 0.f && v <= (float)(kLevels - 1) && v == floorf(v));
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+hipError_t check_levels(hipStream_t s, const float* d_lum, long long n, int* d_flag) {
+    hipError_t e = hipMemsetAsync(d_flag, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    long long g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_check_levels, dim3((unsigned)g), dim3(256), 0, s, d_lum, n, d_flag);
+    return hipGetLastError();
+}
+
+// er: [nrows_local][nR], ecT: [nC][W], Ep: [256][p]
+__global__ void k_hist_tables(GridSpec gs, const Sample4* __restrict__ samples, int p, double inv_hx2,
+                              double inv_hy2, int row0, int nrows_local, double* __restrict__ er,
+                              double* __restrict__ ecT, double* __restrict__ Ep) {
+    const long long n_er = (long long)nrows_local * gs.nSelRows, n_ec = (long long)gs.nSelCols * gs.W,
+                    n_ep = (long long)kLevels * p;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_er + n_ec + n_ep;
+         i += (long long)gridDim.x * blockDim.x) {
+        if (i < n_er) {
+            const int r = row0 + (int)(i / gs.nSelRows), a = (int)(i % gs.nSelRows);
+            const double d = (double)(r - (gs.rowOff + a * gs.rowStep));
+            er[i] = exp(-(d * d) * inv_hx2);
+        } else if (i < n_er + n_ec) {
+            const long long j = i - n_er;
+            const int b = (int)(j / gs.W), c = (int)(j % gs.W);
+            const double d = (double)(c - (gs.colOff + b * gs.colStep));
+            ecT[j] = exp(-(d * d) * inv_hx2);
+        } else {
+            const long long j = i - n_er - n_ec;
+            const int x = (int)(j / p), sidx = (int)(j % p);
+            const double d = (double)x - (double)samples[sidx].z;
+            Ep[j] = exp(-(d * d) * inv_hy2);
+        }
+    }
+}
+
+hipError_t hist_tables(hipStream_t s, GridSpec gs, const Sample4* d_samples, int p, double hx, double hy, int row0,
+                       int nrows_local, double* d_er, double* d_ecT, double* d_Ep) {
+    hipLaunchKernelGGL(k_hist_tables, dim3(256), dim3(256), 0, s, gs, d_samples, p, 1.0 / (hx * hx), 1.0 / (hy * hy),
+                       row0, nrows_local, d_er, d_ecT, d_Ep);
+    return hipGetLastError();
+}
+
+// one workgroup per local image row; partial: [nrows_local][ldp] doubles
+__global__ __launch_bounds__(256) void k_sink_hist(int mode, const float* __restrict__ lum, GridSpec gs, int p,
+                                                   int ldp, int row0, const double* __restrict__ er,
+                                                   const double* __restrict__ ecT, const double* __restrict__ Ep,
+                                                   const double* __restrict__ w, double eps,
+                                                   double* __restrict__ ybuf, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int nC = gs.nSelCols, nR = gs.nSelRows, W = gs.W;
+    double* g = reinterpret_cast<double*>(smem_raw);  // [256][nC]
+    double* h = g + kLevels * nC;                      // [256][nC]
+    double* ew = h + kLevels * nC;                     // [p]   er[r][a] * w[a,b]
+    const int tid = threadIdx.x;
+    const int lrow = blockIdx.x, r = row0 + lrow;
+    const double* er_r = er + (size_t)lrow * nR;
+    for (int i = tid; i < kLevels * nC; i += 256) h[i] = 0.0;
+    if (mode != ROWPASS_COLSUM) {
+        for (int sidx = tid; sidx < p; sidx += 256) ew[sidx] = er_r[sidx / nC] * w[sidx];
+        __syncthreads();
+        for (int i = tid; i < kLevels * nC; i += 256) {
+            const int x = i / nC, b = i - x * nC;
+            const double* ep = Ep + (size_t)x * p + b;
+            double s0 = 0.0, s1 = 0.0;
+            int a = 0;
+            for (; a + 1 < nR; a += 2) {
+                s0 += ew[a * nC + b] * ep[a * nC];
+                s1 += ew[(a + 1) * nC + b] * ep[(a + 1) * nC];
+            }
+            if (a < nR) s0 += ew[a * nC + b] * ep[a * nC];
+            g[i] = s0 + s1;
+        }
+    }
+    __syncthreads();
+    // is this image row a sample row?
+    const int dr = r - gs.rowOff;
+    const bool sample_row = dr >= 0 && (dr % gs.rowStep) == 0 && (dr / gs.rowStep) < nR;
+    for (int c = tid; c < W; c += 256) {
+        const size_t gi = (size_t)r * W + c;
+        const int x = (int)lum[gi];
+        bool smp = false;
+        if (sample_row) {
+            const int dc = c - gs.colOff;
+            smp = dc >= 0 && (dc % gs.colStep) == 0 && (dc / gs.colStep) < nC;
+        }
+        double y = 1.0;
+        if (mode != ROWPASS_COLSUM) {
+            double s0 = 0.0, s1 = 0.0;
+            int b = 0;
+            for (; b + 1 < nC; b += 2) {
+                s0 += ecT[(size_t)b * W + c] * g[x * nC + b];
+                s1 += ecT[(size_t)(b + 1) * W + c] * g[x * nC + b + 1];
+            }
+            if (b < nC) s0 += ecT[(size_t)b * W + c] * g[x * nC + b];
+            y = recip_or_zero_d(s0 + s1, eps);
+        }
+        if (smp) y = 0.0;
+        if (ybuf != nullptr) ybuf[(size_t)lrow * W + c] = y;
+        if (y != 0.0)
+            for (int b = 0; b < nC; ++b) atomicAdd(&h[x * nC + b], ecT[(size_t)b * W + c] * y);
+    }
+    __syncthreads();
+    for (int sidx = tid; sidx < ldp; sidx += 256) {
+        double out = 0.0;
+        if (sidx < p) {
+            const int a = sidx / nC, b = sidx - a * nC;
+            double s0 = 0.0, s1 = 0.0;
+            for (int x = 0; x < kLevels; x += 2) {
+                s0 += Ep[(size_t)x * p + sidx] * h[x * nC + b];
+                s1 += Ep[(size_t)(x + 1) * p + sidx] * h[(x + 1) * nC + b];
+            }
+            out = er_r[a] * (s0 + s1);
+        }
+        partial[(size_t)lrow * ldp + sidx] = out;
+    }
+}
+
+hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, int p, int ldp, int row0,
+                     int nrows_local, const double* d_er, const double* d_ecT, const double* d_Ep,
+                     const double* d_w, double eps, double* d_ybuf, double* d_partial) {
+    if (nrows_local <= 0) return hipSuccess;
+    const size_t shm = ((size_t)2 * kLevels * gs.nSelCols + p) * sizeof(double);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sink_hist),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_sink_hist, dim3((unsigned)nrows_local), dim3(256), shm, s, mode, d_lum, gs, p, ldp, row0, d_er,
+                       d_ecT, d_Ep, d_w, eps, d_ybuf, d_partial);
+    return hipGetLastError();
+}
+
 }  // namespace nlek

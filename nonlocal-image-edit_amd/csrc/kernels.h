@@ -110,6 +110,16 @@ hipError_t project64(hipStream_t s, const float* d_lum, GridSpec gs, const Sampl
                      float npw, long long pix0, long long M, const double* d_D, int K, const double* d_c, float* d_V,
                      int ldv);
 
+// ---- quantised-luminance (integer 0..255) Sinkhorn pass: table look-ups instead of exponentials ----
+int sink_hist_max_cols();
+hipError_t check_levels(hipStream_t s, const float* d_lum, long long n, int* d_flag);  // flag != 0: not quantised
+hipError_t hist_tables(hipStream_t s, GridSpec gs, const Sample4* d_samples, int p, double hx, double hy, int row0,
+                       int nrows_local, double* d_er, double* d_ecT, double* d_Ep);
+// partial: [nrows_local][ldp] doubles (one row per image row); d_ybuf as in sink_pass
+hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, int p, int ldp, int row0,
+                     int nrows_local, const double* d_er, const double* d_ecT, const double* d_Ep,
+                     const double* d_w, double eps, double* d_ybuf, double* d_partial);
+
 // Y[l][i] = sum_k V[i][k] * g[l][k]   (g: L x ld doubles, device)
 hipError_t apply_expand(hipStream_t s, const float* d_V, long long M, int ld, const double* d_g,
                         int L, float* d_Y, long long ystride);

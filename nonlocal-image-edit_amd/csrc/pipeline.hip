@@ -31,7 +31,7 @@ struct nle_ctx {
     std::string err;
     // per-kernel HIP-event timing (nle_ctx_profile): records are resolved at the next
     // point where the stream is synchronised anyway
-    int mode = 0;  // nle_ctx_set_mode: 0 auto, 1 materialised Phi, 2 Phi-free
+    int mode = 0;  // nle_ctx_set_mode: 0 auto, 1 materialised Phi, 2 Phi-free, 3 Phi-free without look-up tables
     bool profiling = false;
     struct ProfRec {
         int kid;
@@ -223,17 +223,25 @@ struct SampleSet {
     std::vector<long long> pix;     // row-major pixel index of each sample (permuted order)
     std::vector<float> val;         // luminance
     std::vector<float4> packed;     // {row, col, lum, 0}
+    bool quantised = false;         // whole plane integer valued in [0, 255] (checked on request)
 };
 
-SampleSet fetch_samples(nle_ctx* c, const float* d_lum, const GridSpec& gs) {
+SampleSet fetch_samples(nle_ctx* c, const float* d_lum, const GridSpec& gs, bool check_quantised = false) {
     SampleSet s;
     s.gs = gs;
     s.p = gs.p();
     DevBuf<float> d_val(s.p);
+    DevBuf<int> d_flag(1);
+    int flag = 1;
     PROFILED(c, NLE_K_SMALL, nlek::gather_samples(c->stream, d_lum, gs, d_val.p));
+    if (check_quantised) {
+        PROFILED(c, NLE_K_SMALL, nlek::check_levels(c->stream, d_lum, (long long)gs.H * gs.W, d_flag.p));
+        HIP_OK(hipMemcpyAsync(&flag, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
     s.val.resize(s.p);
     HIP_OK(hipMemcpyAsync(s.val.data(), d_val.p, s.p * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
+    s.quantised = check_quantised && flag == 0;
     s.pix.resize(s.p);
     s.packed.resize(s.p);
     for (int k = 0; k < s.p; ++k) {
@@ -767,16 +775,33 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     DevBuf<double> d_B(Bh.size()), d_VA(Bh.size()), d_lam(r), d_z((size_t)kZS * P64), d_w(P64), d_uh((size_t)2 * T * r),
         d_partial((size_t)nlek::sink_pass_rows(std::max<long long>(M, 1)) * P64);
     DevBuf<double> d_cbuf((size_t)std::max<long long>(M, 1));
+    // quantised luminance + Cartesian sample grid: table look-ups replace the exponentials (fused.hip)
+    const bool hist = ss.quantised && c->mode != 3 && ss.gs.nSelCols <= nlek::sink_hist_max_cols() && M > 0;
+    const int nrows_local = (int)(M / ss.gs.W), row0 = (int)(pix0 / ss.gs.W);
+    DevBuf<double> d_er, d_ecT, d_Ep;
+    if (hist) {
+        d_er.alloc((size_t)nrows_local * ss.gs.nSelRows);
+        d_ecT.alloc((size_t)ss.gs.nSelCols * ss.gs.W);
+        d_Ep.alloc((size_t)256 * p);
+        d_partial.alloc((size_t)nrows_local * P64);
+        PROFILED(c, NLE_K_SMALL, nlek::hist_tables(c->stream, ss.gs, d_samples.p, p, hx, hy, row0, nrows_local, d_er.p,
+                                                   d_ecT.p, d_Ep.p));
+    }
     HIP_OK(hipMemcpyAsync(d_B.p, Bh.data(), Bh.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemcpyAsync(d_VA.p, ny.VA.data(), Bh.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemsetAsync(d_w.p, 0, P64 * sizeof(double), c->stream));
-    const int nrows = nlek::sink_pass_rows(std::max<long long>(M, 1));
+    const int nrows = hist ? nrows_local : nlek::sink_pass_rows(std::max<long long>(M, 1));
     // pass n uses u = uh[n-1] (w = B u) and produces uh[n]; pass 0 is the column sum Phi^T 1 (:234,239)
     auto one_pass = [&](int n, int mode, double* ybuf) {
         if (M > 0) {
-            PROFILED(c, NLE_K_SINKHORN_PASS, nlek::sink_pass(c->stream, mode, d_lum, ss.gs, d_samples.p, p, d_w.p, nsw,
-                                                             npw, pix0, M, NLE_EPS, ybuf, d_partial.p));
+            if (hist)
+                PROFILED(c, NLE_K_SINKHORN_PASS, nlek::sink_hist(c->stream, mode, d_lum, ss.gs, p, P64, row0, nrows_local,
+                                                                 d_er.p, d_ecT.p, d_Ep.p, d_w.p, NLE_EPS, ybuf,
+                                                                 d_partial.p));
+            else
+                PROFILED(c, NLE_K_SINKHORN_PASS, nlek::sink_pass(c->stream, mode, d_lum, ss.gs, d_samples.p, p, d_w.p, nsw,
+                                                                 npw, pix0, M, NLE_EPS, ybuf, d_partial.p));
             PROFILED(c, NLE_K_REDUCE, nlek::reduce_partials(c->stream, d_partial.p, nrows, P64, d_z.p, kZS));
         } else {
             HIP_OK(hipMemsetAsync(d_z.p, 0, (size_t)kZS * P64 * sizeof(double), c->stream));
@@ -854,11 +879,11 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
     if (!(hx > 0) || !(hy > 0)) throw Fail{NLE_ERR_INVALID, "hx and hy must be > 0"};
     if (gs.p() > 2048) throw Fail{NLE_ERR_INVALID, "more than 2048 samples is not supported"};
     const bool can_fuse = gs.p() <= nlek::sink_pass_max_p() && n_eig <= 128;
-    if (c->mode == 2 && !can_fuse)
+    if (c->mode >= 2 && !can_fuse)
         throw Fail{NLE_ERR_INVALID, "Phi-free path supports at most 256 samples and 128 eigenvectors"};
     // auto: Phi-free needs enough non-sample pixels per sample for its column sums to average
     // their fp32 rounding (DESIGN.md "Numerics"); tiny images cost nothing either way
-    const bool fuse = (c->mode == 2) || (c->mode == 0 && can_fuse && (long long)H * W >= 64ll * gs.p());
+    const bool fuse = (c->mode >= 2) || (c->mode == 0 && can_fuse && (long long)H * W >= 64ll * gs.p());
     HIP_OK(hipSetDevice(c->device));
 
     auto f = new nle_filter();
@@ -875,7 +900,7 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         // --- sample set, Ka and its eigenpairs (:486-491, host fp64)
         Timer tm_a(c->stream);
         tm_a.start();
-        SampleSet ss = fetch_samples(c, d_lum, gs);
+        SampleSet ss = fetch_samples(c, d_lum, gs, fuse && c->mode != 3);
         f->p = ss.p;
         double h0 = now_ms();
         std::vector<double> Ka = build_Ka(ss, hx, hy);
@@ -1044,7 +1069,7 @@ int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
 }
 
 int nle_ctx_set_mode(nle_ctx* ctx, int mode) {
-    if (!ctx || mode < 0 || mode > 2) return NLE_ERR_INVALID;
+    if (!ctx || mode < 0 || mode > 3) return NLE_ERR_INVALID;
     ctx->mode = mode;
     return NLE_OK;
 }

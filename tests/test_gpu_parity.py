@@ -145,7 +145,7 @@ def _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L):
     return f, Y
 
 
-@pytest.fixture(params=[1, 2], ids=["materialised", "phi_free"])
+@pytest.fixture(params=[1, 2, 3], ids=["materialised", "phi_free", "phi_free_exp"])
 def mode(request, ctx):
     """run the test under both formulations of the N-sized passes (NLE_MODE_* in include/nle.h)"""
     ctx.set_mode(request.param)
@@ -165,7 +165,7 @@ def test_train_apply_layers_match_oracle(nle, oracle, ctx, mode, case):
     # 15x20 with 96 samples (a third of the pixels are samples, lambda_min(Ka) = 2e-5) is outside
     # what the Phi-free formulation is selected for in auto mode (< 64 pixels per sample); forced, it
     # still lands within 5e-4
-    forced_tiny = mode == 2 and H * W < 64 * nle.sample_grid(H, W, nr, nc)["n_sel_rows"] * nle.sample_grid(H, W, nr, nc)["n_sel_cols"]
+    forced_tiny = mode >= 2 and H * W < 64 * nle.sample_grid(H, W, nr, nc)["n_sel_rows"] * nle.sample_grid(H, W, nr, nc)["n_sel_cols"]
     tol = 5e-4 if forced_tiny else PER_LAYER_TOL
     assert rel_l2(f.eigvals, S_o) < (5e-5 if forced_tiny else 1e-5)
     for j in range(L):
@@ -241,7 +241,7 @@ def test_cfg2_both_modes_match_oracle(nle, oracle, ctx):
     x = oracle.synthetic_luminance(H, W)
     V_o, S_o = oracle.train_filter_streaming(x, 10, 20, W / 4.0, 30.0, 10, 10)
     Y_o = oracle.apply_layers_streaming(V_o, S_o, x, 4)
-    for m in (1, 2):
+    for m in (1, 2, 3):
         ctx.set_mode(m)
         try:
             f, Y = _run_device(nle, ctx, x, 10, 20, W / 4.0, 30.0, 10, 10, 4)

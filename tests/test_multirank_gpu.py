@@ -48,7 +48,7 @@ def _worker(rank, world, port, args, mode, outdir):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("mode", [1, 2], ids=["materialised", "phi_free"])
+@pytest.mark.parametrize("mode", [1, 2, 3], ids=["materialised", "phi_free", "phi_free_exp"])
 def test_sharded_ranks_match_single_rank(nle, oracle, ctx, tmp_path, world, mode):
     import torch.multiprocessing as mp
     args = (96, 128, 6, 8, 32.0, 30.0, 10, 10, 4)

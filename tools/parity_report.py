@@ -39,7 +39,7 @@ def main():
             V_o, S_o = oracle.train_filter_streaming(x, nr, nc, hx, hy, T, K)
             Y_o = oracle.apply_layers_streaming(V_o, S_o, x, L)
             lam_min = float("nan")
-        for m, name in ((1, "materialised"), (2, "phi_free")):
+        for m, name in ((1, "materialised"), (2, "phi_free"), (3, "phi_free_exp")):
             ctx.set_mode(m)
             f = nle.NLEFilter(ctx).train_filter(x.astype(np.float32), nr, nc, hx, hy, T, K)
             Y = f.apply_layers(x.astype(np.float32), L).cpu().numpy().astype(np.float64)
