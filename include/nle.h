@@ -50,6 +50,9 @@ int nle_ctx_create(int device, void* stream, nle_ctx** out);
 void nle_ctx_destroy(nle_ctx* ctx);
 const char* nle_last_error(const nle_ctx* ctx); /* ctx may be NULL: last create error */
 int nle_ctx_synchronize(nle_ctx* ctx);
+/* The ctx keeps the device workspace of finished calls (and of destroyed filters) for reuse by
+ * the next call; nle_ctx_trim returns it to the driver (nle_ctx_destroy does so too). */
+int nle_ctx_trim(nle_ctx* ctx);
 
 /* Device memory helpers for hosts that do not link the HIP runtime themselves (the C++ surface in
  * include/nle/filter.hpp, a cgo/JNI/ctypes binding): plain hipMalloc / hipFree / hipMemcpy on

@@ -33,6 +33,7 @@ _SIGNATURES = {
     "nle_ctx_destroy": (None, [_P]),
     "nle_last_error": (C.c_char_p, [_P]),
     "nle_ctx_synchronize": (C.c_int, [_P]),
+    "nle_ctx_trim": (C.c_int, [_P]),
     "nle_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "nle_dev_free": (None, [_P, _P]),
     "nle_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -226,6 +227,10 @@ class Context:
     def set_mode(self, mode: int):
         """0 auto, 1 materialised Phi, 2 Phi-free (NLE_MODE_* in include/nle.h)."""
         _check(lib().nle_ctx_set_mode(self._h, int(mode)), self._h)
+
+    def trim(self):
+        """release the cached device workspace"""
+        _check(lib().nle_ctx_trim(self._h), self._h)
 
     def profile(self, enable: bool = True):
         """Per-kernel HIP-event timing on the ctx's stream (resets the counters)."""

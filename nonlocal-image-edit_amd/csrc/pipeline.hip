@@ -8,8 +8,12 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nle.h"
@@ -31,6 +35,12 @@ struct nle_ctx {
     std::string err;
     // per-kernel HIP-event timing (nle_ctx_profile): records are resolved at the next
     // point where the stream is synchronised anyway
+    // workspace cache: device buffers released by a call are kept and handed to the next call
+    // (hipMalloc/hipFree of multi-GB buffers cost milliseconds and hipFree synchronises the device);
+    // everything is stream-ordered on `stream`, so reuse needs no extra synchronisation
+    std::multimap<size_t, void*> arena_free;
+    size_t arena_bytes = 0;
+    std::set<nle_filter*> filters;  // live filters trained on this ctx (orphaned if the ctx dies first)
     int mode = 0;  // nle_ctx_set_mode: 0 auto, 1 materialised Phi, 2 Phi-free, 3 Phi-free without look-up tables
     bool profiling = false;
     struct ProfRec {
@@ -49,6 +59,7 @@ struct nle_filter {
     long long n_local = 0;
     int K = 0, ldv = 0, r = 0, p = 0;
     float* d_V = nullptr;
+    size_t v_bytes = 0;
     std::vector<double> eigvals;
     double ms[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -69,25 +80,69 @@ struct Fail {
             throw Fail{NLE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)};           \
     } while (0)
 
+// ---- device workspace: served from the ctx's cache when a call is in progress (g_cur) ----
+thread_local nle_ctx* g_cur = nullptr;
+struct CurCtx {
+    nle_ctx* prev;
+    explicit CurCtx(nle_ctx* c) : prev(g_cur) { g_cur = c; }
+    ~CurCtx() { g_cur = prev; }
+};
+
+void* arena_alloc(nle_ctx* c, size_t bytes) {
+    if (c) {
+        auto it = c->arena_free.lower_bound(bytes);
+        if (it != c->arena_free.end() && it->first <= bytes + bytes / 4 + 4096) {  // close enough fit
+            void* p = it->second;
+            c->arena_free.erase(it);
+            return p;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess && c && !c->arena_free.empty()) {  // out of memory: drop the cache and retry
+        (void)hipStreamSynchronize(c->stream);
+        for (auto& kv : c->arena_free) (void)hipFree(kv.second);
+        c->arena_free.clear();
+        c->arena_bytes = 0;
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) throw Fail{NLE_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)};
+    if (c) c->arena_bytes += bytes;
+    return p;
+}
+
+void arena_release(nle_ctx* c, void* p, size_t bytes) {
+    if (!p) return;
+    if (c) {
+        c->arena_free.emplace(bytes, p);
+    } else {
+        (void)hipFree(p);
+    }
+}
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    nle_ctx* owner = nullptr;
     DevBuf() = default;
     explicit DevBuf(size_t count) { alloc(count); }
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     void alloc(size_t count) {
         release();
-        if (count) HIP_OK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        if (count) {
+            owner = g_cur;
+            p = static_cast<T*>(arena_alloc(owner, count * sizeof(T)));
+        }
         n = count;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) arena_release(owner, p, n * sizeof(T));
         p = nullptr;
         n = 0;
     }
-    T* take() {
+    T* take() {  // ownership moves to the caller (bytes = n * sizeof(T), release with arena_release)
         T* q = p;
         p = nullptr;
         n = 0;
@@ -430,39 +485,76 @@ std::vector<double> gram_all(nle_ctx* c, const float* d_phi, long long M, int ld
 }
 
 // ---- small host algebra, column-major ----
+// The p x p products of the orthogonalisation are split by output columns over a few short-lived
+// threads (a 200^3 product is ~2 ms on one core; thread start-up is ~50 us).
+template <typename F>
+void par_cols(int n, long long work_per_col, F&& body) {
+    int nt = (int)std::min<long long>(4, (work_per_col * n) / 2000000 + 1);
+    if (const char* e = std::getenv("NLE_HOST_THREADS")) nt = std::max(1, std::atoi(e));
+    nt = std::min(nt, n);
+    if (nt <= 1) {
+        body(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back([&, t] { body((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); });
+    body(0, n / nt);
+    for (auto& x : th) x.join();
+}
 // C (m x n) = A (m x k) * B (k x n)
 void mm(const double* A, const double* B, double* C, int m, int k, int n) {
-    std::fill(C, C + (size_t)m * n, 0.0);
-    for (int j = 0; j < n; ++j)
-        for (int l = 0; l < k; ++l) {
-            const double b = B[(size_t)j * k + l];
-            const double* a = A + (size_t)l * m;
+    par_cols(n, (long long)m * k, [&](int j0, int j1) {
+        for (int j = j0; j < j1; ++j) {
             double* cc = C + (size_t)j * m;
-            for (int i = 0; i < m; ++i) cc[i] += a[i] * b;
+            std::fill(cc, cc + m, 0.0);
+            for (int l = 0; l < k; ++l) {
+                const double b = B[(size_t)j * k + l];
+                const double* a = A + (size_t)l * m;
+                for (int i = 0; i < m; ++i) cc[i] += a[i] * b;
+            }
         }
+    });
 }
 // C (m x n) = A (m x k) * B^T (B is n x k)
 void mm_nt(const double* A, const double* B, double* C, int m, int k, int n) {
-    std::fill(C, C + (size_t)m * n, 0.0);
-    for (int l = 0; l < k; ++l)
-        for (int j = 0; j < n; ++j) {
-            const double b = B[(size_t)l * n + j];
-            const double* a = A + (size_t)l * m;
+    par_cols(n, (long long)m * k, [&](int j0, int j1) {
+        for (int j = j0; j < j1; ++j) {
             double* cc = C + (size_t)j * m;
-            for (int i = 0; i < m; ++i) cc[i] += a[i] * b;
+            std::fill(cc, cc + m, 0.0);
+            for (int l = 0; l < k; ++l) {
+                const double b = B[(size_t)l * n + j];
+                const double* a = A + (size_t)l * m;
+                for (int i = 0; i < m; ++i) cc[i] += a[i] * b;
+            }
         }
+    });
 }
 // C (k x n) = A^T (A is m x k) * B (m x n)
 void mm_tn(const double* A, const double* B, double* C, int m, int k, int n) {
-    for (int j = 0; j < n; ++j)
-        for (int l = 0; l < k; ++l) {
-            const double* a = A + (size_t)l * m;
-            const double* b = B + (size_t)j * m;
-            double s = 0.0;
-            for (int i = 0; i < m; ++i) s += a[i] * b[i];
-            C[(size_t)j * k + l] = s;
-        }
+    par_cols(n, (long long)m * k, [&](int j0, int j1) {
+        for (int j = j0; j < j1; ++j)
+            for (int l = 0; l < k; ++l) {
+                const double* a = A + (size_t)l * m;
+                const double* b = B + (size_t)j * m;
+                double s = 0.0;
+                for (int i = 0; i < m; ++i) s += a[i] * b[i];
+                C[(size_t)j * k + l] = s;
+            }
+    });
 }
+
+double now_ms();
+struct Trace {
+    bool on;
+    double t0, last;
+    Trace() : on(std::getenv("NLE_TRACE") != nullptr) { t0 = last = now_ms(); }
+    void mark(const char* what) {
+        if (!on) return;
+        const double t = now_ms();
+        std::fprintf(stderr, "[nle trace] %-28s +%8.3f ms  (t=%8.3f)\n", what, t - last, t - t0);
+        last = t;
+    }
+};
 
 double now_ms() {
     using namespace std::chrono;
@@ -573,12 +665,21 @@ Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_
 struct OrthoSS {
     int q = 0, K = 0;
     std::vector<double> Sq, D, Vrows;  // D: p x K, Vrows: p x K (col-major)
+    // state between the two halves
+    int p = 0, r = 0;
+    std::vector<double> cA, rA, Kr, P, Wa, S;
 };
 
-OrthoSS orthogonalize_sample_space(const Nystrom& ny, int p, const std::vector<double>& u_c,
-                                   const std::vector<double>& u_r, std::vector<double> Gk, int n_eig) {
+// first half: everything that does not depend on the Gram matrix (runs on the host while the GPU
+// computes Gk): sample scalings, Kr, P, Wa and S = Wa^-1/2 (:287-292)
+void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<double>& u_c,
+                      const std::vector<double>& u_r) {
     const int r = ny.r, q = ny.r;
-    std::vector<double> cA(p), rA(p);
+    o.p = p;
+    o.r = r;
+    o.q = q;
+    o.cA.resize(p);
+    o.rA.resize(p);
     for (int a = 0; a < p; ++a) {
         double sc = 0.0, sr = 0.0;
         for (int k = 0; k < r; ++k) {
@@ -586,13 +687,38 @@ OrthoSS orthogonalize_sample_space(const Nystrom& ny, int p, const std::vector<d
             sc += v * u_c[k];
             sr += v * u_r[k];
         }
-        cA[a] = recip0(sc);
-        rA[a] = recip0(sr);
+        o.cA[a] = recip0(sc);
+        o.rA[a] = recip0(sr);
     }
-    std::vector<double> VL((size_t)p * r), Kr((size_t)p * p);
+    std::vector<double> VL((size_t)p * r);
+    o.Kr.resize((size_t)p * p);
     for (int k = 0; k < r; ++k)
         for (int a = 0; a < p; ++a) VL[(size_t)k * p + a] = ny.VA[(size_t)k * p + a] * ny.lam[k];
-    mm_nt(VL.data(), ny.VA.data(), Kr.data(), p, r, p);
+    mm_nt(VL.data(), ny.VA.data(), o.Kr.data(), p, r, p);
+    if (r < p) {
+        o.P.resize((size_t)p * p);
+        mm_nt(ny.VA.data(), ny.VA.data(), o.P.data(), p, r, p);
+    }
+    o.Wa.resize((size_t)q * q);
+    for (int b = 0; b < q; ++b)
+        for (int a = 0; a < q; ++a) o.Wa[(size_t)b * q + a] = o.rA[a] * o.Kr[(size_t)b * p + a] * o.cA[b];  // :249
+    std::vector<double> U2((size_t)q * q), l2(q);
+    int r2 = 0;
+    if (!nleh::eigen_decomposition(o.Wa.data(), q, NLE_EPS, U2.data(), l2.data(), &r2))
+        throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Wa"};
+    std::vector<double> Us((size_t)q * std::max(r2, 1));
+    o.S.resize((size_t)q * q);
+    for (int k = 0; k < r2; ++k) {
+        const double sv = std::sqrt(recip0(l2[k]));
+        for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * sv;
+    }
+    mm_nt(Us.data(), U2.data(), o.S.data(), q, r2, q);  // :287-292
+}
+
+// second half: needs Gk
+void ortho_ss_finish(OrthoSS& o, std::vector<double> Gk, int n_eig) {
+    const int p = o.p, r = o.r, q = o.q;
+    const std::vector<double>&cA = o.cA, &rA = o.rA, &Kr = o.Kr, &Wa = o.Wa, &S = o.S;
     for (int a = q; a < p; ++a) {  // B-block samples
         const double c2 = cA[a] * cA[a];
         const double* ka = Kr.data() + (size_t)a * p;
@@ -601,32 +727,14 @@ OrthoSS orthogonalize_sample_space(const Nystrom& ny, int p, const std::vector<d
             for (int i = 0; i < p; ++i) Gk[(size_t)j * p + i] += ka[i] * vj;
         }
     }
-    std::vector<double> P;
     if (r < p) {
-        P.resize((size_t)p * p);
-        mm_nt(ny.VA.data(), ny.VA.data(), P.data(), p, r, p);
         std::vector<double> T((size_t)p * p);
-        mm(P.data(), Gk.data(), T.data(), p, p, p);
-        mm(T.data(), P.data(), Gk.data(), p, p, p);
+        mm(o.P.data(), Gk.data(), T.data(), p, p, p);
+        mm(T.data(), o.P.data(), Gk.data(), p, p, p);
     }
-    OrthoSS o;
-    o.q = q;
-    std::vector<double> Wa((size_t)q * q), WW((size_t)q * q);
+    std::vector<double> WW((size_t)q * q);
     for (int b = 0; b < q; ++b)
-        for (int a = 0; a < q; ++a) {
-            Wa[(size_t)b * q + a] = rA[a] * Kr[(size_t)b * p + a] * cA[b];   // :249
-            WW[(size_t)b * q + a] = rA[a] * Gk[(size_t)b * p + a] * rA[b];   // Wab Wab^T, :296
-        }
-    std::vector<double> U2((size_t)q * q), l2(q);
-    int r2 = 0;
-    if (!nleh::eigen_decomposition(Wa.data(), q, NLE_EPS, U2.data(), l2.data(), &r2))
-        throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Wa"};
-    std::vector<double> Us((size_t)q * std::max(r2, 1)), S((size_t)q * q);
-    for (int k = 0; k < r2; ++k) {
-        const double sv = std::sqrt(recip0(l2[k]));
-        for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * sv;
-    }
-    mm_nt(Us.data(), U2.data(), S.data(), q, r2, q);  // :287-292
+        for (int a = 0; a < q; ++a) WW[(size_t)b * q + a] = rA[a] * Gk[(size_t)b * p + a] * rA[b];  // Wab Wab^T, :296
     std::vector<double> T1((size_t)q * q), Qm((size_t)q * q);
     mm(S.data(), WW.data(), T1.data(), q, q, q);
     mm(T1.data(), S.data(), Qm.data(), q, q, q);
@@ -650,7 +758,7 @@ OrthoSS orthogonalize_sample_space(const Nystrom& ny, int p, const std::vector<d
     }
     o.D.resize((size_t)p * K);
     if (r < p) {
-        mm(P.data(), RT2.data(), o.D.data(), p, q, K);  // first q columns of P
+        mm(o.P.data(), RT2.data(), o.D.data(), p, q, K);  // first q columns of P
     } else {
         o.D = RT2;
     }
@@ -665,7 +773,6 @@ OrthoSS orthogonalize_sample_space(const Nystrom& ny, int p, const std::vector<d
             o.Vrows[(size_t)k * p + a] = cA[a] * sv;
         }
     }
-    return o;
 }
 
 // unpack the upper-triangular 32x32 tile list of gram()/gram_fused() into a symmetric n x n matrix
@@ -712,7 +819,7 @@ void scatter_sample_rows(nle_ctx* c, const SampleSet& ss, int nrows, const std::
 
 // ---- the two train paths; both fill f->K, ldv, eigvals, d_V ----
 struct StageMs {
-    double sinkhorn = 0, gram = 0, project = 0, host = 0;
+    double sinkhorn = 0, gram = 0, project = 0, host = 0, host_overlapped = 0;
 };
 
 // (1) materialised Phi: Phi = K_AB^T B written once (N x r fp32), streamed by every later pass
@@ -747,6 +854,7 @@ void train_materialised(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     scatter_sample_rows(c, ss, o.q, o.VArows, o.q, o.K, f->ldv, pix0, M, d_V.p);
     tm_p.stop();
     HIP_OK(hipStreamSynchronize(c->stream));
+    f->v_bytes = d_V.n * sizeof(float);
     f->d_V = d_V.take();
     ms->sinkhorn = tm_s.ms();
     ms->gram = tm_g.ms();
@@ -759,6 +867,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     const int p = ss.p, r = ny.r;
     const int P64 = nlek::sink_pass_ld(p);
     const float nsw = nsw_of(hx), npw = nsw_of(hy);
+    Trace tr;
     Timer tm_s(c->stream), tm_g(c->stream), tm_p(c->stream);
     tm_s.start();
     // the pass kernel reads the sample table up to the next multiple of 16: pad with zeros (their
@@ -792,6 +901,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemsetAsync(d_w.p, 0, P64 * sizeof(double), c->stream));
     const int nrows = hist ? nrows_local : nlek::sink_pass_rows(std::max<long long>(M, 1));
+    tr.mark("ss: alloc+upload");
     // pass n uses u = uh[n-1] (w = B u) and produces uh[n]; pass 0 is the column sum Phi^T 1 (:234,239)
     auto one_pass = [&](int n, int mode, double* ybuf) {
         if (M > 0) {
@@ -821,8 +931,11 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     HIP_OK(hipMemcpyAsync(u_r.data(), d_uh.p + (size_t)(2 * T - 1) * r, r * sizeof(double), hipMemcpyDeviceToHost,
                           c->stream));
     tm_s.stop();
+    tr.mark("ss: passes enqueued");
+    HIP_OK(hipStreamSynchronize(c->stream));
+    tr.mark("ss: sinkhorn sync");
 
-    // Gram in sample space (fp64 MFMA)
+    // Gram in sample space (fp64 MFMA), enqueued; the host half that does not need it runs meanwhile
     tm_g.start();
     const int ntiles = nlek::gram64_num_tiles(p);
     DevBuf<double> d_gpart(std::max<size_t>(nlek::gram64_partial_elems(std::max<long long>(M, 1), p), 1));
@@ -833,15 +946,24 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     } else {
         HIP_OK(hipMemsetAsync(d_tiles.p, 0, (size_t)ntiles * 256 * sizeof(double), c->stream));
     }
+    double h0 = now_ms();
+    OrthoSS o;
+    ortho_ss_prepare(o, ny, p, u_c, u_r);  // host, while the Gram kernel runs
+    const double h_overlapped = now_ms() - h0;
+    tr.mark("ss: ortho prepare (host)");
+    // (a device-to-host copy into pageable memory blocks the host until the stream reaches it, so it
+    // is issued only now)
     all_reduce(c, d_tiles.p, (size_t)ntiles * 256);
     std::vector<double> tiles((size_t)ntiles * 256);
     HIP_OK(hipMemcpyAsync(tiles.data(), d_tiles.p, tiles.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
     tm_g.stop();
-
-    double h0 = now_ms();
-    OrthoSS o = orthogonalize_sample_space(ny, p, u_c, u_r, unpack_tiles(tiles, nlek::gram64_ld(p), p, 16), n_eig);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    tr.mark("ss: gram sync");
+    h0 = now_ms();
+    ortho_ss_finish(o, unpack_tiles(tiles, nlek::gram64_ld(p), p, 16), n_eig);
     ms->host += now_ms() - h0;
+    tr.mark("ss: ortho finish (host)");
+    ms->host_overlapped += h_overlapped;
     f->K = o.K;
     f->ldv = ld4(o.K);
     f->eigvals = o.Sq;
@@ -858,9 +980,12 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     DevBuf<float> d_V((size_t)std::max<long long>(M, 1) * f->ldv);
     PROFILED(c, NLE_K_PROJECT, nlek::project64(c->stream, d_lum, ss.gs, d_samples.p, p, nsw, npw, pix0, M, d_D.p, o.K,
                                                d_cbuf.p, d_V.p, f->ldv));
+    tr.mark("ss: project enqueued");
     scatter_sample_rows(c, ss, p, o.Vrows, p, o.K, f->ldv, pix0, M, d_V.p);
     tm_p.stop();
     HIP_OK(hipStreamSynchronize(c->stream));
+    tr.mark("ss: project sync");
+    f->v_bytes = d_V.n * sizeof(float);
     f->d_V = d_V.take();
     ms->sinkhorn = tm_s.ms();
     ms->gram = tm_g.ms();
@@ -896,15 +1021,19 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         const long long M = (long long)(f->row1 - f->row0) * W;
         f->n_local = M;
         const double t_begin = now_ms();
+        Trace tr;
         StageMs sm;
         // --- sample set, Ka and its eigenpairs (:486-491, host fp64)
         Timer tm_a(c->stream);
         tm_a.start();
         SampleSet ss = fetch_samples(c, d_lum, gs, fuse && c->mode != 3);
+        tr.mark("fetch_samples");
         f->p = ss.p;
         double h0 = now_ms();
         std::vector<double> Ka = build_Ka(ss, hx, hy);
+        tr.mark("build_Ka");
         Nystrom ny = solve_Ka(Ka, ss.p);
+        tr.mark("eig(Ka)");
         sm.host += now_ms() - h0;
         f->r = ny.r;
         tm_a.stop();
@@ -912,6 +1041,7 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
             train_sample_space(c, f, d_lum, ss, ny, hx, hy, T, n_eig, pix0, M, &sm);
         else
             train_materialised(c, f, d_lum, ss, ny, hx, hy, T, n_eig, pix0, M, &sm);
+        tr.mark("train path");
         prof_flush(c);
         f->ms[0] = tm_a.ms();
         f->ms[1] = sm.sinkhorn;
@@ -919,6 +1049,7 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         f->ms[3] = sm.project;
         f->ms[4] = sm.host;
         f->ms[5] = now_ms() - t_begin;
+        c->filters.insert(f);
     } catch (...) {
         delete f;
         throw;
@@ -966,6 +1097,7 @@ void layer_resp(const double* ev, int K, int L, double* out) {
 
 template <typename Fn>
 int guard(nle_ctx* c, Fn&& fn) {
+    CurCtx scope(c);
     try {
         fn();
         return NLE_OK;
@@ -1023,6 +1155,10 @@ void nle_ctx_destroy(nle_ctx* ctx) {
         (void)hipEventDestroy(r.b);
     }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto* f : ctx->filters) f->ctx = nullptr;  // their V is freed directly when they are destroyed
+    for (auto& kv : ctx->arena_free) (void)hipFree(kv.second);
+    ctx->arena_free.clear();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1065,6 +1201,17 @@ int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
         HIP_OK(hipSetDevice(ctx->device));
         HIP_OK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIP_OK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int nle_ctx_trim(nle_ctx* ctx) {
+    if (!ctx) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+        for (auto& kv : ctx->arena_free) (void)hipFree(kv.second);
+        ctx->arena_free.clear();
+        ctx->arena_bytes = 0;
     });
 }
 
@@ -1262,7 +1409,8 @@ int nle_train_host(nle_ctx* ctx, const float* h_lum, int H, int W, int n_row_sam
 
 void nle_filter_destroy(nle_filter* f) {
     if (!f) return;
-    if (f->d_V) (void)hipFree(f->d_V);
+    if (f->ctx) f->ctx->filters.erase(f);
+    if (f->d_V) arena_release(f->ctx, f->d_V, f->v_bytes);  // back to the ctx's workspace cache (or hipFree)
     delete f;
 }
 
@@ -1291,7 +1439,7 @@ int nle_filter_eigvecs(const nle_filter* f, const float** d_V, int* ld) {
 }
 
 int nle_filter_copy_eigvecs(const nle_filter* f, float* d_out) {
-    if (!f || !d_out) return NLE_ERR_INVALID;
+    if (!f || !f->ctx || !d_out) return NLE_ERR_INVALID;
     return guard(f->ctx, [&] {
         HIP_OK(hipSetDevice(f->ctx->device));
         HIP_OK(hipMemcpyAsync(d_out, f->d_V, (size_t)f->n_local * f->ldv * sizeof(float), hipMemcpyDeviceToDevice,
@@ -1307,12 +1455,12 @@ int nle_filter_timings(const nle_filter* f, double* h_ms) {
 }
 
 int nle_apply(nle_filter* f, const float* d_x, int H, int W, const double* h_fS, float* d_y) {
-    if (!f || !d_x || !h_fS || !d_y) return NLE_ERR_INVALID;
+    if (!f || !f->ctx || !d_x || !h_fS || !d_y) return NLE_ERR_INVALID;
     return guard(f->ctx, [&] { apply_impl(f, d_x, H, W, h_fS, 1, d_y); });
 }
 
 int nle_apply_layers(nle_filter* f, const float* d_x, int H, int W, int L, float* d_y) {
-    if (!f || !d_x || !d_y || L < 1) return NLE_ERR_INVALID;
+    if (!f || !f->ctx || !d_x || !d_y || L < 1) return NLE_ERR_INVALID;
     return guard(f->ctx, [&] {
         std::vector<double> resp((size_t)L * f->K);
         layer_resp(f->eigvals.data(), f->K, L, resp.data());
@@ -1333,12 +1481,12 @@ static void apply_host_common(nle_filter* f, const float* h_x, int H, int W, con
 }
 
 int nle_apply_host(nle_filter* f, const float* h_x, int H, int W, const double* h_fS, float* h_y) {
-    if (!f || !h_x || !h_fS || !h_y) return NLE_ERR_INVALID;
+    if (!f || !f->ctx || !h_x || !h_fS || !h_y) return NLE_ERR_INVALID;
     return guard(f->ctx, [&] { apply_host_common(f, h_x, H, W, h_fS, 1, h_y); });
 }
 
 int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, float* h_y) {
-    if (!f || !h_x || !h_y || L < 1) return NLE_ERR_INVALID;
+    if (!f || !f->ctx || !h_x || !h_y || L < 1) return NLE_ERR_INVALID;
     return guard(f->ctx, [&] {
         std::vector<double> resp((size_t)L * f->K);
         layer_resp(f->eigvals.data(), f->K, L, resp.data());
