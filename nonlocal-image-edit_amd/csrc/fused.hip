@@ -707,4 +707,156 @@ hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, i
     return hipGetLastError();
 }
 
+// -------------------------------------------------------------------- Gram via the same tables
+// Gk[(a,b),(a',b')] = sum_r er[r][a] er[r][a'] sum_x Ep[x][a,b] Ep[x][a',b'] A_r[x][b,b'],
+// A_r[x][b,b'] = sum over the non-sample pixels of image row r with level x of c^2 ec[c][b] ec[c][b'].
+//   1. k_ghist_rows : A_r (256 x NP histogram in LDS, NP = nC(nC+1)/2 products per pixel) -> global
+//   2. k_ghist_gemm : C[(a,a')][x,(b,b')] = sum_r EE[r][(a,a')] A_r[x,(b,b')]   (fp64 MFMA GEMM,
+//                     M = nR(nR+1)/2, N = 256 NP, K = local image rows)
+//   3. k_ghist_final: Gk[s][s'] = sum_x Ep[x][s] Ep[x][s'] C[(a,a')][x,(b,b')]
+// ~NP LDS adds per pixel plus a 46 GFLOP GEMM at cfg4, instead of p^2/2 = 20 kFLOP per pixel.
+int ghist_max_cols() { return 11; }  // 256 * NP * 8 B of LDS
+
+__device__ __forceinline__ int tri_index(int i, int j, int n) {  // i <= j < n, row-major upper triangle
+    return i * n - (i * (i - 1)) / 2 + (j - i);
+}
+
+__global__ __launch_bounds__(256) void k_ghist_rows(const float* __restrict__ lum, GridSpec gs, int row0,
+                                                    const double* __restrict__ ecT,
+                                                    const double* __restrict__ cvec, double* __restrict__ Aout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* A = reinterpret_cast<double*>(smem_raw);  // [256][NP]
+    const int nC = gs.nSelCols, W = gs.W, NP = nC * (nC + 1) / 2;
+    const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
+    for (int i = tid; i < kLevels * NP; i += 256) A[i] = 0.0;
+    __syncthreads();
+    for (int c = tid; c < W; c += 256) {
+        const double cf = cvec[(size_t)lrow * W + c];  // 0 at sample pixels
+        if (cf == 0.0) continue;
+        const int x = (int)lum[(size_t)r * W + c];
+        double q[11];
+#pragma unroll
+        for (int b = 0; b < 11; ++b) q[b] = (b < nC) ? cf * ecT[(size_t)b * W + c] : 0.0;
+        double* Ax = A + (size_t)x * NP;
+        int idx = 0;
+#pragma unroll
+        for (int b = 0; b < 11; ++b)
+#pragma unroll
+            for (int b2 = b; b2 < 11; ++b2)
+                if (b2 < nC) atomicAdd(&Ax[idx++], q[b] * q[b2]);
+    }
+    __syncthreads();
+    double* out = Aout + (size_t)lrow * kLevels * NP;
+    for (int i = tid; i < kLevels * NP; i += 256) out[i] = A[i];
+}
+
+// EE[r][m] = er[r][a] er[r][a'] for the m-th pair a <= a' (row stride ldm, zero padded)
+__global__ void k_ghist_ee(const double* __restrict__ er, int nrows, int nR, int ldm, double* __restrict__ EE) {
+    const long long n = (long long)nrows * ldm;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / ldm), m = (int)(i % ldm);
+        double v = 0.0;
+        if (m < nR * (nR + 1) / 2) {
+            int a = 0, t = m;
+            while (t >= nR - a) {
+                t -= nR - a;
+                ++a;
+            }
+            v = er[(size_t)r * nR + a] * er[(size_t)r * nR + a + t];
+        }
+        EE[i] = v;
+    }
+}
+
+// C (ldm x N) = EE^T (K x ldm) * A (K x N); one 16-column tile per wave, MT m-tiles per wave
+template <int MT>
+__global__ __launch_bounds__(256) void k_ghist_gemm(const double* __restrict__ EE, int ldm, const double* __restrict__ A,
+                                                    long long N, int K, double* __restrict__ C) {
+    constexpr int KB = 16;
+    __shared__ __attribute__((aligned(16))) double sE[KB][MT * 16 + 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const long long n0 = ((long long)blockIdx.x * 4 + wave) * 16;
+    const int m0 = blockIdx.y * MT * 16;
+    const bool ncol_ok = n0 + l15 < N;
+    f64x4 acc[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += KB) {
+        __syncthreads();
+        for (int idx = tid; idx < KB * MT * 16; idx += 256) {
+            const int kk = idx / (MT * 16), mm = idx % (MT * 16);
+            sE[kk][mm] = (k0 + kk < K && m0 + mm < ldm) ? EE[(size_t)(k0 + kk) * ldm + m0 + mm] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KB; kk += 4) {
+            const int kr = k0 + kk + kq;
+            const double bv = (ncol_ok && kr < K) ? A[(size_t)kr * N + n0 + l15] : 0.0;
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(sE[kk + kq][j * 16 + l15], bv, acc[j], 0, 0, 0);
+        }
+    }
+    if (ncol_ok) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + j * 16 + kq + 4 * e;
+                if (m < ldm) C[(size_t)m * N + n0 + l15] = acc[j][e];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ghist_final(const double* __restrict__ C, long long N, const double* __restrict__ Ep,
+                                                     int p, int nR, int nC, double* __restrict__ Gk) {
+    const int NP = nC * (nC + 1) / 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)p * p) return;
+    const int s1 = (int)(idx / p), s2 = (int)(idx % p);
+    int a1 = s1 / nC, b1 = s1 % nC, a2 = s2 / nC, b2 = s2 % nC;
+    const int m = tri_index(min(a1, a2), max(a1, a2), nR);
+    const int pc = tri_index(min(b1, b2), max(b1, b2), nC);
+    const double* Cm = C + (size_t)m * N + pc;
+    double t0 = 0.0, t1 = 0.0;
+    for (int x = 0; x < kLevels; x += 2) {
+        t0 += Ep[(size_t)x * p + s1] * Ep[(size_t)x * p + s2] * Cm[(size_t)x * NP];
+        t1 += Ep[(size_t)(x + 1) * p + s1] * Ep[(size_t)(x + 1) * p + s2] * Cm[(size_t)(x + 1) * NP];
+    }
+    Gk[idx] = t0 + t1;  // column-major == row-major (symmetric)
+}
+
+int ghist_ldm(int nR) { return ((nR * (nR + 1) / 2) + 15) & ~15; }
+size_t ghist_workspace_elems(GridSpec gs, int nrows_local) {
+    const size_t NP = (size_t)gs.nSelCols * (gs.nSelCols + 1) / 2, N = 256 * NP;
+    const size_t ldm = (size_t)ghist_ldm(gs.nSelRows);
+    return (size_t)nrows_local * N + (size_t)nrows_local * ldm + ldm * N;
+}
+
+// d_ws: ghist_workspace_elems doubles; d_Gk: p x p doubles (full symmetric matrix of this rank's rows)
+hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
+                     const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_c, double* d_ws,
+                     double* d_Gk) {
+    const int nC = gs.nSelCols, nR = gs.nSelRows;
+    if (nC > ghist_max_cols()) return hipErrorInvalidValue;
+    const int NP = nC * (nC + 1) / 2;
+    const long long N = (long long)kLevels * NP;
+    const int ldm = ghist_ldm(nR);
+    double* d_A = d_ws;
+    double* d_EE = d_A + (size_t)nrows_local * N;
+    double* d_C = d_EE + (size_t)nrows_local * ldm;
+    const size_t shm = (size_t)kLevels * NP * sizeof(double);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ghist_rows),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ghist_rows, dim3((unsigned)nrows_local), dim3(256), shm, s, d_lum, gs, row0, d_ecT, d_c, d_A);
+    hipLaunchKernelGGL(k_ghist_ee, dim3(512), dim3(256), 0, s, d_er, nrows_local, nR, ldm, d_EE);
+    constexpr int MT = 14;
+    const dim3 grid((unsigned)((N / 16 + 3) / 4), (unsigned)((ldm / 16 + MT - 1) / MT));
+    hipLaunchKernelGGL((k_ghist_gemm<MT>), grid, dim3(256), 0, s, d_EE, ldm, d_A, N, nrows_local, d_C);
+    hipLaunchKernelGGL(k_ghist_final, dim3((unsigned)(((long long)p * p + 255) / 256)), dim3(256), 0, s, d_C, N, d_Ep, p,
+                       nR, nC, d_Gk);
+    return hipGetLastError();
+}
+
 }  // namespace nlek

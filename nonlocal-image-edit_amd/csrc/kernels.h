@@ -120,6 +120,13 @@ hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, i
                      int nrows_local, const double* d_er, const double* d_ecT, const double* d_Ep,
                      const double* d_w, double eps, double* d_ybuf, double* d_partial);
 
+// Gram in sample space through the same tables (quantised luminance, nSelCols <= ghist_max_cols())
+int ghist_max_cols();
+size_t ghist_workspace_elems(GridSpec gs, int nrows_local);
+hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
+                     const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_c, double* d_ws,
+                     double* d_Gk);
+
 // Y[l][i] = sum_k V[i][k] * g[l][k]   (g: L x ld doubles, device)
 hipError_t apply_expand(hipStream_t s, const float* d_V, long long M, int ld, const double* d_g,
                         int L, float* d_Y, long long ystride);

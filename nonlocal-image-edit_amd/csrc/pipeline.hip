@@ -935,16 +935,24 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     HIP_OK(hipStreamSynchronize(c->stream));
     tr.mark("ss: sinkhorn sync");
 
-    // Gram in sample space (fp64 MFMA), enqueued; the host half that does not need it runs meanwhile
+    // Gram in sample space, enqueued; the host half that does not need it runs meanwhile.
+    // Quantised luminance: histogram + fp64 GEMM over the look-up tables (k_ghist_*); otherwise
+    // regenerated affinity rows on the fp64 MFMA (k_gram64).
     tm_g.start();
+    const bool ghist = hist && ss.gs.nSelCols <= nlek::ghist_max_cols();
     const int ntiles = nlek::gram64_num_tiles(p);
-    DevBuf<double> d_gpart(std::max<size_t>(nlek::gram64_partial_elems(std::max<long long>(M, 1), p), 1));
-    DevBuf<double> d_tiles((size_t)ntiles * 256);
-    if (M > 0) {
+    const size_t g_elems = ghist ? (size_t)p * p : (size_t)ntiles * 256;
+    DevBuf<double> d_gpart, d_tiles(g_elems);
+    if (M <= 0) {
+        HIP_OK(hipMemsetAsync(d_tiles.p, 0, g_elems * sizeof(double), c->stream));
+    } else if (ghist) {
+        d_gpart.alloc(nlek::ghist_workspace_elems(ss.gs, nrows_local));
+        PROFILED(c, NLE_K_GRAM, nlek::gram_hist(c->stream, d_lum, ss.gs, p, row0, nrows_local, d_er.p, d_ecT.p, d_Ep.p,
+                                                d_cbuf.p, d_gpart.p, d_tiles.p));
+    } else {
+        d_gpart.alloc(std::max<size_t>(nlek::gram64_partial_elems(M, p), 1));
         PROFILED(c, NLE_K_GRAM, nlek::gram64(c->stream, d_lum, ss.gs, d_samples.p, p, nsw, npw, pix0, M, d_cbuf.p,
                                              d_gpart.p, d_tiles.p));
-    } else {
-        HIP_OK(hipMemsetAsync(d_tiles.p, 0, (size_t)ntiles * 256 * sizeof(double), c->stream));
     }
     double h0 = now_ms();
     OrthoSS o;
@@ -953,14 +961,14 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     tr.mark("ss: ortho prepare (host)");
     // (a device-to-host copy into pageable memory blocks the host until the stream reaches it, so it
     // is issued only now)
-    all_reduce(c, d_tiles.p, (size_t)ntiles * 256);
-    std::vector<double> tiles((size_t)ntiles * 256);
+    all_reduce(c, d_tiles.p, g_elems);
+    std::vector<double> tiles(g_elems);
     HIP_OK(hipMemcpyAsync(tiles.data(), d_tiles.p, tiles.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     tm_g.stop();
     HIP_OK(hipStreamSynchronize(c->stream));
     tr.mark("ss: gram sync");
     h0 = now_ms();
-    ortho_ss_finish(o, unpack_tiles(tiles, nlek::gram64_ld(p), p, 16), n_eig);
+    ortho_ss_finish(o, ghist ? std::move(tiles) : unpack_tiles(tiles, nlek::gram64_ld(p), p, 16), n_eig);
     ms->host += now_ms() - h0;
     tr.mark("ss: ortho finish (host)");
     ms->host_overlapped += h_overlapped;
@@ -1119,7 +1127,8 @@ int nle_ld(int n) { return ld4(n); }
 
 size_t nle_comm_len(int n_samples) {
     const int ld = ld4(n_samples);
-    return std::max((size_t)nlek::gram_num_tiles(ld) * 1024, (size_t)nlek::gram64_num_tiles(n_samples) * 256) +
+    return std::max(std::max((size_t)nlek::gram_num_tiles(ld) * 1024, (size_t)nlek::gram64_num_tiles(n_samples) * 256),
+                    (size_t)n_samples * n_samples) +
            8 * (size_t)nlek::sink_pass_ld(n_samples);
 }
 
