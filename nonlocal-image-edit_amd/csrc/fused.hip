@@ -707,6 +707,181 @@ hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, i
     return hipGetLastError();
 }
 
+// -------------------------------------------------------------------- tiled form of the table pass
+// k_sink_hist re-reads the whole Ep table (256 x p doubles) twice per image row from L2, which is
+// what bounds it.  The tiled form splits the pass into three kernels so that Ep is read ~once:
+//   k_hist_g   : g[r][x,b] = sum_a er[r][a] w[a,b] Ep[x][a,b]   (32 rows x 8 levels per block)
+//   k_hist_pix : per image row: d_i, y_i, h[r][x,b] += ec y      (g row and h row in LDS)
+//   k_hist_hh  : HH[slab][x,b][a] = sum_{r in slab} er[r][a] h[r][x,b]
+//   k_hist_z   : z[a,b] = sum_x Ep[x][a,b] sum_slab HH[slab][x,b][a]
+__global__ __launch_bounds__(256) void k_hist_g(GridSpec gs, int p, int nrows, const double* __restrict__ er,
+                                                const double* __restrict__ Ep, const double* __restrict__ w,
+                                                double* __restrict__ g) {
+    constexpr int RT = 32, XT = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int nC = gs.nSelCols, nR = gs.nSelRows;
+    double* sQ = reinterpret_cast<double*>(smem_raw);  // [XT][p]   w o Ep
+    double* sE = sQ + XT * p;                           // [RT][nR]
+    const int tid = threadIdx.x, r0 = blockIdx.x * RT, x0 = blockIdx.y * XT;
+    for (int i = tid; i < XT * p; i += 256) sQ[i] = w[i % p] * Ep[(size_t)x0 * p + i];
+    for (int i = tid; i < RT * nR; i += 256) {
+        const int rr = r0 + i / nR;
+        sE[i] = rr < nrows ? er[(size_t)rr * nR + i % nR] : 0.0;
+    }
+    __syncthreads();
+    const int ncol = XT * nC;
+    for (int o = tid; o < RT * ncol; o += 256) {
+        const int rl = o / ncol, col = o - rl * ncol, xl = col / nC, b = col - xl * nC;
+        if (r0 + rl >= nrows) continue;
+        const double* q = sQ + xl * p + b;
+        const double* e = sE + rl * nR;
+        double s0 = 0.0, s1 = 0.0;
+        int a = 0;
+        for (; a + 1 < nR; a += 2) {
+            s0 += e[a] * q[a * nC];
+            s1 += e[a + 1] * q[(a + 1) * nC];
+        }
+        if (a < nR) s0 += e[a] * q[a * nC];
+        g[(size_t)(r0 + rl) * (kLevels * nC) + (size_t)(x0 + xl) * nC + b] = s0 + s1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restrict__ lum, GridSpec gs, int row0,
+                                                  const double* __restrict__ ecT, const double* __restrict__ g,
+                                                  double eps, double* __restrict__ ybuf, double* __restrict__ hout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int nC = gs.nSelCols, W = gs.W, n = kLevels * nC;
+    double* sg = reinterpret_cast<double*>(smem_raw);  // [256][nC]
+    double* sh = sg + n;                                // [256][nC]
+    const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
+    const double* grow = g + (size_t)lrow * n;
+    for (int i = tid; i < n; i += 256) {
+        sh[i] = 0.0;
+        sg[i] = (mode != ROWPASS_COLSUM) ? grow[i] : 0.0;
+    }
+    __syncthreads();
+    const int dr = r - gs.rowOff;
+    const bool sample_row = dr >= 0 && (dr % gs.rowStep) == 0 && (dr / gs.rowStep) < gs.nSelRows;
+    for (int c = tid; c < W; c += 256) {
+        const int x = (int)lum[(size_t)r * W + c];
+        bool smp = false;
+        if (sample_row) {
+            const int dc = c - gs.colOff;
+            smp = dc >= 0 && (dc % gs.colStep) == 0 && (dc / gs.colStep) < nC;
+        }
+        double e[11];
+#pragma unroll
+        for (int b = 0; b < 11; ++b) e[b] = (b < nC) ? ecT[(size_t)b * W + c] : 0.0;
+        double y = 1.0;
+        if (mode != ROWPASS_COLSUM) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int b = 0; b < 11; ++b) {
+                if (b < nC) {
+                    if (b & 1) s1 += e[b] * sg[x * nC + b];
+                    else s0 += e[b] * sg[x * nC + b];
+                }
+            }
+            y = recip_or_zero_d(s0 + s1, eps);
+        }
+        if (smp) y = 0.0;
+        if (ybuf != nullptr) ybuf[(size_t)lrow * W + c] = y;
+        if (y != 0.0) {
+#pragma unroll
+            for (int b = 0; b < 11; ++b)
+                if (b < nC) atomicAdd(&sh[x * nC + b], e[b] * y);
+        }
+    }
+    __syncthreads();
+    double* hrow = hout + (size_t)lrow * n;
+    for (int i = tid; i < n; i += 256) hrow[i] = sh[i];
+}
+
+// grid (ceil(256 nC / 256), nslabs): HH[slab][col][a], col = x*nC + b
+__global__ __launch_bounds__(256) void k_hist_hh(int nC, int nR, int nrows, int slab_rows, const double* __restrict__ er,
+                                                 const double* __restrict__ h, double* __restrict__ HH) {
+    const int n = kLevels * nC;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * slab_rows, r1 = min(nrows, r0 + slab_rows);
+    double acc[32];
+#pragma unroll
+    for (int a = 0; a < 32; ++a) acc[a] = 0.0;
+    if (col < n) {
+        int r = r0;
+        for (; r + 3 < r1; r += 4) {  // four independent loads in flight
+            const double h0 = h[(size_t)r * n + col], h1 = h[(size_t)(r + 1) * n + col];
+            const double h2 = h[(size_t)(r + 2) * n + col], h3 = h[(size_t)(r + 3) * n + col];
+            const double* e = er + (size_t)r * nR;
+#pragma unroll
+            for (int a = 0; a < 32; ++a)
+                if (a < nR) acc[a] += (e[a] * h0 + e[nR + a] * h1) + (e[2 * nR + a] * h2 + e[3 * nR + a] * h3);
+        }
+        for (; r < r1; ++r) {
+            const double hv = h[(size_t)r * n + col];
+            const double* e = er + (size_t)r * nR;
+#pragma unroll
+            for (int a = 0; a < 32; ++a)
+                if (a < nR) acc[a] += e[a] * hv;
+        }
+        double* out = HH + (size_t)blockIdx.y * n * nR + col;  // [slab][a][col]
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            if (a < nR) out[(size_t)a * n] = acc[a];
+    }
+}
+
+// one block per sample s = (a, b); thread = level x; fixed-order block reduction
+__global__ __launch_bounds__(256) void k_hist_z(int p, int ldp, int nC, int nR, int nslabs, const double* __restrict__ Ep,
+                                                const double* __restrict__ HH, double* __restrict__ z) {
+    __shared__ double sm[kLevels];
+    const int sidx = blockIdx.x, x = threadIdx.x;
+    if (sidx >= p) {
+        if (x == 0) z[sidx] = 0.0;
+        return;
+    }
+    const int a = sidx / nC, b = sidx - a * nC, n = kLevels * nC;
+    double hs = 0.0;
+    for (int sl = 0; sl < nslabs; ++sl) hs += HH[((size_t)sl * nR + a) * n + (size_t)x * nC + b];
+    sm[x] = Ep[(size_t)x * p + sidx] * hs;
+    __syncthreads();
+    for (int off = kLevels / 2; off > 0; off >>= 1) {
+        if (x < off) sm[x] += sm[x + off];
+        __syncthreads();
+    }
+    if (x == 0) z[sidx] = sm[0];
+}
+
+int hist_tiled_max_rows_samples() { return 32; }
+size_t hist_tiled_workspace_elems(GridSpec gs, int nrows_local) {
+    const size_t n = (size_t)kLevels * gs.nSelCols;
+    const int nslabs = (nrows_local + 31) / 32;
+    return 2 * (size_t)nrows_local * n + (size_t)nslabs * n * gs.nSelRows;
+}
+
+// one Sinkhorn half-iteration, tiled form; d_ws: hist_tiled_workspace_elems doubles; d_z: ldp doubles
+hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec gs, int p, int ldp, int row0,
+                           int nrows_local, const double* d_er, const double* d_ecT, const double* d_Ep,
+                           const double* d_w, double eps, double* d_ybuf, double* d_ws, double* d_z) {
+    const int nC = gs.nSelCols, nR = gs.nSelRows;
+    if (nC > 11 || nR > 32) return hipErrorInvalidValue;
+    const size_t n = (size_t)kLevels * nC;
+    const int slab_rows = 32, nslabs = (nrows_local + slab_rows - 1) / slab_rows;
+    double* d_g = d_ws;
+    double* d_h = d_g + (size_t)nrows_local * n;
+    double* d_HH = d_h + (size_t)nrows_local * n;
+    if (mode != ROWPASS_COLSUM) {
+        const size_t shm_g = ((size_t)8 * p + (size_t)32 * nR) * sizeof(double);
+        hipLaunchKernelGGL(k_hist_g, dim3((unsigned)((nrows_local + 31) / 32), kLevels / 8), dim3(256), shm_g, s, gs, p,
+                           nrows_local, d_er, d_Ep, d_w, d_g);
+    }
+    hipLaunchKernelGGL(k_hist_pix, dim3((unsigned)nrows_local), dim3(256), 2 * n * sizeof(double), s, mode, d_lum, gs,
+                       row0, d_ecT, d_g, eps, d_ybuf, d_h);
+    hipLaunchKernelGGL(k_hist_hh, dim3((unsigned)((n + 255) / 256), (unsigned)nslabs), dim3(256), 0, s, nC, nR,
+                       nrows_local, slab_rows, d_er, d_h, d_HH);
+    hipLaunchKernelGGL(k_hist_z, dim3((unsigned)ldp), dim3(kLevels), 0, s, p, ldp, nC, nR, nslabs, d_Ep, d_HH, d_z);
+    return hipGetLastError();
+}
+
 // -------------------------------------------------------------------- Gram via the same tables
 // Gk[(a,b),(a',b')] = sum_r er[r][a] er[r][a'] sum_x Ep[x][a,b] Ep[x][a',b'] A_r[x][b,b'],
 // A_r[x][b,b'] = sum over the non-sample pixels of image row r with level x of c^2 ec[c][b] ec[c][b'].
@@ -856,6 +1031,185 @@ hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int 
     hipLaunchKernelGGL((k_ghist_gemm<MT>), grid, dim3(256), 0, s, d_EE, ldm, d_A, N, nrows_local, d_C);
     hipLaunchKernelGGL(k_ghist_final, dim3((unsigned)(((long long)p * p + 255) / 256)), dim3(256), 0, s, d_C, N, d_Ep, p,
                        nR, nC, d_Gk);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------- projection via the tables
+// V_i[k] = c_i sum_b ec[c_i][b] T_r[x_i][b][k],  T_r[x][b][k] = sum_a er[r][a] Ep[x][a,b] D[a,b][k]
+// (reference :327 in sample space).  One workgroup per image row: D lives in LDS, the row's pixels
+// are counting-sorted by level, then levels are processed 8 at a time: build T_r for the batch
+// (8 x nC x K' doubles in LDS), then one thread per pixel does its nC*K' multiply-adds and stores
+// its K' outputs.  p*(nC+... ) work per pixel becomes nC*K' instead of p*K'.
+constexpr int kPhXB = 4;     // levels per batch
+constexpr int kPhPB = 128;   // pixels per output sub-chunk (staged through LDS for 16-byte stores)
+constexpr int kPhKmax = 64;  // eigenvectors handled by this kernel
+
+template <int KT>  // Kp = 16 KT >= K: sT rows are zero padded to Kp so that the pixel loop has no per-k branch
+__global__ __launch_bounds__(256) void k_project_hist(const float* __restrict__ lum, GridSpec gs, int p, int row0,
+                                                      const double* __restrict__ er, const double* __restrict__ ecT,
+                                                      const double* __restrict__ Ep, const double* __restrict__ Dm,
+                                                      int ldd, int K, const double* __restrict__ cvec,
+                                                      float* __restrict__ V, int ldv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int nC = gs.nSelCols, nR = gs.nSelRows, W = gs.W;
+    constexpr int Kp = 16 * KT;
+    double* sD = reinterpret_cast<double*>(smem_raw);        // [p][K]
+    double* sT = sD + (size_t)p * K;                         // [XB][nC][Kp]
+    double* sE = sT + (size_t)kPhXB * nC * Kp;              // [XB][p]  er[r][a] * Ep[x][a,b]
+    int* cnt = reinterpret_cast<int*>(sE + (size_t)kPhXB * p);  // [257] level offsets
+    int* fill = cnt + kLevels + 4;                           // [256]  (256 + 4 + 256 ints keep sOut 16-byte aligned)
+    float* sOut = reinterpret_cast<float*>(fill + kLevels);  // [PB][ldv]
+    unsigned short* idx = reinterpret_cast<unsigned short*>(sOut + (size_t)kPhPB * ldv);  // [W]
+    const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
+    const double* er_r = er + (size_t)lrow * nR;
+    for (int i = tid; i < p * K; i += 256) sD[i] = Dm[(size_t)(i / K) * ldd + (i % K)];
+    for (int i = tid; i < kLevels; i += 256) {
+        cnt[i] = 0;
+        fill[i] = 0;
+    }
+    if (tid == 0) cnt[kLevels] = 0;
+    __syncthreads();
+    const float* lrowp = lum + (size_t)r * W;
+    for (int c = tid; c < W; c += 256) atomicAdd(&cnt[(int)lrowp[c]], 1);
+    __syncthreads();
+    if (tid < 64) {  // exclusive scan of 256 counters by one wave: 4 per lane + wave scan
+        int v[4], s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = cnt[4 * tid + j];
+            s += v[j];
+        }
+        int incl = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (tid >= off) incl += t;
+        }
+        int base = incl - s;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cnt[4 * tid + j] = base;
+            base += v[j];
+        }
+        if (tid == 63) cnt[kLevels] = base;
+    }
+    __syncthreads();
+    for (int c = tid; c < W; c += 256) {
+        const int x = (int)lrowp[c];
+        idx[cnt[x] + atomicAdd(&fill[x], 1)] = (unsigned short)c;
+    }
+    __syncthreads();
+    for (int x0 = 0; x0 < kLevels; x0 += kPhXB) {
+        const int j0 = cnt[x0], j1 = cnt[x0 + kPhXB];
+        if (j1 == j0) continue;  // uniform: no pixel of this row has one of these levels
+        // stage er[r][a] * Ep[x][a,b] for the batch (coalesced), then T[xl][b][k] = sum_a sE[xl][a,b] D[a,b][k]
+        for (int i = tid; i < kPhXB * p; i += 256) {
+            const int sidx = i % p;
+            sE[i] = er_r[sidx / nC] * Ep[(size_t)x0 * p + i];
+        }
+        __syncthreads();
+        {
+            constexpr int kc = Kp / 4;  // chunks of 4 consecutive k (zero beyond K)
+            for (int o = tid; o < kPhXB * nC * kc; o += 256) {
+                const int xl = o / (nC * kc), rem = o - xl * nC * kc, b = rem / kc, k0 = (rem - b * kc) * 4;
+                const double* se = sE + (size_t)xl * p + b;
+                double t[4] = {0.0, 0.0, 0.0, 0.0};
+                if (k0 + 3 < K) {
+                    for (int a = 0; a < nR; ++a) {
+                        const double ev = se[a * nC];
+                        const double* dp = sD + (size_t)(a * nC + b) * K + k0;
+                        t[0] += ev * dp[0];
+                        t[1] += ev * dp[1];
+                        t[2] += ev * dp[2];
+                        t[3] += ev * dp[3];
+                    }
+                } else if (k0 < K) {
+                    for (int a = 0; a < nR; ++a) {
+                        const double ev = se[a * nC];
+                        const double* dp = sD + (size_t)(a * nC + b) * K + k0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (k0 + q < K) t[q] += ev * dp[q];
+                    }
+                }
+                double* tp = sT + ((size_t)xl * nC + b) * Kp + k0;
+                tp[0] = t[0];
+                tp[1] = t[1];
+                tp[2] = t[2];
+                tp[3] = t[3];
+            }
+        }
+        __syncthreads();
+        for (int jb = j0; jb < j1; jb += kPhPB) {
+            const int npix = min(kPhPB, j1 - jb);
+            if (tid < npix) {
+                const int c = idx[jb + tid];
+                const int xl = (int)lrowp[c] - x0;
+                const double cf = cvec[(size_t)lrow * W + c];
+                double acc[Kp];
+#pragma unroll
+                for (int k = 0; k < Kp; ++k) acc[k] = 0.0;
+                const double* Tx = sT + (size_t)xl * nC * Kp;
+                for (int b = 0; b < nC; ++b) {
+                    const double e = ecT[(size_t)b * W + c];
+                    const double* Tb = Tx + (size_t)b * Kp;
+#pragma unroll
+                    for (int k = 0; k < Kp; ++k) acc[k] += e * Tb[k];
+                }
+                float* so = sOut + (size_t)tid * ldv;
+#pragma unroll
+                for (int k = 0; k < Kp; ++k)
+                    if (k < ldv) so[k] = (float)(cf * acc[k]);  // columns K..ldv-1 are exact zeros (T is zero padded)
+            }
+            __syncthreads();
+            // whole rows of V, 16 bytes per lane
+            const int nq = ldv >> 2;
+            for (int it = tid; it < npix * nq; it += 256) {
+                const int pj = it / nq, q = it - pj * nq;
+                const int c = idx[jb + pj];
+                *reinterpret_cast<float4*>(V + ((size_t)lrow * W + c) * ldv + 4 * q) =
+                    *reinterpret_cast<const float4*>(sOut + (size_t)pj * ldv + 4 * q);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+bool project_hist_ok(GridSpec gs, int p, int K) {
+    if (K > kPhKmax || gs.W > 65535) return false;
+    const size_t Kp = ((size_t)K + 15) & ~(size_t)15;
+    const size_t shm = ((size_t)p * K + (size_t)kPhXB * gs.nSelCols * Kp + (size_t)kPhXB * p) * sizeof(double) +
+                       (size_t)(2 * kLevels + 4) * sizeof(int) + (size_t)kPhPB * (((size_t)K + 3) & ~(size_t)3) * sizeof(float) +
+                       (size_t)gs.W * sizeof(unsigned short) + 16;
+    return K <= kPhKmax && shm <= 150 * 1024;
+}
+
+hipError_t project_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
+                        const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_D, int ldd, int K,
+                        const double* d_c, float* d_V, int ldv) {
+    if (nrows_local <= 0) return hipSuccess;
+    const int KT = (K + 15) / 16;
+    const size_t shm = ((size_t)p * K + (size_t)kPhXB * gs.nSelCols * 16 * KT + (size_t)kPhXB * p) * sizeof(double) +
+                       (size_t)(2 * kLevels + 4) * sizeof(int) + (size_t)kPhPB * ldv * sizeof(float) +
+                       (size_t)gs.W * sizeof(unsigned short) + 16;
+    hipError_t e = hipSuccess;
+#define NLE_PH_CASE(T)                                                                                              \
+    case T:                                                                                                         \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_project_hist<T>),                                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                             \
+        if (e != hipSuccess) return e;                                                                              \
+        hipLaunchKernelGGL((k_project_hist<T>), dim3((unsigned)nrows_local), dim3(256), shm, s, d_lum, gs, p, row0, \
+                           d_er, d_ecT, d_Ep, d_D, ldd, K, d_c, d_V, ldv);                                          \
+        break;
+    switch (KT) {
+        NLE_PH_CASE(1)
+        NLE_PH_CASE(2)
+        NLE_PH_CASE(3)
+        NLE_PH_CASE(4)
+        default:
+            return hipErrorInvalidValue;
+    }
+#undef NLE_PH_CASE
     return hipGetLastError();
 }
 

@@ -120,12 +120,24 @@ hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, i
                      int nrows_local, const double* d_er, const double* d_ecT, const double* d_Ep,
                      const double* d_w, double eps, double* d_ybuf, double* d_partial);
 
+// tiled form of sink_hist (three kernels, Ep read once per pass); writes the full column sums to d_z
+size_t hist_tiled_workspace_elems(GridSpec gs, int nrows_local);
+hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec gs, int p, int ldp, int row0,
+                           int nrows_local, const double* d_er, const double* d_ecT, const double* d_Ep,
+                           const double* d_w, double eps, double* d_ybuf, double* d_ws, double* d_z);
+
 // Gram in sample space through the same tables (quantised luminance, nSelCols <= ghist_max_cols())
 int ghist_max_cols();
 size_t ghist_workspace_elems(GridSpec gs, int nrows_local);
 hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
                      const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_c, double* d_ws,
                      double* d_Gk);
+
+// projection through the tables (quantised luminance): V = diag(c) K D, one workgroup per image row
+bool project_hist_ok(GridSpec gs, int p, int K);
+hipError_t project_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
+                        const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_D, int ldd, int K,
+                        const double* d_c, float* d_V, int ldv);
 
 // Y[l][i] = sum_k V[i][k] * g[l][k]   (g: L x ld doubles, device)
 hipError_t apply_expand(hipStream_t s, const float* d_V, long long M, int ld, const double* d_g,

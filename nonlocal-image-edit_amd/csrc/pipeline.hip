@@ -900,11 +900,19 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     HIP_OK(hipMemcpyAsync(d_VA.p, ny.VA.data(), Bh.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemsetAsync(d_w.p, 0, P64 * sizeof(double), c->stream));
+    const bool hist_tiled = hist && ss.gs.nSelCols <= 11 && ss.gs.nSelRows <= 32 && std::getenv("NLE_HIST_UNTILED") == nullptr;
+    DevBuf<double> d_hws;
+    if (hist_tiled) d_hws.alloc(nlek::hist_tiled_workspace_elems(ss.gs, nrows_local));
     const int nrows = hist ? nrows_local : nlek::sink_pass_rows(std::max<long long>(M, 1));
     tr.mark("ss: alloc+upload");
     // pass n uses u = uh[n-1] (w = B u) and produces uh[n]; pass 0 is the column sum Phi^T 1 (:234,239)
     auto one_pass = [&](int n, int mode, double* ybuf) {
-        if (M > 0) {
+        if (M > 0 && hist_tiled) {
+            // tiled table pass: writes the local column sums straight into slice 0 of d_z
+            PROFILED(c, NLE_K_SINKHORN_PASS,
+                     nlek::sink_hist_tiled(c->stream, mode, d_lum, ss.gs, p, P64, row0, nrows_local, d_er.p, d_ecT.p,
+                                           d_Ep.p, d_w.p, NLE_EPS, ybuf, d_hws.p, d_z.p));
+        } else if (M > 0) {
             if (hist)
                 PROFILED(c, NLE_K_SINKHORN_PASS, nlek::sink_hist(c->stream, mode, d_lum, ss.gs, p, P64, row0, nrows_local,
                                                                  d_er.p, d_ecT.p, d_Ep.p, d_w.p, NLE_EPS, ybuf,
@@ -916,9 +924,10 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         } else {
             HIP_OK(hipMemsetAsync(d_z.p, 0, (size_t)kZS * P64 * sizeof(double), c->stream));
         }
-        all_reduce(c, d_z.p, (size_t)kZS * P64);
+        const int zrows = hist_tiled ? 1 : kZS;
+        all_reduce(c, d_z.p, (size_t)zrows * P64);
         PROFILED(c, NLE_K_SMALL,
-                 nlek::sink_update(c->stream, mode, p, r, d_B.p, d_VA.p, d_lam.p, d_z.p, kZS, P64,
+                 nlek::sink_update(c->stream, mode, p, r, d_B.p, d_VA.p, d_lam.p, d_z.p, zrows, P64,
                                    n > 0 ? d_uh.p + (size_t)(n - 1) * r : nullptr, NLE_EPS, d_uh.p + (size_t)n * r,
                                    d_w.p, P64));
     };
@@ -986,8 +995,14 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     DevBuf<double> d_D(Dp.size());
     HIP_OK(hipMemcpyAsync(d_D.p, Dp.data(), Dp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     DevBuf<float> d_V((size_t)std::max<long long>(M, 1) * f->ldv);
-    PROFILED(c, NLE_K_PROJECT, nlek::project64(c->stream, d_lum, ss.gs, d_samples.p, p, nsw, npw, pix0, M, d_D.p, o.K,
-                                               d_cbuf.p, d_V.p, f->ldv));
+    // the table form of the projection (k_project_hist) is correct but latency-bound (one workgroup per
+    // CU, 64 serial level batches): 20 ms vs 10 ms for the fp64-MFMA kernel at cfg4 -- opt-in only
+    if (hist && nlek::project_hist_ok(ss.gs, p, o.K) && std::getenv("NLE_PROJECT_HIST") != nullptr)
+        PROFILED(c, NLE_K_PROJECT, nlek::project_hist(c->stream, d_lum, ss.gs, p, row0, nrows_local, d_er.p, d_ecT.p,
+                                                      d_Ep.p, d_D.p, ldd, o.K, d_cbuf.p, d_V.p, f->ldv));
+    else
+        PROFILED(c, NLE_K_PROJECT, nlek::project64(c->stream, d_lum, ss.gs, d_samples.p, p, nsw, npw, pix0, M, d_D.p, o.K,
+                                                   d_cbuf.p, d_V.p, f->ldv));
     tr.mark("ss: project enqueued");
     scatter_sample_rows(c, ss, p, o.Vrows, p, o.K, f->ldv, pix0, M, d_V.p);
     tm_p.stop();
