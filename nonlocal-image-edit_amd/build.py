@@ -55,8 +55,11 @@ def build_lib(force: bool = False) -> str:
         for s in srcs:
             o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
             if force or _newer(o, deps):
-                _run([_hipcc(), "-x", "hip", "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC",
-                      "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
+                if s.endswith(".cpp"):  # host-only fp64 algebra: plain g++ (needs function multiversioning)
+                    _run(["g++", "-O3", "-fopenmp-simd", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
+                else:
+                    _run([_hipcc(), "-x", "hip", "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC",
+                          "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
             objs.append(o)
         _run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lpthread"])
     return LIB

@@ -20,9 +20,19 @@ namespace {
 
 inline double& at(double* v, int n, int row, int col) { return v[(size_t)col * n + row]; }
 
+// hypot without the libm call on the common path (no overflow/underflow of the squares)
+inline double hyp(double a, double b) {
+    const double s = a * a + b * b;
+    return (s > 1e-280 && s < 1e280) ? std::sqrt(s) : std::hypot(a, b);
+}
+
 // V: n x n col-major, in: symmetric matrix (lower triangle valid, mirrored by caller);
 // out: orthogonal Q with Q^T A Q tridiagonal (d diag, e[1..n-1] sub-diagonal).
-void tridiagonalize(int n, double* V, double* d, double* e) {
+// The O(n^3) loops below are unit-stride; the library is built without -march (it has to run on
+// whatever host the GPU box has), so they are multiversioned and resolved at load time.
+#define NLE_SIMD_CLONES __attribute__((target_clones("default", "avx2", "avx512f")))
+
+NLE_SIMD_CLONES void tridiagonalize(int n, double* V, double* d, double* e) {
     for (int j = 0; j < n; ++j) d[j] = at(V, n, n - 1, j);
     for (int i = n - 1; i > 0; --i) {
         double scale = 0.0, h = 0.0;
@@ -52,6 +62,7 @@ void tridiagonalize(int n, double* V, double* d, double* e) {
                 g = e[j] + at(V, n, j, j) * f;
                 const double* col = &at(V, n, 0, j);
                 double gs = 0.0;
+#pragma omp simd reduction(+ : gs)
                 for (int k = j + 1; k <= i - 1; ++k) {
                     gs += col[k] * d[k];
                     e[k] += col[k] * f;
@@ -69,6 +80,7 @@ void tridiagonalize(int n, double* V, double* d, double* e) {
                 f = d[j];
                 g = e[j];
                 double* col = &at(V, n, 0, j);
+#pragma omp simd
                 for (int k = j; k <= i - 1; ++k) col[k] -= (f * e[k] + g * d[k]);
                 d[j] = at(V, n, i - 1, j);
                 at(V, n, i, j) = 0.0;
@@ -87,7 +99,9 @@ void tridiagonalize(int n, double* V, double* d, double* e) {
             for (int j = 0; j <= i; ++j) {
                 double* cj = &at(V, n, 0, j);
                 double g = 0.0;
+#pragma omp simd reduction(+ : g)
                 for (int k = 0; k <= i; ++k) g += ci1[k] * cj[k];
+#pragma omp simd
                 for (int k = 0; k <= i; ++k) cj[k] -= g * d[k];
             }
         }
@@ -103,7 +117,7 @@ void tridiagonalize(int n, double* V, double* d, double* e) {
 
 // implicit QL on (d, e) accumulating rotations into V's columns; returns false if an
 // eigenvalue needs more than 60 sweeps.
-bool ql_implicit(int n, double* V, double* d, double* e) {
+NLE_SIMD_CLONES bool ql_implicit(int n, double* V, double* d, double* e) {
     for (int i = 1; i < n; ++i) e[i - 1] = e[i];
     e[n - 1] = 0.0;
     double f = 0.0, tst1 = 0.0;
@@ -121,7 +135,7 @@ bool ql_implicit(int n, double* V, double* d, double* e) {
                 if (++iter > 60) return false;
                 double g = d[l];
                 double p = (d[l + 1] - g) / (2.0 * e[l]);
-                double r = std::hypot(p, 1.0);
+                double r = hyp(p, 1.0);
                 if (p < 0) r = -r;
                 d[l] = e[l] / (p + r);
                 d[l + 1] = e[l] * (p + r);
@@ -139,7 +153,7 @@ bool ql_implicit(int n, double* V, double* d, double* e) {
                     s2 = s;
                     g = c * e[i];
                     h = c * p;
-                    r = std::hypot(p, e[i]);
+                    r = hyp(p, e[i]);
                     e[i + 1] = s * r;
                     s = e[i] / r;
                     c = p / r;
@@ -147,6 +161,7 @@ bool ql_implicit(int n, double* V, double* d, double* e) {
                     d[i + 1] = h + s * (c * g + s * d[i]);
                     double* vi = &at(V, n, 0, i);
                     double* vi1 = &at(V, n, 0, i + 1);
+#pragma omp simd
                     for (int k = 0; k < n; ++k) {
                         const double hk = vi1[k];
                         vi1[k] = s * vi[k] + c * hk;

@@ -15,6 +15,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace nlek {
 
@@ -517,6 +518,142 @@ __global__ __launch_bounds__(256) void k_project64(const float* __restrict__ lum
         }
 }
 
+__host__ __device__ constexpr int project64_res_ldb(int nt, int rem) {
+    // smallest row stride >= nt*16 + rem that is == 16 (mod 32) doubles (conflict-free ds_read_b64 of 4 rows)
+    int w = nt * 16 + rem;
+    int ld = (w + 15) / 16 * 16;
+    if (ld % 32 == 0) ld += 16;
+    return ld;
+}
+
+// Resident-D variant: the whole D (p x NT*16 fp64) and the sample table stay in LDS, workgroups are
+// persistent over 128-pixel tiles, so the MFMA loop runs without staging barriers.
+template <int NT, int NW, int REM>
+__global__ __launch_bounds__(NW * 64) void k_project64_res(const float* __restrict__ lum, GridSpec gs,
+                                                           const Sample4* __restrict__ samples, int p, float nsw,
+                                                           float npw, unsigned pix0, long long M,
+                                                           const double* __restrict__ Dm, int ldd,
+                                                           const double* __restrict__ cvec, float* __restrict__ V,
+                                                           int ldv) {
+    // LDS row: NT*16 MFMA columns [+ REM leftover columns handled on the VALU], stride == 16 (mod 32) doubles
+    constexpr int LDB = project64_res_ldb(NT, REM);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int p4 = (p + 3) & ~3;
+    double* sB = reinterpret_cast<double*>(smem_raw);                 // [p4][LDB]
+    Sample4* sS = reinterpret_cast<Sample4*>(sB + (size_t)p4 * LDB);  // [p4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    constexpr int NCOL = NT * 16 + REM;
+    for (int idx = tid; idx < p4 * NCOL; idx += NW * 64) {
+        const int kk = idx / NCOL, cc = idx - kk * NCOL;
+        sB[(size_t)kk * LDB + cc] = (kk < p && cc < ldd) ? Dm[(size_t)kk * ldd + cc] : 0.0;
+    }
+    for (int k = tid; k < p4; k += NW * 64) sS[k] = (k < p) ? samples[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const long long ntiles = (M + NW * 32 - 1) / (NW * 32);
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long m0 = tile * (NW * 32) + wave * 32;
+        float pr[2], pc[2], px[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            long long li = m0 + mt * 16 + l15;
+            if (li >= M) li = M - 1;
+            const unsigned gi = pix0 + (unsigned)li;
+            const unsigned row = gi / (unsigned)gs.W;
+            pr[mt] = (float)row;
+            pc[mt] = (float)(gi - row * (unsigned)gs.W);
+            px[mt] = lum[gi];
+        }
+        f64x4 acc[2][NT];
+        double rem0[REM > 0 ? REM : 1], rem1[REM > 0 ? REM : 1];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[mt][n] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < (REM > 0 ? REM : 1); ++q) rem0[q] = rem1[q] = 0.0;
+        // software pipeline: the affinities of step k+1 are generated while the MFMAs of step k run
+        Sample4 sm = sS[kq];
+        double a0 = (double)affinity_value(pr[0], pc[0], px[0], sm, nsw, npw);
+        double a1 = (double)affinity_value(pr[1], pc[1], px[1], sm, nsw, npw);
+        for (int kk = 0; kk < p4; kk += 4) {
+            const double* brow = sB + (size_t)(kk + kq) * LDB;
+            double bv[NT], br[REM > 0 ? REM : 1];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bv[n] = brow[n * 16 + l15];
+#pragma unroll
+            for (int q = 0; q < REM; ++q) br[q] = brow[NT * 16 + q];
+            const int kn = (kk + 4 < p4) ? kk + 4 : kk;
+            const Sample4 sn = sS[kn + kq];
+            const double c0 = a0, c1 = a1;
+            a0 = (double)affinity_value(pr[0], pc[0], px[0], sn, nsw, npw);
+            a1 = (double)affinity_value(pr[1], pc[1], px[1], sn, nsw, npw);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                acc[0][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, bv[n], acc[0][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, bv[n], acc[1][n], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < REM; ++q) {  // leftover columns: this lane's (pixel l15, sample kk+kq) term
+                rem0[q] += c0 * br[q];
+                rem1[q] += c1 * br[q];
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long long li = m0 + mt * 16 + kq + 4 * e;
+                if (li < M) {
+                    const double cf = cvec[li];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int col = n * 16 + l15;
+                        if (col < ldv) V[(size_t)li * ldv + col] = (float)(cf * acc[mt][n][e]);
+                    }
+                }
+            }
+        if constexpr (REM > 0) {
+#pragma unroll
+            for (int q = 0; q < REM; ++q) {  // sum the 4 sample quarters (lanes l15 + 16 kq)
+                rem0[q] += __shfl_xor(rem0[q], 16);
+                rem0[q] += __shfl_xor(rem0[q], 32);
+                rem1[q] += __shfl_xor(rem1[q], 16);
+                rem1[q] += __shfl_xor(rem1[q], 32);
+            }
+            if (kq == 0) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const long long li = m0 + mt * 16 + l15;
+                    if (li < M) {
+                        const double cf = cvec[li];
+#pragma unroll
+                        for (int q = 0; q < REM; ++q) {
+                            const int col = NT * 16 + q;
+                            if (col < ldv) V[(size_t)li * ldv + col] = (float)(cf * (mt == 0 ? rem0[q] : rem1[q]));
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NT, int NW, int REM>
+static hipError_t launch_project64_res(hipStream_t s, long long M, const float* d_lum, GridSpec gs,
+                                       const Sample4* d_samples, int p, float nsw, float npw, long long pix0,
+                                       const double* d_D, int ldd, const double* d_c, float* d_V, int ldv) {
+    const int p4 = (p + 3) & ~3;
+    const size_t shm = (size_t)p4 * project64_res_ldb(NT, REM) * sizeof(double) + (size_t)p4 * sizeof(Sample4);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_project64_res<NT, NW, REM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    const long long ntiles = (M + NW * 32 - 1) / (NW * 32);
+    const unsigned grid = (unsigned)std::min<long long>(ntiles, 256);
+    hipLaunchKernelGGL((k_project64_res<NT, NW, REM>), dim3(grid), dim3(NW * 64), shm, s, d_lum, gs, d_samples, p, nsw,
+                       npw, (unsigned)pix0, M, d_D, ldd, d_c, d_V, ldv);
+    return hipGetLastError();
+}
+
 int project64_ld(int K) { return (K + 15) & ~15; }
 
 hipError_t project64(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples, int p, float nsw,
@@ -525,6 +662,26 @@ hipError_t project64(hipStream_t s, const float* d_lum, GridSpec gs, const Sampl
     if (M <= 0) return hipSuccess;
     const int ldd = project64_ld(K);
     const int nt = ldd / 16;
+    {   // D resident in LDS when it fits (one persistent 16-wave workgroup per CU); up to 4 leftover
+        // columns beyond a multiple of 16 are done on the VALU instead of paying a whole MFMA tile
+        int nt_r = K / 16, rem = K % 16;
+        if (rem > 4 || nt_r == 0) {
+            nt_r = (K + 15) / 16;
+            rem = 0;
+        }
+        const int p4 = (p + 3) & ~3;
+        const size_t shm = (size_t)p4 * project64_res_ldb(nt_r, rem) * sizeof(double) + (size_t)p4 * sizeof(Sample4);
+        if (nt_r <= 4 && shm <= 150 * 1024 && std::getenv("NLE_PROJECT_CHUNKED") == nullptr) {
+#define NLE_PR(NTV, REMV) \
+    if (nt_r == NTV && rem == REMV) \
+        return launch_project64_res<NTV, 16, REMV>(s, M, d_lum, gs, d_samples, p, nsw, npw, pix0, d_D, ldd, d_c, d_V, ldv);
+            NLE_PR(1, 0) NLE_PR(1, 1) NLE_PR(1, 2) NLE_PR(1, 3) NLE_PR(1, 4)
+            NLE_PR(2, 0) NLE_PR(2, 1) NLE_PR(2, 2) NLE_PR(2, 3) NLE_PR(2, 4)
+            NLE_PR(3, 0) NLE_PR(3, 1) NLE_PR(3, 2) NLE_PR(3, 3) NLE_PR(3, 4)
+            NLE_PR(4, 0) NLE_PR(4, 1) NLE_PR(4, 2) NLE_PR(4, 3) NLE_PR(4, 4)
+#undef NLE_PR
+        }
+    }
     const dim3 grid((unsigned)((M + 127) / 128)), block(256);
 #define NLE_PJ_CASE(NTV)                                                                                   \
     case NTV:                                                                                              \
