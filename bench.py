@@ -40,32 +40,69 @@ FP32_PEAK_TF = 157.3        # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vecto
 FP64_MFMA_PEAK_TF = 78.6    # MI355X FP64 matrix peak (spec; SURVEY.md section 8d quotes ~79 TFLOP/s fp64)
 
 
-def roofline_models(info, L, phi_free):
-    """kernel name -> (bound, algorithmic units per launch, peak) from SURVEY.md section 8(d) (fp32 storage,
-    s = 4 B), per rank (n = pixels of this rank's slab).
+def roofline_models(info, L, form, grid):
+    """kernel name -> (bound, algorithmic units per launch, peak) for this rank (n = pixels of its slab).
 
-    Phi-free mode: the Sinkhorn pass regenerates the affinities (section 8d: ~8 flop + 1 exp per element) and does
-    the 4 flop per element of the pass itself; it moves ~12 B/pixel and uses no MFMA, so its roof is the
-    fp32 vector pipe ("valu", same 157.3 TFLOP/s figure as the fp32 MFMA).  `hbm_equivalent` is what the
-    canonical streaming form (B_C/(2T) = n*r*4 bytes per pass) would have needed.  Gram and projection run
-    on the fp64 MFMA there."""
+    Per-unit figures are SURVEY.md section 8(d)'s (fp32 storage, s = 4 B) where the kernel still does the
+    work that formula describes.  `form`:
+      materialised     Phi streamed: Sinkhorn B_C/(2T) = n r s bytes per pass (HBM), GEMMs on the fp32 MFMA
+      phi_free_exp     affinities regenerated: Sinkhorn pass = n p (8 flop + 1 exp + 4 flop) on the fp32 vector
+                       pipe ("valu", 157.3 TFLOP/s, the same figure as the fp32 MFMA), Gram/projection on
+                       the fp64 MFMA with r -> p
+      phi_free_tables  quantised luminance: the Sinkhorn and Gram passes are table look-ups whose own
+                       traffic/flops are listed (they are LDS-atomic / latency bound, far from either roof);
+                       the projection is the fp64-MFMA Nystrom-extension GEMM F_E = 2 n p K."""
     n, r, p, K = info["n_local"], info["r"], info["p"], info["K"]
+    nC, nR = grid["n_sel_cols"], grid["n_sel_rows"]
+    rows = info["row1"] - info["row0"]
     s = 4.0
     m = {
         "affinity": ("hbm", n * s * (1 + p), HBM_PEAK_GBS),              # B_A = N s (1 + p)
         "apply_reduce": ("hbm", n * s * (K + 1), HBM_PEAK_GBS),          # B_F, first pass: V and x
         "apply_expand": ("hbm", n * s * (K + L), HBM_PEAK_GBS),          # B_F, second pass: V in, L planes out
     }
-    if phi_free:
-        m["sinkhorn_pass"] = ("valu", n * p * (8.0 + 1.0 + 4.0), FP32_PEAK_TF)
-        m["gram"] = ("mfma", 2.0 * n * p * p, FP64_MFMA_PEAK_TF)         # F_D with r -> p (sample space)
-        m["project"] = ("mfma", 2.0 * n * p * K, FP64_MFMA_PEAK_TF)      # F_E with r -> p
-    else:
+    if form == "materialised":
         m["nystrom_extend"] = ("mfma", 2.0 * n * p * r, FP32_PEAK_TF)    # F_B = 2 N p r
         m["sinkhorn_pass"] = ("hbm", n * r * s, HBM_PEAK_GBS)            # B_C / (2T)
         m["gram"] = ("mfma", 2.0 * n * r * r, FP32_PEAK_TF)              # F_D = 2 N r^2
         m["project"] = ("mfma", 2.0 * n * r * K, FP32_PEAK_TF)           # F_E = 2 N r K
+    else:
+        m["project"] = ("mfma", 2.0 * n * p * K, FP64_MFMA_PEAK_TF)      # F_E with r -> p, fp64 MFMA
+        if form == "phi_free_exp":
+            m["sinkhorn_pass"] = ("valu", n * p * (8.0 + 1.0 + 4.0), FP32_PEAK_TF)
+            m["gram"] = ("mfma", 2.0 * n * p * p, FP64_MFMA_PEAK_TF)     # F_D with r -> p
+        else:
+            tab = rows * 256.0 * nC * 8.0                                # one 256 x nC fp64 table per image row
+            npair = nC * (nC + 1) / 2.0
+            ldm = ((nR * (nR + 1) // 2) + 15) // 16 * 16
+            m["sink_tables"] = ("hbm", tab, HBM_PEAK_GBS)                # g written
+            m["sinkhorn_pass"] = ("hbm", n * s + 2.0 * tab, HBM_PEAK_GBS)  # luminance + g in + h out
+            m["gram_rows"] = ("hbm", n * (s + 8.0) + rows * 256.0 * npair * 8.0, HBM_PEAK_GBS)
+            m["gram_gemm"] = ("mfma", 2.0 * ldm * 256.0 * npair * rows, FP64_MFMA_PEAK_TF)
     return m
+
+
+def load_traffic():
+    """HBM bytes per launch from the committed PMC summary (tools/prof.sh + tools/pmc_summary.py):
+    {kernel-name substring: bytes}; rocprofv3 cannot run inside bench.py."""
+    import csv
+    import glob
+    out = {}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
+    if not files:
+        return out
+    for row in csv.DictReader(open(files[-1])):
+        out[row["kernel"]] = float(row["hbm_bytes_per_launch"])
+    return out
+
+
+KERNEL_SYMBOLS = {  # bench kernel name -> substring of the HIP kernel symbol (for the PMC table)
+    "project": ("k_project64_res", "k_project64", "k_tsgemm<2, false>"),
+    "sinkhorn_pass": ("k_hist_pix", "k_sink_pass", "k_rowpass<8"),
+    "gram_gemm": ("k_ghist_gemm",), "gram_rows": ("k_ghist_rows",), "sink_tables": ("k_hist_g",),
+    "gram": ("k_gram64", "k_gram("), "nystrom_extend": ("k_tsgemm<7, true>",),
+    "apply_expand": ("k_apply_expand",), "apply_reduce": ("k_rowpass<4",),
+}
 
 
 def main():
@@ -146,8 +183,10 @@ def main():
     value = (H * W / 1e6) / (elapsed / args.steps)
 
     # ---- roofline of the dominant kernel (this rank's launches)
-    phi_free = "nystrom_extend" not in {k for k, v in stats.items() if v[0] > 0}
-    models = roofline_models(info, L, phi_free)
+    ran = {k for k, v in stats.items() if v[0] > 0}
+    form = "materialised" if "nystrom_extend" in ran else ("phi_free_tables" if "sink_tables" in ran else "phi_free_exp")
+    models = roofline_models(info, L, form, g)
+    traffic = load_traffic()
     per_kernel = {}
     for name, (launches, total_ms) in stats.items():
         if launches == 0:
@@ -161,16 +200,20 @@ def main():
             else:
                 ach, unit = units / (avg_ms * 1e-3) / 1e12, "TFLOP/s"
             rec.update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
-            if name == "sinkhorn_pass" and phi_free:
+            if name == "sinkhorn_pass" and form != "materialised":
                 rec["hbm_equivalent_GBs"] = info["n_local"] * info["r"] * 4.0 / (avg_ms * 1e-3) / 1e9
+            rec["traffic"] = None
+            for sym in KERNEL_SYMBOLS.get(name, ()):
+                hit = [v for k, v in traffic.items() if sym in k]
+                if hit:
+                    rec["traffic"] = hit[0]
+                    break
         per_kernel[name] = rec
     dom = max((k for k in per_kernel if "bound" in per_kernel[k]), key=lambda k: per_kernel[k]["total_ms_per_step"])
     d = per_kernel[dom]
     roofline = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                "frac": d["frac"], "traffic": None, "avg_launch_ms": d["avg_ms"],
+                "frac": d["frac"], "traffic": d.get("traffic"), "avg_launch_ms": d["avg_ms"],
                 "launches_per_step": d["launches_per_step"]}
-    if "hbm_equivalent_GBs" in d:
-        roofline["hbm_equivalent_GBs"] = d["hbm_equivalent_GBs"]
 
     # ---- CPU baseline: the fp64 numpy oracle on a bounded sample (rank 0, N = 1 only)
     cpu = None
@@ -199,11 +242,12 @@ def main():
             "metric": "megapixels/sec end-to-end enhance (4K img, m=200, K=50)",
             "value": value, "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {H}x{W} synthetic luminance, {cfg['n_row']}x{cfg['n_col']} samples "
                                    f"(p={p}), K={cfg['K']}, T={cfg['T']}, L={L} layers; input resident in HBM",
                        "parallelism": f"row-slab x{world}" if world > 1 else "single GPU",
-                       "formulation": "phi_free" if phi_free else "materialised_phi"},
+                       "formulation": form,
+                       "storage": "fp64 tables, reductions and MFMA; fp32 affinities in the projection; V and outputs fp32"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": per_kernel,

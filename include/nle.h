@@ -197,7 +197,10 @@ enum {
     NLE_K_APPLY_REDUCE = 6,  /* t = V^T x                                                */
     NLE_K_APPLY_EXPAND = 7,  /* y_l = V (g_l o t)                                        */
     NLE_K_SMALL = 8,         /* everything p/r/K-sized on the device                     */
-    NLE_KERNEL_COUNT = 9
+    NLE_K_SINK_TABLES = 9,   /* table pass: per-row g tables (k_hist_g)                  */
+    NLE_K_GRAM_ROWS = 10,    /* table Gram: per-row histograms (k_ghist_rows)            */
+    NLE_K_GRAM_GEMM = 11,    /* table Gram: fp64 MFMA GEMM (k_ghist_gemm)                */
+    NLE_KERNEL_COUNT = 12
 };
 const char* nle_kernel_name(int kid);
 /* enable != 0: bracket every kernel launch of the ctx with HIP events recorded on the ctx's

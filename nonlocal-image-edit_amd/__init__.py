@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libnle_hip.so")
 
 NLE_OK, NLE_ERR_INVALID, NLE_ERR_HIP, NLE_ERR_NUMERIC, NLE_ERR_COMM = 0, 1, 2, 3, 4
 EPS = 1e-10
-KERNEL_COUNT = 9  # NLE_KERNEL_COUNT
+KERNEL_COUNT = 12  # NLE_KERNEL_COUNT
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 

@@ -1011,28 +1011,39 @@ __global__ __launch_bounds__(256) void k_hist_z(int p, int ldp, int nC, int nR, 
 int hist_tiled_max_rows_samples() { return 32; }
 size_t hist_tiled_workspace_elems(GridSpec gs, int nrows_local) {
     const size_t n = (size_t)kLevels * gs.nSelCols;
-    const int nslabs = (nrows_local + 31) / 32;
+    const int nslabs = (nrows_local + 63) / 64;
     return 2 * (size_t)nrows_local * n + (size_t)nslabs * n * gs.nSelRows;
 }
 
 // one Sinkhorn half-iteration, tiled form; d_ws: hist_tiled_workspace_elems doubles; d_z: ldp doubles
 hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec gs, int p, int ldp, int row0,
                            int nrows_local, const double* d_er, const double* d_ecT, const double* d_Ep,
-                           const double* d_w, double eps, double* d_ybuf, double* d_ws, double* d_z) {
+                           const double* d_w, double eps, double* d_ybuf, double* d_ws, double* d_z,
+                           LaunchObserver* obs) {
     const int nC = gs.nSelCols, nR = gs.nSelRows;
     if (nC > 11 || nR > 32) return hipErrorInvalidValue;
+    struct Scope {
+        LaunchObserver* o;
+        Scope(LaunchObserver* ob, int sub) : o(ob) { if (o) o->begin(sub); }
+        ~Scope() { if (o) o->end(); }
+    };
     const size_t n = (size_t)kLevels * nC;
-    const int slab_rows = 32, nslabs = (nrows_local + slab_rows - 1) / slab_rows;
+    const int slab_rows = 64, nslabs = (nrows_local + slab_rows - 1) / slab_rows;
     double* d_g = d_ws;
     double* d_h = d_g + (size_t)nrows_local * n;
     double* d_HH = d_h + (size_t)nrows_local * n;
     if (mode != ROWPASS_COLSUM) {
+        Scope sc(obs, SUB_HIST_G);
         const size_t shm_g = ((size_t)8 * p + (size_t)32 * nR) * sizeof(double);
         hipLaunchKernelGGL(k_hist_g, dim3((unsigned)((nrows_local + 31) / 32), kLevels / 8), dim3(256), shm_g, s, gs, p,
                            nrows_local, d_er, d_Ep, d_w, d_g);
     }
-    hipLaunchKernelGGL(k_hist_pix, dim3((unsigned)nrows_local), dim3(256), 2 * n * sizeof(double), s, mode, d_lum, gs,
-                       row0, d_ecT, d_g, eps, d_ybuf, d_h);
+    {
+        Scope sc(obs, SUB_HIST_PIX);
+        hipLaunchKernelGGL(k_hist_pix, dim3((unsigned)nrows_local), dim3(256), 2 * n * sizeof(double), s, mode, d_lum,
+                           gs, row0, d_ecT, d_g, eps, d_ybuf, d_h);
+    }
+    Scope sc(obs, SUB_HIST_HH);
     hipLaunchKernelGGL(k_hist_hh, dim3((unsigned)((n + 255) / 256), (unsigned)nslabs), dim3(256), 0, s, nC, nR,
                        nrows_local, slab_rows, d_er, d_h, d_HH);
     hipLaunchKernelGGL(k_hist_z, dim3((unsigned)ldp), dim3(kLevels), 0, s, p, ldp, nC, nR, nslabs, d_Ep, d_HH, d_z);
@@ -1168,7 +1179,7 @@ size_t ghist_workspace_elems(GridSpec gs, int nrows_local) {
 // d_ws: ghist_workspace_elems doubles; d_Gk: p x p doubles (full symmetric matrix of this rank's rows)
 hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
                      const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_c, double* d_ws,
-                     double* d_Gk) {
+                     double* d_Gk, LaunchObserver* obs) {
     const int nC = gs.nSelCols, nR = gs.nSelRows;
     if (nC > ghist_max_cols()) return hipErrorInvalidValue;
     const int NP = nC * (nC + 1) / 2;
@@ -1181,13 +1192,18 @@ hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ghist_rows),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
+    if (obs) obs->begin(SUB_GHIST_ROWS);
     hipLaunchKernelGGL(k_ghist_rows, dim3((unsigned)nrows_local), dim3(256), shm, s, d_lum, gs, row0, d_ecT, d_c, d_A);
+    if (obs) obs->end(), obs->begin(SUB_GHIST_EE);
     hipLaunchKernelGGL(k_ghist_ee, dim3(512), dim3(256), 0, s, d_er, nrows_local, nR, ldm, d_EE);
     constexpr int MT = 14;
     const dim3 grid((unsigned)((N / 16 + 3) / 4), (unsigned)((ldm / 16 + MT - 1) / MT));
+    if (obs) obs->end(), obs->begin(SUB_GHIST_GEMM);
     hipLaunchKernelGGL((k_ghist_gemm<MT>), grid, dim3(256), 0, s, d_EE, ldm, d_A, N, nrows_local, d_C);
+    if (obs) obs->end(), obs->begin(SUB_GHIST_FINAL);
     hipLaunchKernelGGL(k_ghist_final, dim3((unsigned)(((long long)p * p + 255) / 256)), dim3(256), 0, s, d_C, N, d_Ep, p,
                        nR, nC, d_Gk);
+    if (obs) obs->end();
     return hipGetLastError();
 }
 

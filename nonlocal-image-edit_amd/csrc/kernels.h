@@ -32,6 +32,15 @@ __device__ __forceinline__ bool is_sample_pixel(const GridSpec& gs, int row, int
 }
 #endif
 
+// composite launchers report each kernel they enqueue so that the caller can time them separately
+struct LaunchObserver {
+    virtual void begin(int sub) = 0;  // sub: index of the kernel inside the composite
+    virtual void end() = 0;
+    virtual ~LaunchObserver() = default;
+};
+enum { SUB_HIST_G = 0, SUB_HIST_PIX = 1, SUB_HIST_HH = 2, SUB_HIST_Z = 3 };
+enum { SUB_GHIST_ROWS = 0, SUB_GHIST_EE = 1, SUB_GHIST_GEMM = 2, SUB_GHIST_FINAL = 3 };
+
 constexpr int kRowpassMaxBlocks = 1024;
 constexpr int kGramTilesPerWave = 7;
 constexpr int kGramRowsPerStage = 32;
@@ -124,14 +133,15 @@ hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, i
 size_t hist_tiled_workspace_elems(GridSpec gs, int nrows_local);
 hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec gs, int p, int ldp, int row0,
                            int nrows_local, const double* d_er, const double* d_ecT, const double* d_Ep,
-                           const double* d_w, double eps, double* d_ybuf, double* d_ws, double* d_z);
+                           const double* d_w, double eps, double* d_ybuf, double* d_ws, double* d_z,
+                           LaunchObserver* obs = nullptr);
 
 // Gram in sample space through the same tables (quantised luminance, nSelCols <= ghist_max_cols())
 int ghist_max_cols();
 size_t ghist_workspace_elems(GridSpec gs, int nrows_local);
 hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
                      const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_c, double* d_ws,
-                     double* d_Gk);
+                     double* d_Gk, LaunchObserver* obs = nullptr);
 
 // projection through the tables (quantised luminance): V = diag(c) K D, one workgroup per image row
 bool project_hist_ok(GridSpec gs, int p, int K);

@@ -215,6 +215,23 @@ struct Prof {
         pf_.end();                  \
     } while (0)
 
+// times the kernels of a composite launcher separately (kernels.h: LaunchObserver)
+struct ProfObserver : nlek::LaunchObserver {
+    nle_ctx* c;
+    const int* map;
+    Prof* cur = nullptr;
+    ProfObserver(nle_ctx* c_, const int* map_) : c(c_), map(map_) {}
+    void begin(int sub) override { cur = new Prof(c, map[sub]); }
+    void end() override {
+        if (cur) {
+            cur->end();
+            delete cur;
+            cur = nullptr;
+        }
+    }
+    ~ProfObserver() override { end(); }
+};
+
 // resolve pending records; the caller has synchronised the stream
 void prof_flush(nle_ctx* c) {
     for (auto& r : c->prof_pending) {
@@ -909,9 +926,10 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     auto one_pass = [&](int n, int mode, double* ybuf) {
         if (M > 0 && hist_tiled) {
             // tiled table pass: writes the local column sums straight into slice 0 of d_z
-            PROFILED(c, NLE_K_SINKHORN_PASS,
-                     nlek::sink_hist_tiled(c->stream, mode, d_lum, ss.gs, p, P64, row0, nrows_local, d_er.p, d_ecT.p,
-                                           d_Ep.p, d_w.p, NLE_EPS, ybuf, d_hws.p, d_z.p));
+            static const int kmap[4] = {NLE_K_SINK_TABLES, NLE_K_SINKHORN_PASS, NLE_K_REDUCE, NLE_K_REDUCE};
+            ProfObserver obs(c, kmap);
+            HIP_OK(nlek::sink_hist_tiled(c->stream, mode, d_lum, ss.gs, p, P64, row0, nrows_local, d_er.p, d_ecT.p,
+                                         d_Ep.p, d_w.p, NLE_EPS, ybuf, d_hws.p, d_z.p, &obs));
         } else if (M > 0) {
             if (hist)
                 PROFILED(c, NLE_K_SINKHORN_PASS, nlek::sink_hist(c->stream, mode, d_lum, ss.gs, p, P64, row0, nrows_local,
@@ -956,8 +974,10 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         HIP_OK(hipMemsetAsync(d_tiles.p, 0, g_elems * sizeof(double), c->stream));
     } else if (ghist) {
         d_gpart.alloc(nlek::ghist_workspace_elems(ss.gs, nrows_local));
-        PROFILED(c, NLE_K_GRAM, nlek::gram_hist(c->stream, d_lum, ss.gs, p, row0, nrows_local, d_er.p, d_ecT.p, d_Ep.p,
-                                                d_cbuf.p, d_gpart.p, d_tiles.p));
+        static const int gmap[4] = {NLE_K_GRAM_ROWS, NLE_K_SMALL, NLE_K_GRAM_GEMM, NLE_K_SMALL};
+        ProfObserver obs(c, gmap);
+        HIP_OK(nlek::gram_hist(c->stream, d_lum, ss.gs, p, row0, nrows_local, d_er.p, d_ecT.p, d_Ep.p, d_cbuf.p,
+                               d_gpart.p, d_tiles.p, &obs));
     } else {
         d_gpart.alloc(std::max<size_t>(nlek::gram64_partial_elems(M, p), 1));
         PROFILED(c, NLE_K_GRAM, nlek::gram64(c->stream, d_lum, ss.gs, d_samples.p, p, nsw, npw, pix0, M, d_cbuf.p,
@@ -1520,7 +1540,8 @@ int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, 
 
 static const char* const kKernelNames[NLE_KERNEL_COUNT] = {
     "affinity", "nystrom_extend", "sinkhorn_pass", "reduce_partials", "gram",
-    "project",  "apply_reduce",   "apply_expand",  "small"};
+    "project",  "apply_reduce",   "apply_expand",  "small",           "sink_tables", "gram_rows",
+    "gram_gemm"};
 
 const char* nle_kernel_name(int kid) { return (kid >= 0 && kid < NLE_KERNEL_COUNT) ? kKernelNames[kid] : ""; }
 
