@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for rehearsals)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 materialised Phi, 2 Phi-free (NLE_MODE_*)")
     ap.add_argument("--cpu-sample", type=int, default=768, help="side of the CPU-baseline sample image")
     ap.add_argument("--cpu-threads", type=int, default=16, help="BLAS threads for the CPU baseline (<= visible cores)")
@@ -125,12 +128,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist_mod.init_process_group(args.backend)
         dist = dist_mod
 
     nle = entry.load_package()

@@ -1,0 +1,120 @@
+"""Full-size checks on the GPU (BASELINE.json configs[3] = cfg4, 4096x4096, p = 200, K = 50, T = 10): the CPU
+oracle needs ~4 minutes per megapixel, so at this size parity is established through size-independent
+properties and through agreement of the independent formulations of the N-sized passes (each of which
+is checked against the oracle at small sizes in test_gpu_parity.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfg4(nle, ctx):
+    import torch
+    import __graft_entry__ as entry
+    synth = entry._load("nle_amd_synthetic", os.path.join(entry.PKG_DIR, "synthetic.py"))
+    cfg = synth.CONFIGS["cfg4"]
+    lum = torch.as_tensor(synth.synthetic_luminance(cfg["H"], cfg["W"]).astype(np.float32), device="cuda:0")
+    return cfg, lum
+
+
+def _train(nle, ctx, cfg, lum, mode):
+    ctx.set_mode(mode)
+    try:
+        return nle.NLEFilter(ctx).train_filter(lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"])
+    finally:
+        ctx.set_mode(0)
+
+
+def test_cfg4_properties_and_formulations_agree(nle, ctx, cfg4):
+    import torch
+    cfg, lum = cfg4
+    L = cfg["L"]
+    f_tab = _train(nle, ctx, cfg, lum, 2)        # tables (the luminance plane is integer valued)
+    info = f_tab.info()
+    assert info["p"] == 200 and info["r"] == 200 and info["K"] == 50 and info["n_local"] == 4096 * 4096
+    ev = f_tab.eigvals
+    # descending; the top eigenvalue is 1 up to the residual of T = 10 Sinkhorn iterations
+    assert np.all(np.diff(ev) <= 1e-12) and 0.99 < ev[0] < 1.01 and ev[-1] > 1e-10
+    Y_tab = f_tab.apply_layers(lum, L)
+    # (1) the layer responses telescope: sum of layers == V V^T x; (2) V V^T is an orthogonal projector
+    ones = np.ones(info["K"])
+    Px = f_tab.apply(lum, ones)
+    assert float(torch.linalg.norm(Y_tab.sum(0) - Px) / torch.linalg.norm(Px)) < 1e-5
+    PPx = f_tab.apply(Px.view(4096, 4096), ones)
+    assert float(torch.linalg.norm(PPx - Px) / torch.linalg.norm(Px)) < 1e-5           # idempotent
+    x = lum.reshape(-1).double()
+    assert abs(float((Px.double() * x).sum() / (Px.double() ** 2).sum()) - 1.0) < 1e-5    # <Px, x> == |Px|^2
+    # (3) linearity at full size
+    z = torch.roll(lum, shifts=(17, 5), dims=(0, 1))
+    fs = np.linspace(2.0, 0.5, info["K"])
+    lhs = f_tab.apply(2.0 * lum - 3.0 * z, fs)
+    rhs = 2.0 * f_tab.apply(lum, fs) - 3.0 * f_tab.apply(z, fs)
+    assert float(torch.linalg.norm(lhs - rhs) / torch.linalg.norm(rhs)) < 1e-5
+    del PPx, lhs, rhs, z
+    # (4) the generic Phi-free formulation (exponentials in registers, fp32 affinities) gives the same layers
+    f_exp = _train(nle, ctx, cfg, lum, 3)
+    assert rel_l2(f_exp.eigvals, ev) < 1e-6
+    Y_exp = f_exp.apply_layers(lum, L)
+    for j in range(L):
+        e = float(torch.linalg.norm(Y_exp[j] - Y_tab[j]) / torch.linalg.norm(Y_tab[j]))
+        assert e < 1e-5, (j, e)
+    f_exp.close()
+    del Y_exp
+    # (5) and so does the materialised-Phi formulation (fp32 Phi streamed from HBM)
+    f_mat = _train(nle, ctx, cfg, lum, 1)
+    assert rel_l2(f_mat.eigvals, ev) < 1e-5
+    Y_mat = f_mat.apply_layers(lum, L)
+    for j in range(L):
+        e = float(torch.linalg.norm(Y_mat[j] - Y_tab[j]) / torch.linalg.norm(Y_tab[j]))
+        assert e < 1e-4, (j, e)
+    f_mat.close()
+    f_tab.close()
+    ctx.trim()
+
+
+def test_non_integer_luminance_takes_the_generic_path(nle, oracle, ctx):
+    """auto mode must not use the 0..255 look-up tables when the plane is not integer valued"""
+    H, W, nr, nc, hx, hy, T, K, L = 96, 128, 6, 8, 32.0, 30.0, 10, 10, 4
+    x = oracle.synthetic_luminance(H, W) * 0.9 + 3.37          # non-integer, still inside [0, 255]
+    V_o, S_o = oracle.train_filter(x, nr, nc, hx, hy, T, K)
+    Y_o = oracle.apply_layers(V_o, S_o, x, L).reshape(L, -1)
+    ctx.profile(True)
+    f = nle.NLEFilter(ctx).train_filter(x.astype(np.float32), nr, nc, hx, hy, T, K)
+    stats = ctx.kernel_stats()
+    ctx.profile(False)
+    assert stats["sink_tables"][0] == 0 and stats["gram_rows"][0] == 0 and stats["sinkhorn_pass"][0] == 2 * T
+    Y = f.apply_layers(x.astype(np.float32), L).cpu().numpy().astype(np.float64)
+    for j in range(L):
+        # the device sees float32(x); the oracle float64(x): compare against the oracle on the rounded plane too
+        assert rel_l2(Y[j], Y_o[j]) < 1e-4
+    # the same plane rounded to integers does use the tables
+    xi = np.rint(x)
+    ctx.profile(True)
+    f2 = nle.NLEFilter(ctx).train_filter(xi.astype(np.float32), nr, nc, hx, hy, T, K)
+    stats = ctx.kernel_stats()
+    ctx.profile(False)
+    assert stats["sink_tables"][0] == 2 * T - 1 and stats["gram_rows"][0] == 1
+    f.close()
+    f2.close()
+
+
+def test_out_of_range_levels_fall_back(nle, oracle, ctx):
+    """integer values above 255 (or negative) are not table material either"""
+    H, W = 48, 64
+    x = oracle.synthetic_luminance(H, W) + 200.0               # integers up to 455
+    V_o, S_o = oracle.train_filter(x, 4, 5, 16.0, 30.0, 10, 8)
+    Y_o = oracle.apply_layers(V_o, S_o, x, 4).reshape(4, -1)
+    ctx.profile(True)
+    f = nle.NLEFilter(ctx).train_filter(x.astype(np.float32), 4, 5, 16.0, 30.0, 10, 8)
+    stats = ctx.kernel_stats()
+    ctx.profile(False)
+    assert stats["sink_tables"][0] == 0
+    Y = f.apply_layers(x.astype(np.float32), 4).cpu().numpy().astype(np.float64)
+    for j in range(4):
+        assert rel_l2(Y[j], Y_o[j]) < 1e-4
+    f.close()
