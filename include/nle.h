@@ -44,8 +44,10 @@ typedef struct nle_ctx nle_ctx;
 typedef struct nle_filter nle_filter;
 
 /* ---- context ------------------------------------------------------------------- */
-/* `stream` is a hipStream_t to run on (e.g. torch.cuda.current_stream().cuda_stream),
- * or NULL to let the ctx create and own one. */
+/* `stream` is a hipStream_t to run on, or NULL to let the ctx create and own a non-blocking
+ * stream.  NB: the handle of HIP's legacy default stream IS NULL, so it cannot be passed; a host
+ * that wants its own collectives ordered with the ctx's kernels (torch.distributed) creates a
+ * stream, hands its handle over and issues the collectives on it (the Python mirror does). */
 int nle_ctx_create(int device, void* stream, nle_ctx** out);
 void nle_ctx_destroy(nle_ctx* ctx);
 const char* nle_last_error(const nle_ctx* ctx); /* ctx may be NULL: last create error */

@@ -190,8 +190,11 @@ class Context:
         self.device = int(device)
         torch.cuda.set_device(self.device)
         self._h = C.c_void_p()
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        st = lib().nle_ctx_create(self.device, C.c_void_p(stream), C.byref(self._h))
+        # A dedicated torch stream: its handle is never the null stream (a NULL stream argument means
+        # "create your own" in the C ABI), torch collectives issued under it are ordered with the
+        # kernels of the ctx, and `_sync_in` orders the ctx after whatever produced its inputs.
+        self._stream = torch.cuda.Stream(device=self.device)
+        st = lib().nle_ctx_create(self.device, C.c_void_p(self._stream.cuda_stream), C.byref(self._h))
         if st != NLE_OK:
             raise NLEError(st, (lib().nle_last_error(None) or b"").decode())
         self.rank, self.world = rank, world
@@ -211,7 +214,11 @@ class Context:
         def _cb(user, d_buf, count):
             try:
                 off = (int(d_buf) - base) // 8
-                allreduce(comm[off:off + int(count)])
+                if os.environ.get("NLE_DEBUG_COMM"):
+                    with open(os.environ["NLE_DEBUG_COMM"] + f".rank{rank}", "a") as fh:
+                        fh.write(f"{int(count)}\n")
+                with torch.cuda.stream(self._stream):   # same stream as the ctx's kernels
+                    allreduce(comm[off:off + int(count)])
                 return 0
             except Exception as e:  # noqa: BLE001 - must not propagate through C
                 print("nle allreduce callback failed:", repr(e), flush=True)
@@ -256,12 +263,18 @@ class Context:
         except Exception:  # noqa: BLE001
             pass
 
+    def _sync_in(self):
+        """order the ctx stream after the work already queued on torch's current stream"""
+        torch = _torch()
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+
     # ---- stage-level entry points (device tensors in/out) ----
     def _lum(self, lum):
         torch = _torch()
         t = torch.as_tensor(lum, dtype=torch.float32, device=f"cuda:{self.device}").contiguous()
         if t.ndim != 2:
             raise NLEError(NLE_ERR_INVALID, "luminance must be H x W")
+        self._sync_in()
         return t
 
     def local_pixels(self, H, W):
@@ -308,6 +321,7 @@ class Context:
     def ts_gemm(self, A, kd, B):
         """C = A[:, :kd] @ B  (A fp32 CUDA M x lda, B fp64 numpy kd x nc) -> CUDA M x ld(nc)."""
         torch = _torch()
+        self._sync_in()
         B = np.asfortranarray(np.asarray(B, dtype=np.float64))
         M, lda = A.shape
         nc = B.shape[1]
@@ -320,12 +334,14 @@ class Context:
         """Sinkhorn iterations (src/filter.cpp:238-245) on device phi -> (u_c, u_r)."""
         ev = np.ascontiguousarray(eigvals, dtype=np.float64)
         uc, ur = np.zeros(r), np.zeros(r)
+        self._sync_in()
         M, ldp = phi.shape
         _check(lib().nle_sinkhorn_scalings(self._h, C.c_void_p(phi.data_ptr()), M, ldp, r, _np_ptr(ev), max_iter,
                                            _np_ptr(uc), _np_ptr(ur)), self._h)
         return uc, ur
 
     def gram(self, phi, r, u):
+        self._sync_in()
         u = np.ascontiguousarray(u, dtype=np.float64)
         G = np.zeros((r, r), dtype=np.float64, order="F")
         M, ldp = phi.shape
@@ -334,6 +350,7 @@ class Context:
 
     def row_scalings(self, phi, r, u):
         torch = _torch()
+        self._sync_in()
         u = np.ascontiguousarray(u, dtype=np.float64)
         M, ldp = phi.shape
         out = torch.empty(M, dtype=torch.float64, device=phi.device)
@@ -354,6 +371,7 @@ class Context:
         return ms.value, kab
 
     def bench_sinkhorn_pass(self, phi, r, reps=10):
+        self._sync_in()
         ms = C.c_double()
         M, ldp = phi.shape
         _check(lib().nle_bench_sinkhorn_pass(self._h, C.c_void_p(phi.data_ptr()), M, ldp, r, reps, C.byref(ms)),
