@@ -903,13 +903,15 @@ __global__ __launch_bounds__(256) void k_hist_g(GridSpec gs, int p, int nrows, c
     }
 }
 
+template <int NC>  // NC = nSelCols: compile-time so that the per-pixel loops carry no branches
 __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restrict__ lum, GridSpec gs, int row0,
                                                   const double* __restrict__ ecT, const double* __restrict__ g,
                                                   double eps, double* __restrict__ ybuf, double* __restrict__ hout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int nC = gs.nSelCols, W = gs.W, n = kLevels * nC;
-    double* sg = reinterpret_cast<double*>(smem_raw);  // [256][nC]
-    double* sh = sg + n;                                // [256][nC]
+    constexpr int n = kLevels * NC;
+    const int W = gs.W;
+    double* sg = reinterpret_cast<double*>(smem_raw);  // [256][NC]
+    double* sh = sg + n;                                // [256][NC]
     const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
     const double* grow = g + (size_t)lrow * n;
     for (int i = tid; i < n; i += 256) {
@@ -924,20 +926,21 @@ __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restr
         bool smp = false;
         if (sample_row) {
             const int dc = c - gs.colOff;
-            smp = dc >= 0 && (dc % gs.colStep) == 0 && (dc / gs.colStep) < nC;
+            smp = dc >= 0 && (dc % gs.colStep) == 0 && (dc / gs.colStep) < NC;
         }
-        double e[11];
+        double e[NC];
 #pragma unroll
-        for (int b = 0; b < 11; ++b) e[b] = (b < nC) ? ecT[(size_t)b * W + c] : 0.0;
+        for (int b = 0; b < NC; ++b) e[b] = ecT[(size_t)b * W + c];
         double y = 1.0;
         if (mode != ROWPASS_COLSUM) {
+            double gv[NC];
+#pragma unroll
+            for (int b = 0; b < NC; ++b) gv[b] = sg[x * NC + b];
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int b = 0; b < 11; ++b) {
-                if (b < nC) {
-                    if (b & 1) s1 += e[b] * sg[x * nC + b];
-                    else s0 += e[b] * sg[x * nC + b];
-                }
+            for (int b = 0; b < NC; ++b) {
+                if (b & 1) s1 += e[b] * gv[b];
+                else s0 += e[b] * gv[b];
             }
             y = recip_or_zero_d(s0 + s1, eps);
         }
@@ -945,8 +948,7 @@ __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restr
         if (ybuf != nullptr) ybuf[(size_t)lrow * W + c] = y;
         if (y != 0.0) {
 #pragma unroll
-            for (int b = 0; b < 11; ++b)
-                if (b < nC) atomicAdd(&sh[x * nC + b], e[b] * y);
+            for (int b = 0; b < NC; ++b) atomicAdd(&sh[x * NC + b], e[b] * y);
         }
     }
     __syncthreads();
@@ -1040,8 +1042,16 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
     }
     {
         Scope sc(obs, SUB_HIST_PIX);
-        hipLaunchKernelGGL(k_hist_pix, dim3((unsigned)nrows_local), dim3(256), 2 * n * sizeof(double), s, mode, d_lum,
-                           gs, row0, d_ecT, d_g, eps, d_ybuf, d_h);
+#define NLE_HP(NCV)                                                                                                 \
+    case NCV:                                                                                                       \
+        hipLaunchKernelGGL((k_hist_pix<NCV>), dim3((unsigned)nrows_local), dim3(256), 2 * n * sizeof(double), s, mode, \
+                           d_lum, gs, row0, d_ecT, d_g, eps, d_ybuf, d_h);                                          \
+        break;
+        switch (nC) {
+            NLE_HP(1) NLE_HP(2) NLE_HP(3) NLE_HP(4) NLE_HP(5) NLE_HP(6) NLE_HP(7) NLE_HP(8) NLE_HP(9) NLE_HP(10) NLE_HP(11)
+            default: return hipErrorInvalidValue;
+        }
+#undef NLE_HP
     }
     Scope sc(obs, SUB_HIST_HH);
     hipLaunchKernelGGL(k_hist_hh, dim3((unsigned)((n + 255) / 256), (unsigned)nslabs), dim3(256), 0, s, nC, nR,
