@@ -1023,7 +1023,7 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
                            const double* d_w, double eps, double* d_ybuf, double* d_ws, double* d_z,
                            LaunchObserver* obs) {
     const int nC = gs.nSelCols, nR = gs.nSelRows;
-    if (nC > 11 || nR > 32) return hipErrorInvalidValue;
+    if (nC > 36 || nR > 32) return hipErrorInvalidValue;
     struct Scope {
         LaunchObserver* o;
         Scope(LaunchObserver* ob, int sub) : o(ob) { if (o) o->begin(sub); }
@@ -1037,6 +1037,11 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
     if (mode != ROWPASS_COLSUM) {
         Scope sc(obs, SUB_HIST_G);
         const size_t shm_g = ((size_t)8 * p + (size_t)32 * nR) * sizeof(double);
+        if (shm_g > 48 * 1024) {
+            hipError_t eg = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_g),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_g);
+            if (eg != hipSuccess) return eg;
+        }
         hipLaunchKernelGGL(k_hist_g, dim3((unsigned)((nrows_local + 31) / 32), kLevels / 8), dim3(256), shm_g, s, gs, p,
                            nrows_local, d_er, d_Ep, d_w, d_g);
     }
@@ -1047,8 +1052,23 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
         hipLaunchKernelGGL((k_hist_pix<NCV>), dim3((unsigned)nrows_local), dim3(256), 2 * n * sizeof(double), s, mode, \
                            d_lum, gs, row0, d_ecT, d_g, eps, d_ybuf, d_h);                                          \
         break;
+        if (nC > 11) {
+            hipError_t ea = hipSuccess;
+            switch (nC) {  // > 64 KB of LDS: raise the limit of the instantiation that is about to run
+#define NLE_HPA(NCV) case NCV: ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_pix<NCV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * n * sizeof(double))); break;
+                NLE_HPA(12) NLE_HPA(13) NLE_HPA(14) NLE_HPA(15) NLE_HPA(16) NLE_HPA(17) NLE_HPA(18) NLE_HPA(19) NLE_HPA(20)
+                NLE_HPA(21) NLE_HPA(22) NLE_HPA(23) NLE_HPA(24) NLE_HPA(25) NLE_HPA(26) NLE_HPA(27) NLE_HPA(28) NLE_HPA(29)
+                NLE_HPA(30) NLE_HPA(31) NLE_HPA(32) NLE_HPA(33) NLE_HPA(34) NLE_HPA(35) NLE_HPA(36)
+#undef NLE_HPA
+                default: break;
+            }
+            if (ea != hipSuccess) return ea;
+        }
         switch (nC) {
             NLE_HP(1) NLE_HP(2) NLE_HP(3) NLE_HP(4) NLE_HP(5) NLE_HP(6) NLE_HP(7) NLE_HP(8) NLE_HP(9) NLE_HP(10) NLE_HP(11)
+            NLE_HP(12) NLE_HP(13) NLE_HP(14) NLE_HP(15) NLE_HP(16) NLE_HP(17) NLE_HP(18) NLE_HP(19) NLE_HP(20)
+            NLE_HP(21) NLE_HP(22) NLE_HP(23) NLE_HP(24) NLE_HP(25) NLE_HP(26) NLE_HP(27) NLE_HP(28) NLE_HP(29)
+            NLE_HP(30) NLE_HP(31) NLE_HP(32) NLE_HP(33) NLE_HP(34) NLE_HP(35) NLE_HP(36)
             default: return hipErrorInvalidValue;
         }
 #undef NLE_HP
@@ -1068,7 +1088,7 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
 //                     M = nR(nR+1)/2, N = 256 NP, K = local image rows)
 //   3. k_ghist_final: Gk[s][s'] = sum_x Ep[x][s] Ep[x][s'] C[(a,a')][x,(b,b')]
 // ~NP LDS adds per pixel plus a 46 GFLOP GEMM at cfg4, instead of p^2/2 = 20 kFLOP per pixel.
-int ghist_max_cols() { return 11; }  // 256 * NP * 8 B of LDS
+int ghist_max_cols() { return 36; }  // one launch of k_ghist_rows up to 11, pair chunks beyond
 
 __device__ __forceinline__ int tri_index(int i, int j, int n) {  // i <= j < n, row-major upper triangle
     return i * n - (i * (i - 1)) / 2 + (j - i);
@@ -1101,6 +1121,49 @@ __global__ __launch_bounds__(256) void k_ghist_rows(const float* __restrict__ lu
     __syncthreads();
     double* out = Aout + (size_t)lrow * kLevels * NP;
     for (int i = tid; i < kLevels * NP; i += 256) out[i] = A[i];
+}
+
+// General form for 12 <= nC <= 36: the pair list does not fit in LDS at once, so a launch handles the
+// pairs (b, b..nC-1) of sample columns b in [b0, b1) (<= kGhistChunkPairs pairs, chosen by the host) and
+// writes that slice of A.
+constexpr int kGhistMaxCols = 36;
+constexpr int kGhistChunkPairs = 72;  // 256 * 72 * 8 B = 147 KB of LDS
+
+__global__ __launch_bounds__(256) void k_ghist_rows_chunk(const float* __restrict__ lum, GridSpec gs, int row0, int b0,
+                                                          int b1, int pair_off, int npairs,
+                                                          const double* __restrict__ ecT,
+                                                          const double* __restrict__ cvec,
+                                                          double* __restrict__ Aout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* A = reinterpret_cast<double*>(smem_raw);  // [256][npairs]
+    const int nC = gs.nSelCols, W = gs.W, NP = nC * (nC + 1) / 2;
+    const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
+    for (int i = tid; i < kLevels * npairs; i += 256) A[i] = 0.0;
+    __syncthreads();
+    for (int c = tid; c < W; c += 256) {
+        const double cf = cvec[(size_t)lrow * W + c];  // 0 at sample pixels
+        if (cf == 0.0) continue;
+        const int x = (int)lum[(size_t)r * W + c];
+        double q[kGhistMaxCols];
+#pragma unroll
+        for (int b = 0; b < kGhistMaxCols; ++b) q[b] = (b < nC) ? cf * ecT[(size_t)b * W + c] : 0.0;
+        double* Ax = A + (size_t)x * npairs;
+        int idx = 0;
+#pragma unroll
+        for (int b = 0; b < kGhistMaxCols; ++b) {
+            if (b >= b0 && b < b1) {  // wave-uniform
+#pragma unroll
+                for (int b2 = b; b2 < kGhistMaxCols; ++b2)
+                    if (b2 < nC) atomicAdd(&Ax[idx++], q[b] * q[b2]);
+            }
+        }
+    }
+    __syncthreads();
+    double* out = Aout + (size_t)lrow * kLevels * NP + pair_off;
+    for (int i = tid; i < kLevels * npairs; i += 256) {
+        const int x = i / npairs, j = i - x * npairs;
+        out[(size_t)x * NP + j] = A[i];
+    }
 }
 
 // EE[r][m] = er[r][a] er[r][a'] for the m-th pair a <= a' (row stride ldm, zero padded)
@@ -1191,19 +1254,40 @@ hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int 
                      const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_c, double* d_ws,
                      double* d_Gk, LaunchObserver* obs) {
     const int nC = gs.nSelCols, nR = gs.nSelRows;
-    if (nC > ghist_max_cols()) return hipErrorInvalidValue;
+    if (nC > kGhistMaxCols) return hipErrorInvalidValue;
     const int NP = nC * (nC + 1) / 2;
     const long long N = (long long)kLevels * NP;
     const int ldm = ghist_ldm(nR);
     double* d_A = d_ws;
     double* d_EE = d_A + (size_t)nrows_local * N;
     double* d_C = d_EE + (size_t)nrows_local * ldm;
-    const size_t shm = (size_t)kLevels * NP * sizeof(double);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ghist_rows),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    if (e != hipSuccess) return e;
+    hipError_t e;
     if (obs) obs->begin(SUB_GHIST_ROWS);
-    hipLaunchKernelGGL(k_ghist_rows, dim3((unsigned)nrows_local), dim3(256), shm, s, d_lum, gs, row0, d_ecT, d_c, d_A);
+    if (nC <= 11) {
+        const size_t shm = (size_t)kLevels * NP * sizeof(double);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ghist_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_ghist_rows, dim3((unsigned)nrows_local), dim3(256), shm, s, d_lum, gs, row0, d_ecT, d_c,
+                           d_A);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ghist_rows_chunk),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLevels * kGhistChunkPairs * (int)sizeof(double));
+        if (e != hipSuccess) return e;
+        int b0 = 0, off = 0;
+        while (b0 < nC) {  // greedy: as many whole rows of the pair triangle as fit
+            int b1 = b0, np = 0;
+            while (b1 < nC && np + (nC - b1) <= kGhistChunkPairs) {
+                np += nC - b1;
+                ++b1;
+            }
+            if (b1 == b0) return hipErrorInvalidValue;  // cannot happen for nC <= 36 < 72
+            hipLaunchKernelGGL(k_ghist_rows_chunk, dim3((unsigned)nrows_local), dim3(256),
+                               (size_t)kLevels * np * sizeof(double), s, d_lum, gs, row0, b0, b1, off, np, d_ecT, d_c, d_A);
+            off += np;
+            b0 = b1;
+        }
+    }
     if (obs) obs->end(), obs->begin(SUB_GHIST_EE);
     hipLaunchKernelGGL(k_ghist_ee, dim3(512), dim3(256), 0, s, d_er, nrows_local, nR, ldm, d_EE);
     constexpr int MT = 14;

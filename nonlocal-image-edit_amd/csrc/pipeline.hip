@@ -506,7 +506,7 @@ std::vector<double> gram_all(nle_ctx* c, const float* d_phi, long long M, int ld
 // threads (a 200^3 product is ~2 ms on one core; thread start-up is ~50 us).
 template <typename F>
 void par_cols(int n, long long work_per_col, F&& body) {
-    int nt = (int)std::min<long long>(4, (work_per_col * n) / 2000000 + 1);
+    int nt = (int)std::min<long long>(work_per_col * n > 200000000ll ? 16 : 4, (work_per_col * n) / 2000000 + 1);
     if (const char* e = std::getenv("NLE_HOST_THREADS")) nt = std::max(1, std::atoi(e));
     nt = std::min(nt, n);
     if (nt <= 1) {
@@ -902,7 +902,9 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         d_partial((size_t)nlek::sink_pass_rows(std::max<long long>(M, 1)) * P64);
     DevBuf<double> d_cbuf((size_t)std::max<long long>(M, 1));
     // quantised luminance + Cartesian sample grid: table look-ups replace the exponentials (fused.hip)
-    const bool hist = ss.quantised && c->mode != 3 && ss.gs.nSelCols <= nlek::sink_hist_max_cols() && M > 0;
+    const bool hist = ss.quantised && c->mode != 3 && ss.gs.nSelCols <= nlek::sink_hist_max_cols() &&
+                      ss.gs.nSelRows <= 32 && M > 0;
+    if (!hist && p > nlek::sink_pass_max_p()) throw Fail{NLE_ERR_INVALID, "Phi-free path: too many samples for the generic kernels"};
     const int nrows_local = (int)(M / ss.gs.W), row0 = (int)(pix0 / ss.gs.W);
     DevBuf<double> d_er, d_ecT, d_Ep;
     if (hist) {
@@ -917,7 +919,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     HIP_OK(hipMemcpyAsync(d_VA.p, ny.VA.data(), Bh.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemsetAsync(d_w.p, 0, P64 * sizeof(double), c->stream));
-    const bool hist_tiled = hist && ss.gs.nSelCols <= 11 && ss.gs.nSelRows <= 32 && std::getenv("NLE_HIST_UNTILED") == nullptr;
+    const bool hist_tiled = hist && ss.gs.nSelCols <= 36 && ss.gs.nSelRows <= 32 && std::getenv("NLE_HIST_UNTILED") == nullptr;
     DevBuf<double> d_hws;
     if (hist_tiled) d_hws.alloc(nlek::hist_tiled_workspace_elems(ss.gs, nrows_local));
     const int nrows = hist ? nrows_local : nlek::sink_pass_rows(std::max<long long>(M, 1));
@@ -1046,12 +1048,17 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
     if (n_eig < 1) throw Fail{NLE_ERR_INVALID, "nEigenVectors must be >= 1"};
     if (!(hx > 0) || !(hy > 0)) throw Fail{NLE_ERR_INVALID, "hx and hy must be > 0"};
     if (gs.p() > 2048) throw Fail{NLE_ERR_INVALID, "more than 2048 samples is not supported"};
-    const bool can_fuse = gs.p() <= nlek::sink_pass_max_p() && n_eig <= 128;
-    if (c->mode >= 2 && !can_fuse)
-        throw Fail{NLE_ERR_INVALID, "Phi-free path supports at most 256 samples and 128 eigenvectors"};
-    // auto: Phi-free needs enough non-sample pixels per sample for its column sums to average
-    // their fp32 rounding (DESIGN.md "Numerics"); tiny images cost nothing either way
-    const bool fuse = (c->mode >= 2) || (c->mode == 0 && can_fuse && (long long)H * W >= 64ll * gs.p());
+    // Phi-free needs <= 128 eigenvectors; its generic kernels need <= 256 samples, its table kernels
+    // (quantised luminance, checked on the device below) a sample grid of at most 32 x 36.
+    const bool generic_ok = gs.p() <= nlek::sink_pass_max_p() && n_eig <= 128;
+    const bool tables_ok = n_eig <= 128 && gs.nSelCols <= nlek::ghist_max_cols() && gs.nSelRows <= 32 && c->mode != 3;
+    if (c->mode == 3 && !generic_ok)
+        throw Fail{NLE_ERR_INVALID, "Phi-free path without tables supports at most 256 samples and 128 eigenvectors"};
+    if (c->mode == 2 && !generic_ok && !tables_ok)
+        throw Fail{NLE_ERR_INVALID, "Phi-free path supports at most 128 eigenvectors and a 32 x 36 sample grid"};
+    // auto: Phi-free needs enough non-sample pixels per sample (DESIGN.md "Numerics"); tiny images cost
+    // nothing either way
+    const bool want_fuse = c->mode >= 2 || (c->mode == 0 && (long long)H * W >= 64ll * gs.p());
     HIP_OK(hipSetDevice(c->device));
 
     auto f = new nle_filter();
@@ -1069,7 +1076,10 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         // --- sample set, Ka and its eigenpairs (:486-491, host fp64)
         Timer tm_a(c->stream);
         tm_a.start();
-        SampleSet ss = fetch_samples(c, d_lum, gs, fuse && c->mode != 3);
+        SampleSet ss = fetch_samples(c, d_lum, gs, want_fuse && tables_ok);
+        const bool fuse = want_fuse && (generic_ok || (tables_ok && ss.quantised));
+        if (c->mode == 2 && !fuse)
+            throw Fail{NLE_ERR_INVALID, "Phi-free path: more than 256 samples needs an integer-valued luminance plane"};
         tr.mark("fetch_samples");
         f->p = ss.p;
         double h0 = now_ms();
