@@ -164,6 +164,9 @@ void nle_filter_destroy(nle_filter* f);
 int nle_filter_info(const nle_filter* f, long long* n_local, int* K, int* r, int* p,
                     int* row0, int* row1);
 int nle_filter_eigvals(const nle_filter* f, double* h_eigvals /* K */);
+/* min / max coefficient of the first `ncols` eigenvectors over this rank's slab (what the reference
+ * prints at src/filter.cpp:506): h_min[ncols], h_max[ncols] */
+int nle_filter_eigvec_range(const nle_filter* f, int ncols, double* h_min, double* h_max);
 /* device pointer + leading dimension of V (n_local x ld), for inspection */
 int nle_filter_eigvecs(const nle_filter* f, const float** d_V, int* ld);
 /* copy V (n_local x ld floats) into a caller-owned DEVICE buffer */
@@ -183,6 +186,16 @@ int nle_apply_layers(nle_filter* f, const float* d_x, int H, int W, int L, float
 int nle_apply_host(nle_filter* f, const float* h_x, int H, int W, const double* h_fS,
                    float* h_y);
 int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, float* h_y);
+
+/* ---- colour wrapper on the device (the code either side of the path) ------------------------------- */
+/* cv::cvtColor(COLOR_BGR2Lab) on an 8-bit image as the reference uses it (src/filter.cpp:423,463) and
+ * the split / convertTo(CV_64F) of the L channel (:424-426,465-467): d_bgr n x 3 bytes -> d_lab n x 3
+ * bytes (may be NULL) and d_L n floats = L in 0..255 (may be NULL).  OpenCV's own 8-bit path is a
+ * version-dependent fixed-point table; this is the documented float formula (about one grey level). */
+int nle_bgr2lab8(nle_ctx* ctx, const unsigned char* d_bgr, long long n, unsigned char* d_lab, float* d_L);
+/* max(0) / min(255) / convertTo(CV_8U) / merge / cvtColor(COLOR_Lab2BGR) (src/filter.cpp:434-440): the L
+ * channel is taken from d_L (clamped, rounded half to even) when given, else from d_lab. */
+int nle_lab2bgr8(nle_ctx* ctx, const unsigned char* d_lab, const float* d_L, long long n, unsigned char* d_bgr);
 
 /* leading dimension used for a logical width n: (n + 3) & ~3 */
 int nle_ld(int n);

@@ -157,6 +157,9 @@ Vec transformEigenValues(const Vec& eigvals, const std::vector<DType>& weights);
 // 8-bit BGR <-> Lab as cv::cvtColor(COLOR_BGR2Lab / COLOR_Lab2BGR) documents it (host)
 Image bgr2lab8(const Image& bgr);
 Image lab2bgr8(const Image& lab);
+// the same on the GPU (what NLEFilter uses); agree with the host forms except for isolated rounding ties
+Image bgr2lab8_device(const Image& bgr);
+Image lab2bgr8_device(const Image& lab);
 
 // include/filter.hpp:35-54.  The trained state (m_eigvecs N x K', m_eigvals) lives on the GPU.
 class NLEFilter {
@@ -176,6 +179,9 @@ public:
     Image apply(const Image& channel, const Vec& transformedEigVals) const;
     void trainFilter(const Image& channel, int nRowSamples, int nColSamples, DType hx, DType hy, int nSinkhornIter,
                      int nEigenVectors);
+    // train on an fp32 luminance plane that is already on the device
+    void trainOnDevice(const float* d_lum, int rows, int cols, int nRowSamples, int nColSamples, DType hx, DType hy,
+                       int nSinkhornIter, int nEigenVectors);
     // per-layer outputs (L planes, CV_64F) -- what the 1e-4 per-detail-layer bar compares
     std::vector<Image> applyLayers(const Image& channel, int nLayers) const;
 

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "nle_filter_destroy": (None, [_P]),
     "nle_filter_info": (C.c_int, [_P, C.POINTER(C.c_longlong)] + [C.POINTER(C.c_int)] * 5),
     "nle_filter_eigvals": (C.c_int, [_P, _P]),
+    "nle_filter_eigvec_range": (C.c_int, [_P, C.c_int, _P, _P]),
     "nle_filter_eigvecs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int)]),
     "nle_filter_copy_eigvecs": (C.c_int, [_P, _P]),
     "nle_filter_timings": (C.c_int, [_P, _P]),
@@ -67,6 +68,8 @@ _SIGNATURES = {
     "nle_apply_layers": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "nle_apply_host": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "nle_apply_layers_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "nle_bgr2lab8": (C.c_int, [_P, _P, C.c_longlong, _P, _P]),
+    "nle_lab2bgr8": (C.c_int, [_P, _P, _P, C.c_longlong, _P]),
     "nle_ld": (C.c_int, [C.c_int]),
     "nle_kernel_name": (C.c_char_p, [C.c_int]),
     "nle_ctx_profile": (C.c_int, [_P, C.c_int]),
@@ -96,6 +99,13 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: run `python nonlocal-image-edit_amd/build.py` "
                 "(or __graft_entry__.build()); there is no CPU fallback")
+        # torch-rocm ships its own copy of the HIP runtime: load torch first so that this process ends up
+        # with ONE libamdhip64 (loading ours first leaves torch and the library on different runtimes and
+        # hipGetDeviceCount then reports no device)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it

@@ -1,0 +1,121 @@
+// 8-bit BGR <-> Lab on the device: the colour wrapper either side of the hot path
+// (reference src/filter.cpp:460-469 getLuminanceChannel, :422-426 and :434-440 in NLEFilter::enhance,
+// where it is cv::cvtColor on 8-bit images).  Same formulas as the host restatement in
+// host/filter.cpp (sRGB decode, XYZ D65, L*a*b*, L*255/100, a+128, b+128), evaluated in fp64 so
+// that the two agree except for isolated round-to-nearest ties.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace nlek {
+
+namespace {
+__device__ __forceinline__ double lab_f(double t) { return t > 0.008856 ? cbrt(t) : 7.787 * t + 16.0 / 116.0; }
+__device__ __forceinline__ unsigned char sat8(double v) {
+    return (unsigned char)fmin(255.0, fmax(0.0, rint(v)));  // round half to even, saturate (cv convertTo CV_8U)
+}
+__device__ __forceinline__ double lin2srgb(double v) {
+    return v <= 0.0031308 ? 12.92 * v : 1.055 * pow(fmax(v, 0.0), 1.0 / 2.4) - 0.055;
+}
+}  // namespace
+
+// lut[i] = sRGB-decoded i/255 (256 doubles, built by the host); d_L (optional) = L channel as fp32
+__global__ __launch_bounds__(256) void k_bgr2lab8(const unsigned char* __restrict__ bgr, long long n,
+                                                  const double* __restrict__ lut, unsigned char* __restrict__ lab,
+                                                  float* __restrict__ Lf) {
+    __shared__ double sl[256];
+    sl[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double b = sl[bgr[3 * i + 0]], g = sl[bgr[3 * i + 1]], r = sl[bgr[3 * i + 2]];
+        const double x = (0.412453 * r + 0.357580 * g + 0.180423 * b) / 0.950456;
+        const double y = 0.212671 * r + 0.715160 * g + 0.072169 * b;
+        const double z = (0.019334 * r + 0.119193 * g + 0.950227 * b) / 1.088754;
+        const double L = y > 0.008856 ? 116.0 * cbrt(y) - 16.0 : 903.3 * y;
+        const unsigned char L8 = sat8(L * 255.0 / 100.0);
+        if (lab != nullptr) {
+            lab[3 * i + 0] = L8;
+            lab[3 * i + 1] = sat8(500.0 * (lab_f(x) - lab_f(y)) + 128.0);
+            lab[3 * i + 2] = sat8(200.0 * (lab_f(y) - lab_f(z)) + 128.0);
+        }
+        if (Lf != nullptr) Lf[i] = (float)L8;
+    }
+}
+
+// L from Lf when given (clamped to [0,255] and rounded half-to-even like :434-436), else lab's own
+__global__ __launch_bounds__(256) void k_lab2bgr8(const unsigned char* __restrict__ lab, const float* __restrict__ Lf,
+                                                  long long n, unsigned char* __restrict__ bgr) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double L8 = Lf != nullptr ? (double)sat8((double)Lf[i]) : (double)lab[3 * i + 0];
+        const double L = L8 * 100.0 / 255.0, a = (double)lab[3 * i + 1] - 128.0, b = (double)lab[3 * i + 2] - 128.0;
+        double fy = (L + 16.0) / 116.0, y;
+        if (L > 7.9996248) {
+            y = fy * fy * fy;
+        } else {
+            y = L / 903.3;
+            fy = 7.787 * y + 16.0 / 116.0;
+        }
+        const double fx = a / 500.0 + fy, fz = fy - b / 200.0;
+        const double x = (fx > 0.206893 ? fx * fx * fx : (fx - 16.0 / 116.0) / 7.787) * 0.950456;
+        const double z = (fz > 0.206893 ? fz * fz * fz : (fz - 16.0 / 116.0) / 7.787) * 1.088754;
+        const double r = 3.240479 * x - 1.53715 * y - 0.498535 * z;
+        const double g = -0.969256 * x + 1.875991 * y + 0.041556 * z;
+        const double bl = 0.055648 * x - 0.204043 * y + 1.057311 * z;
+        bgr[3 * i + 0] = sat8(lin2srgb(fmin(1.0, fmax(0.0, bl))) * 255.0);
+        bgr[3 * i + 1] = sat8(lin2srgb(fmin(1.0, fmax(0.0, g))) * 255.0);
+        bgr[3 * i + 2] = sat8(lin2srgb(fmin(1.0, fmax(0.0, r))) * 255.0);
+    }
+}
+
+hipError_t bgr2lab8(hipStream_t s, const unsigned char* d_bgr, long long n, const double* d_lut, unsigned char* d_lab,
+                    float* d_L) {
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_bgr2lab8, dim3(grid), dim3(256), 0, s, d_bgr, n, d_lut, d_lab, d_L);
+    return hipGetLastError();
+}
+
+hipError_t lab2bgr8(hipStream_t s, const unsigned char* d_lab, const float* d_L, long long n, unsigned char* d_bgr) {
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_lab2bgr8, dim3(grid), dim3(256), 0, s, d_lab, d_L, n, d_bgr);
+    return hipGetLastError();
+}
+
+// per-block min / max of the first ncols columns of X (M x ld): out[block][2*ncols]
+__global__ __launch_bounds__(256) void k_col_range(const float* __restrict__ X, long long M, int ld, int ncols,
+                                                   float* __restrict__ out) {
+    __shared__ float smn[256], smx[256];
+    for (int k = 0; k < ncols; ++k) {
+        float mn = 3.4e38f, mx = -3.4e38f;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M; i += (long long)gridDim.x * 256) {
+            const float v = X[(size_t)i * ld + k];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+        smn[threadIdx.x] = mn;
+        smx[threadIdx.x] = mx;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) {
+                smn[threadIdx.x] = fminf(smn[threadIdx.x], smn[threadIdx.x + off]);
+                smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + off]);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            out[(size_t)blockIdx.x * 2 * ncols + 2 * k] = smn[0];
+            out[(size_t)blockIdx.x * 2 * ncols + 2 * k + 1] = smx[0];
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t col_range(hipStream_t s, const float* d_X, long long M, int ld, int ncols, float* d_out, int nblocks) {
+    hipLaunchKernelGGL(k_col_range, dim3(nblocks), dim3(256), 0, s, d_X, M, ld, ncols, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace nlek

@@ -149,6 +149,14 @@ hipError_t project_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, i
                         const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_D, int ldd, int K,
                         const double* d_c, float* d_V, int ldv);
 
+// 8-bit BGR <-> Lab (colour.hip): d_lut = 256 sRGB-decoded doubles; d_lab / d_L optional outputs
+hipError_t bgr2lab8(hipStream_t s, const unsigned char* d_bgr, long long n, const double* d_lut, unsigned char* d_lab,
+                    float* d_L);
+hipError_t lab2bgr8(hipStream_t s, const unsigned char* d_lab, const float* d_L, long long n, unsigned char* d_bgr);
+
+// out[block][2*ncols] = {min, max} of the first ncols columns of X over the block's rows
+hipError_t col_range(hipStream_t s, const float* d_X, long long M, int ld, int ncols, float* d_out, int nblocks);
+
 // Y[l][i] = sum_k V[i][k] * g[l][k]   (g: L x ld doubles, device)
 hipError_t apply_expand(hipStream_t s, const float* d_V, long long M, int ld, const double* d_g,
                         int L, float* d_Y, long long ystride);

@@ -40,6 +40,7 @@ struct nle_ctx {
     // everything is stream-ordered on `stream`, so reuse needs no extra synchronisation
     std::multimap<size_t, void*> arena_free;
     size_t arena_bytes = 0;
+    double* d_lut = nullptr;        // sRGB decode table of the colour wrapper
     std::set<nle_filter*> filters;  // live filters trained on this ctx (orphaned if the ctx dies first)
     int mode = 0;  // nle_ctx_set_mode: 0 auto, 1 materialised Phi, 2 Phi-free, 3 Phi-free without look-up tables
     bool profiling = false;
@@ -1211,6 +1212,7 @@ void nle_ctx_destroy(nle_ctx* ctx) {
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto* f : ctx->filters) f->ctx = nullptr;  // their V is freed directly when they are destroyed
+    if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     for (auto& kv : ctx->arena_free) (void)hipFree(kv.second);
     ctx->arena_free.clear();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1254,6 +1256,39 @@ int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
     return guard(ctx, [&] {
         HIP_OK(hipSetDevice(ctx->device));
         HIP_OK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+namespace {
+const double* colour_lut(nle_ctx* c) {  // sRGB decode of i/255, uploaded once per ctx
+    if (!c->d_lut) {
+        double lut[256];
+        for (int i = 0; i < 256; ++i) {
+            const double v = i / 255.0;
+            lut[i] = v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4);
+        }
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->d_lut), sizeof lut));
+        HIP_OK(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+    }
+    return c->d_lut;
+}
+}  // namespace
+
+int nle_bgr2lab8(nle_ctx* ctx, const unsigned char* d_bgr, long long n, unsigned char* d_lab, float* d_L) {
+    if (!ctx || !d_bgr || n < 0 || (!d_lab && !d_L)) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        HIP_OK(nlek::bgr2lab8(ctx->stream, d_bgr, n, colour_lut(ctx), d_lab, d_L));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int nle_lab2bgr8(nle_ctx* ctx, const unsigned char* d_lab, const float* d_L, long long n, unsigned char* d_bgr) {
+    if (!ctx || !d_lab || !d_bgr || n < 0) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        HIP_OK(nlek::lab2bgr8(ctx->stream, d_lab, d_L, n, d_bgr));
         HIP_OK(hipStreamSynchronize(ctx->stream));
     });
 }
@@ -1483,6 +1518,29 @@ int nle_filter_eigvals(const nle_filter* f, double* h_eigvals) {
     if (!f || !h_eigvals) return NLE_ERR_INVALID;
     std::copy(f->eigvals.begin(), f->eigvals.end(), h_eigvals);
     return NLE_OK;
+}
+
+int nle_filter_eigvec_range(const nle_filter* f, int ncols, double* h_min, double* h_max) {
+    if (!f || !f->ctx || ncols < 1 || ncols > f->K || !h_min || !h_max) return NLE_ERR_INVALID;
+    return guard(f->ctx, [&] {
+        nle_ctx* c = f->ctx;
+        HIP_OK(hipSetDevice(c->device));
+        const int nb = 256;
+        DevBuf<float> d_out((size_t)nb * 2 * ncols);
+        HIP_OK(nlek::col_range(c->stream, f->d_V, f->n_local, f->ldv, ncols, d_out.p, nb));
+        std::vector<float> out((size_t)nb * 2 * ncols);
+        HIP_OK(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < ncols; ++k) {
+            double mn = out[2 * k], mx = out[2 * k + 1];
+            for (int b = 1; b < nb; ++b) {
+                mn = std::min(mn, (double)out[(size_t)b * 2 * ncols + 2 * k]);
+                mx = std::max(mx, (double)out[(size_t)b * 2 * ncols + 2 * k + 1]);
+            }
+            h_min[k] = mn;
+            h_max[k] = mx;
+        }
+    });
 }
 
 int nle_filter_eigvecs(const nle_filter* f, const float** d_V, int* ld) {

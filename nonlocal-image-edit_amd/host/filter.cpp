@@ -345,6 +345,32 @@ Image lab2bgr8(const Image& lab) {
     return bgr;
 }
 
+// the same conversions on the GPU (csrc/colour.hip) -- what NLEFilter uses; results agree with the host
+// functions above except for isolated rounding ties
+Image bgr2lab8_device(const Image& bgr) {
+    if (bgr.channels() != 3 || bgr.depth() != NLE_8U) throw std::runtime_error("bgr2lab8: 8UC3 image expected");
+    nle_ctx* c = shared_ctx();
+    const size_t n = bgr.total();
+    Dev d_in(c, n * 3), d_out(c, n * 3);
+    check(nle_dev_upload(c, d_in.p, bgr.ptr<unsigned char>(), n * 3), c);
+    check(nle_bgr2lab8(c, static_cast<unsigned char*>(d_in.p), (long long)n, static_cast<unsigned char*>(d_out.p), nullptr), c);
+    Image lab(bgr.rows, bgr.cols, NLE_8U, 3);
+    check(nle_dev_download(c, lab.ptr<unsigned char>(), d_out.p, n * 3), c);
+    return lab;
+}
+
+Image lab2bgr8_device(const Image& lab) {
+    if (lab.channels() != 3 || lab.depth() != NLE_8U) throw std::runtime_error("lab2bgr8: 8UC3 image expected");
+    nle_ctx* c = shared_ctx();
+    const size_t n = lab.total();
+    Dev d_in(c, n * 3), d_out(c, n * 3);
+    check(nle_dev_upload(c, d_in.p, lab.ptr<unsigned char>(), n * 3), c);
+    check(nle_lab2bgr8(c, static_cast<unsigned char*>(d_in.p), nullptr, (long long)n, static_cast<unsigned char*>(d_out.p)), c);
+    Image bgr(lab.rows, lab.cols, NLE_8U, 3);
+    check(nle_dev_download(c, bgr.ptr<unsigned char>(), d_out.p, n * 3), c);
+    return bgr;
+}
+
 namespace {
 Image luminance_plane(const Image& lab) {  // split + convertTo(CV_64F), :460-469
     Image L(lab.rows, lab.cols, NLE_64F, 1);
@@ -369,11 +395,19 @@ void NLEFilter::trainFilter(const Image& channel, int nRowSamples, int nColSampl
     if (nRowSamples > channel.rows || nColSamples > channel.cols)
         throw std::runtime_error("Number of samples per row and col must be <= that of image.");
     ctx_ = shared_ctx();
+    std::vector<float> lum = plane_f32(channel);
+    Dev d_lum(ctx_, lum.size() * 4);
+    check(nle_dev_upload(ctx_, d_lum.p, lum.data(), lum.size() * 4), ctx_);
+    trainOnDevice(d_lum.f(), channel.rows, channel.cols, nRowSamples, nColSamples, hx, hy, nSinkhornIter, nEigenVectors);
+}
+
+void NLEFilter::trainOnDevice(const float* d_lum, int rows, int cols, int nRowSamples, int nColSamples, DType hx,
+                              DType hy, int nSinkhornIter, int nEigenVectors) {
+    ctx_ = shared_ctx();
     if (f_) {
         nle_filter_destroy(f_);
         f_ = nullptr;
     }
-    std::vector<float> lum = plane_f32(channel);
     if (verbose) {
         // the four stages run as one fused GPU pipeline; the banners keep the reference's stdout (:483-498)
         std::cout << "Computing kernel" << std::endl;
@@ -381,28 +415,32 @@ void NLEFilter::trainFilter(const Image& channel, int nRowSamples, int nColSampl
         std::cout << "Sinkhorn" << std::endl;
         std::cout << "Orthogonalize" << std::endl;
     }
-    check(nle_train_host(ctx_, lum.data(), channel.rows, channel.cols, nRowSamples, nColSamples, hx, hy, nSinkhornIter,
-                         nEigenVectors, &f_), ctx_);
-    rows_ = channel.rows;
-    cols_ = channel.cols;
+    check(nle_train(ctx_, d_lum, rows, cols, nRowSamples, nColSamples, hx, hy, nSinkhornIter, nEigenVectors, &f_), ctx_);
+    rows_ = rows;
+    cols_ = cols;
     if (verbose) {
         Vec ev = eigvals();
-        Mat V = eigvecs();
-        for (int i = 0; i < std::min(std::min(nEigenVectors, 5), ev.size()); i++) {  // :504-506 (imshow dropped)
-            double mn = V(0, i), mx = V(0, i);
-            for (int r = 1; r < V.rows(); ++r) {
-                mn = std::min(mn, V(r, i));
-                mx = std::max(mx, V(r, i));
-            }
-            std::cout << "Eigvec " << i << " eigval: " << ev(i) << " minCoeff: " << mn << " maxCoeff: " << mx << std::endl;
-        }
+        const int nshow = std::min(std::min(nEigenVectors, 5), ev.size());  // :504-506 (imshow dropped)
+        double mn[5], mx[5];
+        if (nshow > 0) check(nle_filter_eigvec_range(f_, nshow, mn, mx), ctx_);  // min/max on the device
+        for (int i = 0; i < nshow; i++)
+            std::cout << "Eigvec " << i << " eigval: " << ev(i) << " minCoeff: " << mn[i] << " maxCoeff: " << mx[i]
+                      << std::endl;
     }
 }
 
 void NLEFilter::trainForEnhancement(const Image& image, int nRowSamples, int nColSamples, DType hx, DType hy,
                                     int nSinkhornIter, int nEigenVectors) {  // :514-519
-    Image luminance = luminance_plane(bgr2lab8(image));
-    trainFilter(luminance, nRowSamples, nColSamples, hx, hy, nSinkhornIter, nEigenVectors);
+    if (image.channels() != 3 || image.depth() != NLE_8U) throw std::runtime_error("Can only enhance RGB image.");
+    if (nRowSamples > image.rows || nColSamples > image.cols)
+        throw std::runtime_error("Number of samples per row and col must be <= that of image.");
+    // getLuminanceChannel (:460-469) on the device: BGR -> Lab (8 bit) -> L as float
+    ctx_ = shared_ctx();
+    const size_t n = image.total();
+    Dev d_bgr(ctx_, n * 3), d_L(ctx_, n * 4);
+    check(nle_dev_upload(ctx_, d_bgr.p, image.ptr<unsigned char>(), n * 3), ctx_);
+    check(nle_bgr2lab8(ctx_, static_cast<unsigned char*>(d_bgr.p), (long long)n, nullptr, d_L.f()), ctx_);
+    trainOnDevice(d_L.f(), image.rows, image.cols, nRowSamples, nColSamples, hx, hy, nSinkhornIter, nEigenVectors);
 }
 
 Image NLEFilter::apply(const Image& channel, const Vec& transformedEigVals) const {  // :445-458
@@ -445,15 +483,20 @@ Image NLEFilter::enhance(const Image& image, const std::vector<DType>& weights) 
     if (!f_ || (long long)image.total() != n)
         throw std::runtime_error(
             "Cannot apply filter on image with different size from the image filter was trained on.");
-    Image lab = bgr2lab8(image);
-    Image L = luminance_plane(lab);
+    if (image.depth() != NLE_8U) throw std::runtime_error("Can only enhance RGB image.");
+    // :422-440 on the device: BGR -> Lab, L -> float, apply, clamp + round to 8 bit, merge with a, b, Lab -> BGR
+    const size_t np = image.total();
+    Dev d_bgr(ctx_, np * 3), d_lab(ctx_, np * 3), d_L(ctx_, np * 4), d_y(ctx_, np * 4);
+    check(nle_dev_upload(ctx_, d_bgr.p, image.ptr<unsigned char>(), np * 3), ctx_);
+    check(nle_bgr2lab8(ctx_, static_cast<unsigned char*>(d_bgr.p), (long long)np, static_cast<unsigned char*>(d_lab.p),
+                       d_L.f()), ctx_);
     Vec fS = transformEigenValues(eigvals(), weights);
-    Image Lf = apply(L, fS);
-    unsigned char* d = lab.ptr<unsigned char>();
-    const double* s = Lf.ptr<double>();
-    for (size_t i = 0; i < lab.total(); ++i)  // max(0), min(255), convertTo(CV_8U): round half to even, :434-436
-        d[3 * i] = sat8(std::min(255.0, std::max(0.0, s[i])));
-    return lab2bgr8(lab);  // a, b unchanged, :438-440
+    check(nle_apply(f_, d_L.f(), image.rows, image.cols, fS.data(), d_y.f()), ctx_);
+    check(nle_lab2bgr8(ctx_, static_cast<unsigned char*>(d_lab.p), d_y.f(), (long long)np,
+                       static_cast<unsigned char*>(d_bgr.p)), ctx_);
+    Image out(image.rows, image.cols, NLE_8U, 3);
+    check(nle_dev_download(ctx_, out.ptr<unsigned char>(), d_bgr.p, np * 3), ctx_);
+    return out;
 }
 
 Vec NLEFilter::eigvals() const {

@@ -177,6 +177,25 @@ int main() {
         }
         CHECK(threw);  // src/filter.cpp:117-119
     }
+    {  // colour wrapper: device kernels against the host restatement of cv::cvtColor on 8-bit images
+        std::uniform_int_distribution<int> u8(0, 255);
+        nle::Image img(61, 83, nle::NLE_8U, 3);
+        for (size_t i = 0; i < img.total() * 3; ++i) img.ptr<unsigned char>()[i] = (unsigned char)u8(gen);
+        nle::Image lab_h = nle::bgr2lab8(img), lab_d = nle::bgr2lab8_device(img);
+        nle::Image bgr_h = nle::lab2bgr8(lab_h), bgr_d = nle::lab2bgr8_device(lab_h);
+        size_t bad_lab = 0, bad_bgr = 0;
+        int worst = 0;
+        for (size_t i = 0; i < img.total() * 3; ++i) {
+            const int d1 = std::abs((int)lab_h.ptr<unsigned char>()[i] - (int)lab_d.ptr<unsigned char>()[i]);
+            const int d2 = std::abs((int)bgr_h.ptr<unsigned char>()[i] - (int)bgr_d.ptr<unsigned char>()[i]);
+            bad_lab += d1 != 0;
+            bad_bgr += d2 != 0;
+            worst = std::max(worst, std::max(d1, d2));
+        }
+        CHECK(worst <= 1);                                   // only rounding ties may differ
+        CHECK(bad_lab * 1000 <= img.total() * 3);            // and at most 0.1 % of the values
+        CHECK(bad_bgr * 1000 <= img.total() * 3);
+    }
     std::printf("%d checks, %d failed\n", g_total, g_fail);
     return g_fail == 0 ? 0 : 1;
 }
