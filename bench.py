@@ -171,7 +171,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.profile(True)
+    ctx.profile(1)   # HIP events around the N-sized kernels of the timed region
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -192,7 +192,7 @@ def main():
 
     # ---- roofline of the dominant kernel (this rank's launches)
     ran = {k for k, v in stats.items() if v[0] > 0}
-    form = "materialised" if "nystrom_extend" in ran else ("phi_free_tables" if "sink_tables" in ran else "phi_free_exp")
+    form = "materialised" if "nystrom_extend" in ran else ("phi_free_tables" if "gram_gemm" in ran else "phi_free_exp")
     models = roofline_models(info, L, form, g)
     traffic = load_traffic()
     per_kernel = {}

@@ -218,9 +218,10 @@ enum {
     NLE_KERNEL_COUNT = 12
 };
 const char* nle_kernel_name(int kid);
-/* enable != 0: bracket every kernel launch of the ctx with HIP events recorded on the ctx's
- * stream and accumulate per-kernel launch counts and durations (resolved whenever the
- * pipeline synchronises the stream).  Resets the counters. */
+/* enable != 0: bracket kernel launches of the ctx with HIP events recorded on the ctx's stream and
+ * accumulate per-kernel launch counts and durations (resolved whenever the pipeline synchronises the
+ * stream).  enable == 1: the N-sized kernels only; enable == 2: also the p-sized / second-stage
+ * kernels (every timed launch opens a ~10 us gap on the stream).  Resets the counters. */
 int nle_ctx_profile(nle_ctx* ctx, int enable);
 int nle_ctx_kernel_stats(nle_ctx* ctx, int kid, long long* launches, double* total_ms);
 /* Run `reps` launches of the materialising affinity kernel (the HBM-roofline pass of

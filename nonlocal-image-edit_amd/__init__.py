@@ -249,9 +249,11 @@ class Context:
         """release the cached device workspace"""
         _check(lib().nle_ctx_trim(self._h), self._h)
 
-    def profile(self, enable: bool = True):
-        """Per-kernel HIP-event timing on the ctx's stream (resets the counters)."""
-        _check(lib().nle_ctx_profile(self._h, 1 if enable else 0), self._h)
+    def profile(self, enable=True):
+        """Per-kernel HIP-event timing on the ctx's stream (resets the counters).  True / 2: every
+        kernel; 1: the N-sized kernels only (cheaper: each timed launch costs ~10 us of stream gaps)."""
+        level = 2 if enable is True else int(enable)
+        _check(lib().nle_ctx_profile(self._h, level), self._h)
 
     def kernel_stats(self):
         """{kernel name: (launches, total_ms)} accumulated since `profile(True)`."""

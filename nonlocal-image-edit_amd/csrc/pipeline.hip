@@ -44,6 +44,7 @@ struct nle_ctx {
     std::set<nle_filter*> filters;  // live filters trained on this ctx (orphaned if the ctx dies first)
     int mode = 0;  // nle_ctx_set_mode: 0 auto, 1 materialised Phi, 2 Phi-free, 3 Phi-free without look-up tables
     bool profiling = false;
+    bool profile_all = false;  // level 2: also the small / second-stage kernels (each timed launch costs ~10 us of gaps)
     struct ProfRec {
         int kid;
         hipEvent_t a, b;
@@ -197,6 +198,7 @@ struct Prof {
     hipEvent_t a = nullptr, b = nullptr;
     Prof(nle_ctx* c_, int kid_) : c(c_), kid(kid_) {
         if (!c->profiling) return;
+        if (!c->profile_all && (kid == NLE_K_SMALL || kid == NLE_K_REDUCE || kid == NLE_K_SINK_TABLES)) return;
         a = prof_event(c);
         b = prof_event(c);
         HIP_OK(hipEventRecord(a, c->stream));
@@ -1619,6 +1621,7 @@ int nle_ctx_profile(nle_ctx* ctx, int enable) {
         HIP_OK(hipStreamSynchronize(ctx->stream));
         prof_flush(ctx);
         ctx->profiling = enable != 0;
+        ctx->profile_all = enable >= 2;
         for (int k = 0; k < NLE_KERNEL_COUNT; ++k) {
             ctx->prof_launches[k] = 0;
             ctx->prof_ms[k] = 0.0;
