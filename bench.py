@@ -40,7 +40,7 @@ FP32_PEAK_TF = 157.3        # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vecto
 FP64_MFMA_PEAK_TF = 78.6    # MI355X FP64 matrix peak (spec; SURVEY.md section 8d quotes ~79 TFLOP/s fp64)
 
 
-def roofline_models(info, L, form, grid):
+def roofline_models(info, L, form, grid, lazy=False):
     """kernel name -> (bound, algorithmic units per launch, peak) for this rank (n = pixels of its slab).
 
     Per-unit figures are SURVEY.md section 8(d)'s (fp32 storage, s = 4 B) where the kernel still does the
@@ -79,6 +79,9 @@ def roofline_models(info, L, form, grid):
             m["sinkhorn_pass"] = ("hbm", n * s + 2.0 * tab, HBM_PEAK_GBS)  # luminance + g in + h out
             m["gram_rows"] = ("hbm", n * (s + 8.0) + rows * 256.0 * npair * 8.0, HBM_PEAK_GBS)
             m["gram_gemm"] = ("mfma", 2.0 * ldm * 256.0 * npair * rows, FP64_MFMA_PEAK_TF)
+            if lazy:  # V stays implicit: apply runs on the tables too (bytes the two kernels really move)
+                m["apply_reduce"] = ("hbm", n * (s + 8.0 + s) + tab, HBM_PEAK_GBS)        # luminance, c, x in; h out
+                m["apply_expand"] = ("hbm", n * (s + 8.0 + s) + tab, HBM_PEAK_GBS)        # luminance, c, g in; y out
     return m
 
 
@@ -193,7 +196,8 @@ def main():
     # ---- roofline of the dominant kernel (this rank's launches)
     ran = {k for k, v in stats.items() if v[0] > 0}
     form = "materialised" if "nystrom_extend" in ran else ("phi_free_tables" if "gram_gemm" in ran else "phi_free_exp")
-    models = roofline_models(info, L, form, g)
+    lazy = form == "phi_free_tables" and "project" not in ran
+    models = roofline_models(info, L, form, g, lazy)
     traffic = load_traffic()
     per_kernel = {}
     for name, (launches, total_ms) in stats.items():
@@ -254,7 +258,7 @@ def main():
             "config": {"workload": f"{args.config}: {H}x{W} synthetic luminance, {cfg['n_row']}x{cfg['n_col']} samples "
                                    f"(p={p}), K={cfg['K']}, T={cfg['T']}, L={L} layers; input resident in HBM",
                        "parallelism": f"row-slab x{world}" if world > 1 else "single GPU",
-                       "formulation": form,
+                       "formulation": form + (" (V implicit, apply in sample space)" if lazy else ""),
                        "storage": "fp64 tables, reductions and MFMA; fp32 affinities in the projection; V and outputs fp32"},
             "roofline": roofline,
             "cpu_baseline": cpu,

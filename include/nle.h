@@ -167,7 +167,9 @@ int nle_filter_eigvals(const nle_filter* f, double* h_eigvals /* K */);
 /* min / max coefficient of the first `ncols` eigenvectors over this rank's slab (what the reference
  * prints at src/filter.cpp:506): h_min[ncols], h_max[ncols] */
 int nle_filter_eigvec_range(const nle_filter* f, int ncols, double* h_min, double* h_max);
-/* device pointer + leading dimension of V (n_local x ld), for inspection */
+/* device pointer + leading dimension of V (n_local x ld), for inspection.  In the table formulation
+ * the filter keeps V implicit (V = diag(c) K D) and applies it on its p-sized side; the first call of
+ * this / nle_filter_copy_eigvecs / nle_filter_eigvec_range materialises the matrix (one projection GEMM). */
 int nle_filter_eigvecs(const nle_filter* f, const float** d_V, int* ld);
 /* copy V (n_local x ld floats) into a caller-owned DEVICE buffer */
 int nle_filter_copy_eigvecs(const nle_filter* f, float* d_out);

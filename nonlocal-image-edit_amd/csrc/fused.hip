@@ -906,17 +906,20 @@ __global__ __launch_bounds__(256) void k_hist_g(GridSpec gs, int p, int nrows, c
 template <int NC>  // NC = nSelCols: compile-time so that the per-pixel loops carry no branches
 __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restrict__ lum, GridSpec gs, int row0,
                                                   const double* __restrict__ ecT, const double* __restrict__ g,
-                                                  double eps, double* __restrict__ ybuf, double* __restrict__ hout) {
+                                                  double eps, double* __restrict__ ybuf, double* __restrict__ hout,
+                                                  const double* __restrict__ cvec, const float* __restrict__ xvec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int n = kLevels * NC;
+    constexpr int NS = NC | 1;  // odd row stride (in doubles): spreads the levels of a wave over the LDS banks
     const int W = gs.W;
-    double* sg = reinterpret_cast<double*>(smem_raw);  // [256][NC]
-    double* sh = sg + n;                                // [256][NC]
+    double* sg = reinterpret_cast<double*>(smem_raw);  // [256][NS]
+    double* sh = sg + kLevels * NS;                     // [256][NS]
     const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
     const double* grow = g + (size_t)lrow * n;
     for (int i = tid; i < n; i += 256) {
-        sh[i] = 0.0;
-        sg[i] = (mode != ROWPASS_COLSUM) ? grow[i] : 0.0;
+        const int xx = i / NC, bb = i - xx * NC;
+        sh[xx * NS + bb] = 0.0;
+        sg[xx * NS + bb] = (mode == ROWPASS_RECIP) ? grow[i] : 0.0;
     }
     __syncthreads();
     const int dr = r - gs.rowOff;
@@ -932,10 +935,12 @@ __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restr
 #pragma unroll
         for (int b = 0; b < NC; ++b) e[b] = ecT[(size_t)b * W + c];
         double y = 1.0;
-        if (mode != ROWPASS_COLSUM) {
+        if (mode == ROWPASS_XVEC) {  // apply: y_i = c_i x_i (c is 0 at sample pixels)
+            y = cvec[(size_t)lrow * W + c] * (double)xvec[(size_t)r * W + c];
+        } else if (mode == ROWPASS_RECIP) {
             double gv[NC];
 #pragma unroll
-            for (int b = 0; b < NC; ++b) gv[b] = sg[x * NC + b];
+            for (int b = 0; b < NC; ++b) gv[b] = sg[x * NS + b];
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int b = 0; b < NC; ++b) {
@@ -948,12 +953,94 @@ __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restr
         if (ybuf != nullptr) ybuf[(size_t)lrow * W + c] = y;
         if (y != 0.0) {
 #pragma unroll
-            for (int b = 0; b < NC; ++b) atomicAdd(&sh[x * NC + b], e[b] * y);
+            for (int b = 0; b < NC; ++b) atomicAdd(&sh[x * NS + b], e[b] * y);
         }
     }
     __syncthreads();
     double* hrow = hout + (size_t)lrow * n;
-    for (int i = tid; i < n; i += 256) hrow[i] = sh[i];
+    for (int i = tid; i < n; i += 256) {
+        const int xx = i / NC, bb = i - xx * NC;
+        hrow[i] = sh[xx * NS + bb];
+    }
+}
+
+// apply, expand half: out[i] = (float)(c_i * sum_b ec[c_i][b] g_r[x_i][b]) with g built from w' = D (f o t)
+template <int NC>
+__global__ __launch_bounds__(256) void k_hist_dot(const float* __restrict__ lum, GridSpec gs, int row0,
+                                                  const double* __restrict__ ecT, const double* __restrict__ g,
+                                                  const double* __restrict__ cvec, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int n = kLevels * NC;
+    const int W = gs.W;
+    double* sg = reinterpret_cast<double*>(smem_raw);  // [256][NC]
+    const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
+    const double* grow = g + (size_t)lrow * n;
+    for (int i = tid; i < n; i += 256) sg[i] = grow[i];
+    __syncthreads();
+    for (int c = tid; c < W; c += 256) {
+        const int x = (int)lum[(size_t)r * W + c];
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int b = 0; b < NC; ++b) {
+            const double t = ecT[(size_t)b * W + c] * sg[x * NC + b];
+            if (b & 1) s1 += t;
+            else s0 += t;
+        }
+        out[(size_t)lrow * W + c] = (float)(cvec[(size_t)lrow * W + c] * (s0 + s1));
+    }
+}
+
+// p-, K-sized half of the sample-space apply (one workgroup):
+//   t = D^T m + Vrows^T x_A,  W'[l] = D (resp_l o t),  YA[l][a] = Vrows[a] . (resp_l o t)
+// D, Vrows: p x ldk row-major fp64; m: p column sums sum_i k_i c_i x_i; x: the full image
+__global__ __launch_bounds__(256) void k_apply_small(int p, int K, int ldk, int L, int ldw, const double* __restrict__ m,
+                                                     const double* __restrict__ Dm, const double* __restrict__ Vrows,
+                                                     const float* __restrict__ x, const long long* __restrict__ sample_pix,
+                                                     const double* __restrict__ resp, double* __restrict__ t_out,
+                                                     double* __restrict__ Wp, double* __restrict__ YA) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* sm = reinterpret_cast<double*>(smem_raw);  // [p]
+    double* sx = sm + p;                                // [p]
+    double* st = sx + p;                                // [K]
+    const int tid = threadIdx.x;
+    for (int a = tid; a < p; a += 256) {
+        sm[a] = m[a];
+        sx[a] = (double)x[sample_pix[a]];
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int a = 0; a < p; ++a) {
+            s0 += Dm[(size_t)a * ldk + k] * sm[a];
+            s1 += Vrows[(size_t)a * ldk + k] * sx[a];
+        }
+        st[k] = s0 + s1;
+        t_out[k] = s0 + s1;
+    }
+    __syncthreads();
+    for (int o = tid; o < L * ldw; o += 256) {
+        const int l = o / ldw, a = o - l * ldw;
+        double w = 0.0, ya = 0.0;
+        if (a < p) {
+            const double* rl = resp + (size_t)l * K;
+            for (int k = 0; k < K; ++k) {
+                const double gk = rl[k] * st[k];
+                w += Dm[(size_t)a * ldk + k] * gk;
+                ya += Vrows[(size_t)a * ldk + k] * gk;
+            }
+            YA[(size_t)l * p + a] = ya;
+        }
+        Wp[o] = w;
+    }
+}
+
+// Y[l][loc[a]] = YA[l][a] for the samples this rank owns (loc < 0: not local)
+__global__ void k_scatter_samples(int p, int L, const long long* __restrict__ loc, const double* __restrict__ YA,
+                                  float* __restrict__ Y, long long ystride) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= L * p) return;
+    const int l = o / p, a = o - l * p;
+    if (loc[a] >= 0) Y[(size_t)l * ystride + loc[a]] = (float)YA[o];
 }
 
 // grid (ceil(256 nC / 256), nslabs): HH[slab][col][a], col = x*nC + b
@@ -1021,7 +1108,7 @@ size_t hist_tiled_workspace_elems(GridSpec gs, int nrows_local) {
 hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec gs, int p, int ldp, int row0,
                            int nrows_local, const double* d_er, const double* d_ecT, const double* d_Ep,
                            const double* d_w, double eps, double* d_ybuf, double* d_ws, double* d_z,
-                           LaunchObserver* obs) {
+                           LaunchObserver* obs, const double* d_cvec, const float* d_xvec) {
     const int nC = gs.nSelCols, nR = gs.nSelRows;
     if (nC > 36 || nR > 32) return hipErrorInvalidValue;
     struct Scope {
@@ -1034,7 +1121,7 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
     double* d_g = d_ws;
     double* d_h = d_g + (size_t)nrows_local * n;
     double* d_HH = d_h + (size_t)nrows_local * n;
-    if (mode != ROWPASS_COLSUM) {
+    if (mode == ROWPASS_RECIP) {
         Scope sc(obs, SUB_HIST_G);
         const size_t shm_g = ((size_t)8 * p + (size_t)32 * nR) * sizeof(double);
         if (shm_g > 48 * 1024) {
@@ -1049,13 +1136,14 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
         Scope sc(obs, SUB_HIST_PIX);
 #define NLE_HP(NCV)                                                                                                 \
     case NCV:                                                                                                       \
-        hipLaunchKernelGGL((k_hist_pix<NCV>), dim3((unsigned)nrows_local), dim3(256), 2 * n * sizeof(double), s, mode, \
-                           d_lum, gs, row0, d_ecT, d_g, eps, d_ybuf, d_h);                                          \
+        hipLaunchKernelGGL((k_hist_pix<NCV>), dim3((unsigned)nrows_local), dim3(256),                              \
+                           (size_t)2 * kLevels * ((NCV) | 1) * sizeof(double), s, mode,                            \
+                           d_lum, gs, row0, d_ecT, d_g, eps, d_ybuf, d_h, d_cvec, d_xvec);                          \
         break;
         if (nC > 11) {
             hipError_t ea = hipSuccess;
             switch (nC) {  // > 64 KB of LDS: raise the limit of the instantiation that is about to run
-#define NLE_HPA(NCV) case NCV: ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_pix<NCV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * n * sizeof(double))); break;
+#define NLE_HPA(NCV) case NCV: ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_pix<NCV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kLevels * ((NCV) | 1) * sizeof(double))); break;
                 NLE_HPA(12) NLE_HPA(13) NLE_HPA(14) NLE_HPA(15) NLE_HPA(16) NLE_HPA(17) NLE_HPA(18) NLE_HPA(19) NLE_HPA(20)
                 NLE_HPA(21) NLE_HPA(22) NLE_HPA(23) NLE_HPA(24) NLE_HPA(25) NLE_HPA(26) NLE_HPA(27) NLE_HPA(28) NLE_HPA(29)
                 NLE_HPA(30) NLE_HPA(31) NLE_HPA(32) NLE_HPA(33) NLE_HPA(34) NLE_HPA(35) NLE_HPA(36)
@@ -1077,6 +1165,62 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
     hipLaunchKernelGGL(k_hist_hh, dim3((unsigned)((n + 255) / 256), (unsigned)nslabs), dim3(256), 0, s, nC, nR,
                        nrows_local, slab_rows, d_er, d_h, d_HH);
     hipLaunchKernelGGL(k_hist_z, dim3((unsigned)ldp), dim3(kLevels), 0, s, p, ldp, nC, nR, nslabs, d_Ep, d_HH, d_z);
+    return hipGetLastError();
+}
+
+// expand half of the sample-space apply for one layer: g tables from w' (ldp doubles), then the dot kernel
+hipError_t apply_hist_layer(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
+                            const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_wl,
+                            const double* d_c, double* d_ws, float* d_out, LaunchObserver* obs) {
+    const int nC = gs.nSelCols, nR = gs.nSelRows;
+    if (nC > 36 || nR > 32 || nrows_local <= 0) return nrows_local <= 0 ? hipSuccess : hipErrorInvalidValue;
+    const size_t n = (size_t)kLevels * nC;
+    double* d_g = d_ws;
+    if (obs) obs->begin(SUB_HIST_G);
+    const size_t shm_g = ((size_t)8 * p + (size_t)32 * nR) * sizeof(double);
+    if (shm_g > 48 * 1024) {
+        hipError_t eg = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_g),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_g);
+        if (eg != hipSuccess) return eg;
+    }
+    hipLaunchKernelGGL(k_hist_g, dim3((unsigned)((nrows_local + 31) / 32), kLevels / 8), dim3(256), shm_g, s, gs, p,
+                       nrows_local, d_er, d_Ep, d_wl, d_g);
+    if (obs) obs->end(), obs->begin(SUB_HIST_PIX);
+#define NLE_HD(NCV)                                                                                                  \
+    case NCV: {                                                                                                      \
+        if (n * sizeof(double) > 48 * 1024) {                                                                        \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_dot<NCV>),                      \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(n * sizeof(double))); \
+            if (ea != hipSuccess) return ea;                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_hist_dot<NCV>), dim3((unsigned)nrows_local), dim3(256), n * sizeof(double), s, d_lum, gs, \
+                           row0, d_ecT, d_g, d_c, d_out);                                                            \
+    } break;
+    switch (nC) {
+        NLE_HD(1) NLE_HD(2) NLE_HD(3) NLE_HD(4) NLE_HD(5) NLE_HD(6) NLE_HD(7) NLE_HD(8) NLE_HD(9) NLE_HD(10) NLE_HD(11)
+        NLE_HD(12) NLE_HD(13) NLE_HD(14) NLE_HD(15) NLE_HD(16) NLE_HD(17) NLE_HD(18) NLE_HD(19) NLE_HD(20)
+        NLE_HD(21) NLE_HD(22) NLE_HD(23) NLE_HD(24) NLE_HD(25) NLE_HD(26) NLE_HD(27) NLE_HD(28) NLE_HD(29)
+        NLE_HD(30) NLE_HD(31) NLE_HD(32) NLE_HD(33) NLE_HD(34) NLE_HD(35) NLE_HD(36)
+        default: return hipErrorInvalidValue;
+    }
+#undef NLE_HD
+    if (obs) obs->end();
+    return hipGetLastError();
+}
+
+hipError_t apply_small(hipStream_t s, int p, int K, int ldk, int L, int ldw, const double* d_m, const double* d_D,
+                       const double* d_Vrows, const float* d_x, const long long* d_sample_pix, const double* d_resp,
+                       double* d_t, double* d_Wp, double* d_YA) {
+    const size_t shm = (size_t)(2 * p + K) * sizeof(double);
+    hipLaunchKernelGGL(k_apply_small, dim3(1), dim3(256), shm, s, p, K, ldk, L, ldw, d_m, d_D, d_Vrows, d_x,
+                       d_sample_pix, d_resp, d_t, d_Wp, d_YA);
+    return hipGetLastError();
+}
+
+hipError_t scatter_samples(hipStream_t s, int p, int L, const long long* d_loc, const double* d_YA, float* d_Y,
+                           long long ystride) {
+    hipLaunchKernelGGL(k_scatter_samples, dim3((unsigned)((L * p + 255) / 256)), dim3(256), 0, s, p, L, d_loc, d_YA, d_Y,
+                       ystride);
     return hipGetLastError();
 }
 

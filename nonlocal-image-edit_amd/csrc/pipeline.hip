@@ -14,6 +14,7 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/nle.h"
@@ -60,10 +61,24 @@ struct nle_filter {
     int H = 0, W = 0, row0 = 0, row1 = 0;
     long long n_local = 0;
     int K = 0, ldv = 0, r = 0, p = 0;
-    float* d_V = nullptr;
+    float* d_V = nullptr;  // m_eigvecs (n_local x ldv fp32); in the lazy form it is materialised on first request
     size_t v_bytes = 0;
     std::vector<double> eigvals;
     double ms[6] = {0, 0, 0, 0, 0, 0};
+    // Lazy / sample-space form (tables formulation): m_eigvecs is the implicit V = diag(c) K D.  apply()
+    // works on the p-sized side of it (t = D^T sum_i k_i c_i x_i, y = c_i k_i . D(f o t)) and never needs
+    // the N x K' matrix; nle_filter_eigvecs & co. build it on demand with the projection kernel.
+    bool lazy = false;
+    nlek::GridSpec gs{};
+    float nsw = 0.f, npw = 0.f;
+    int ldd = 0, P64 = 0;
+    float* d_lum = nullptr;  // this rank's slab of the training luminance
+    double *d_c = nullptr, *d_er = nullptr, *d_ecT = nullptr, *d_Ep = nullptr, *d_D = nullptr, *d_Vrows = nullptr;
+    float4* d_samples = nullptr;
+    long long *d_sample_pix = nullptr, *d_sample_loc = nullptr;
+    std::vector<std::pair<void*, size_t>> owned;  // workspace-cache buffers that live as long as the filter
+    std::vector<double> h_Vrows;                  // p x K col-major: exact rows of V at the sample pixels
+    std::vector<long long> h_sample_pix;
 };
 
 static thread_local std::string g_create_err;
@@ -816,12 +831,12 @@ std::vector<double> unpack_tiles(const std::vector<double>& tiles, int ld, int n
     return G;
 }
 
-void scatter_sample_rows(nle_ctx* c, const SampleSet& ss, int nrows, const std::vector<double>& rows_cm, int ldrows,
-                         int K, int ldv, long long pix0, long long M, float* d_V) {
+void scatter_sample_rows(nle_ctx* c, const std::vector<long long>& pix, int nrows, const std::vector<double>& rows_cm,
+                         int ldrows, int K, int ldv, long long pix0, long long M, float* d_V) {
     std::vector<float> rows;
     std::vector<long long> idx;
     for (int a = 0; a < nrows; ++a) {
-        const long long loc = ss.pix[a] - pix0;
+        const long long loc = pix[a] - pix0;
         if (loc < 0 || loc >= M) continue;
         idx.push_back(loc);
         const size_t off = rows.size();
@@ -871,7 +886,7 @@ void train_materialised(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     DevBuf<float> d_V((size_t)std::max<long long>(M, 1) * f->ldv);
     PROFILED(c, NLE_K_PROJECT, nlek::ts_gemm(c->stream, false, d_phi.p, ny.ldr, nullptr, ss.gs, nullptr, 0.f, 0.f, 0,
                                              d_Cp.p, f->ldv, ny.r, d_V.p, f->ldv, M, d_u_c.p, NLE_EPS));
-    scatter_sample_rows(c, ss, o.q, o.VArows, o.q, o.K, f->ldv, pix0, M, d_V.p);
+    scatter_sample_rows(c, ss.pix, o.q, o.VArows, o.q, o.K, f->ldv, pix0, M, d_V.p);
     tm_p.stop();
     HIP_OK(hipStreamSynchronize(c->stream));
     f->v_bytes = d_V.n * sizeof(float);
@@ -1014,14 +1029,62 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     tm_p.start();
     if (o.K > 128) throw Fail{NLE_ERR_INVALID, "Phi-free path supports at most 128 eigenvectors"};
     const int ldd = nlek::project64_ld(o.K);
-    std::vector<double> Dp((size_t)p * ldd, 0.0);
+    std::vector<double> Dp((size_t)p * ldd, 0.0), Vr((size_t)p * ldd, 0.0);
     for (int k = 0; k < o.K; ++k)
-        for (int a = 0; a < p; ++a) Dp[(size_t)a * ldd + k] = o.D[(size_t)k * p + a];
+        for (int a = 0; a < p; ++a) {
+            Dp[(size_t)a * ldd + k] = o.D[(size_t)k * p + a];
+            Vr[(size_t)a * ldd + k] = o.Vrows[(size_t)k * p + a];
+        }
     DevBuf<double> d_D(Dp.size());
     HIP_OK(hipMemcpyAsync(d_D.p, Dp.data(), Dp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const bool lazy = hist_tiled && std::getenv("NLE_EAGER_V") == nullptr;
+    if (lazy) {
+        // keep what defines V implicitly; the projection runs only if somebody asks for the matrix
+        auto own = [&](auto& buf) {
+            using T = std::remove_pointer_t<decltype(buf.p)>;
+            const size_t bytes = buf.n * sizeof(T);
+            T* ptr = buf.take();
+            f->owned.emplace_back(ptr, bytes);
+            return ptr;
+        };
+        DevBuf<double> d_Vr(Vr.size());
+        DevBuf<long long> d_spix(p), d_sloc(p);
+        DevBuf<float> d_slab((size_t)M);
+        std::vector<long long> sloc(p);
+        for (int a = 0; a < p; ++a) {
+            const long long loc = ss.pix[a] - pix0;
+            sloc[a] = (loc >= 0 && loc < M) ? loc : -1;
+        }
+        HIP_OK(hipMemcpyAsync(d_Vr.p, Vr.data(), Vr.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_spix.p, ss.pix.data(), p * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_sloc.p, sloc.data(), p * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_slab.p, d_lum + pix0, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));  // the host staging vectors go out of scope
+        f->lazy = true;
+        f->gs = ss.gs;
+        f->nsw = nsw;
+        f->npw = npw;
+        f->ldd = ldd;
+        f->P64 = P64;
+        f->d_lum = own(d_slab);
+        f->d_c = own(d_cbuf);
+        f->d_er = own(d_er);
+        f->d_ecT = own(d_ecT);
+        f->d_Ep = own(d_Ep);
+        f->d_D = own(d_D);
+        f->d_Vrows = own(d_Vr);
+        f->d_samples = own(d_samples);
+        f->d_sample_pix = own(d_spix);
+        f->d_sample_loc = own(d_sloc);
+        f->h_Vrows = o.Vrows;
+        f->h_sample_pix = ss.pix;
+        tm_p.stop();
+        ms->sinkhorn = tm_s.ms();
+        ms->gram = tm_g.ms();
+        ms->project = tm_p.ms();
+        return;
+    }
     DevBuf<float> d_V((size_t)std::max<long long>(M, 1) * f->ldv);
-    // the table form of the projection (k_project_hist) is correct but latency-bound (one workgroup per
-    // CU, 64 serial level batches): 20 ms vs 10 ms for the fp64-MFMA kernel at cfg4 -- opt-in only
     if (hist && nlek::project_hist_ok(ss.gs, p, o.K) && std::getenv("NLE_PROJECT_HIST") != nullptr)
         PROFILED(c, NLE_K_PROJECT, nlek::project_hist(c->stream, d_lum, ss.gs, p, row0, nrows_local, d_er.p, d_ecT.p,
                                                       d_Ep.p, d_D.p, ldd, o.K, d_cbuf.p, d_V.p, f->ldv));
@@ -1029,7 +1092,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         PROFILED(c, NLE_K_PROJECT, nlek::project64(c->stream, d_lum, ss.gs, d_samples.p, p, nsw, npw, pix0, M, d_D.p, o.K,
                                                    d_cbuf.p, d_V.p, f->ldv));
     tr.mark("ss: project enqueued");
-    scatter_sample_rows(c, ss, p, o.Vrows, p, o.K, f->ldv, pix0, M, d_V.p);
+    scatter_sample_rows(c, ss.pix, p, o.Vrows, p, o.K, f->ldv, pix0, M, d_V.p);
     tm_p.stop();
     HIP_OK(hipStreamSynchronize(c->stream));
     tr.mark("ss: project sync");
@@ -1038,6 +1101,54 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     ms->sinkhorn = tm_s.ms();
     ms->gram = tm_g.ms();
     ms->project = tm_p.ms();
+}
+
+// materialise V = diag(c) K D of a lazy filter (projection kernel + exact sample rows)
+void ensure_V(nle_filter* f) {
+    if (f->d_V || !f->lazy) return;
+    nle_ctx* c = f->ctx;
+    const long long M = f->n_local, pix0 = (long long)f->row0 * f->W;
+    DevBuf<float> d_V((size_t)std::max<long long>(M, 1) * f->ldv);
+    PROFILED(c, NLE_K_PROJECT, nlek::project64(c->stream, f->d_lum - pix0, f->gs, f->d_samples, f->p, f->nsw, f->npw, pix0,
+                                               M, f->d_D, f->K, f->d_c, d_V.p, f->ldv));
+    scatter_sample_rows(c, f->h_sample_pix, f->p, f->h_Vrows, f->p, f->K, f->ldv, pix0, M, d_V.p);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    f->v_bytes = d_V.n * sizeof(float);
+    f->d_V = d_V.take();
+}
+
+// apply on the p-sized side of a lazy filter: reduce half (column sums m = sum_i k_i c_i x_i through the
+// tables), the p/K-sized middle (k_apply_small), and one table pass per output layer
+void apply_sample_space(nle_filter* f, const float* d_x, const double* h_g /* L x K */, int L, float* d_y) {
+    nle_ctx* c = f->ctx;
+    const long long M = f->n_local, pix0 = (long long)f->row0 * f->W;
+    const int p = f->p, K = f->K, P64 = f->P64, nrows_local = (int)(M / f->W);
+    const float* lum = f->d_lum - pix0;  // indexed by global pixel, only this rank's rows are touched
+    DevBuf<double> d_ws(std::max<size_t>(nlek::hist_tiled_workspace_elems(f->gs, std::max(nrows_local, 1)), 1)), d_m(P64),
+        d_resp((size_t)L * K), d_t(K), d_Wp((size_t)L * P64), d_YA((size_t)L * p);
+    HIP_OK(hipMemcpyAsync(d_resp.p, h_g, (size_t)L * K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (M > 0) {
+        static const int rmap[4] = {NLE_K_SINK_TABLES, NLE_K_APPLY_REDUCE, NLE_K_REDUCE, NLE_K_REDUCE};
+        ProfObserver obs(c, rmap);
+        HIP_OK(nlek::sink_hist_tiled(c->stream, nlek::ROWPASS_XVEC, lum, f->gs, p, P64, f->row0, nrows_local, f->d_er,
+                                     f->d_ecT, f->d_Ep, nullptr, NLE_EPS, nullptr, d_ws.p, d_m.p, &obs, f->d_c, d_x));
+    } else {
+        HIP_OK(hipMemsetAsync(d_m.p, 0, P64 * sizeof(double), c->stream));
+    }
+    all_reduce(c, d_m.p, P64);
+    PROFILED(c, NLE_K_SMALL, nlek::apply_small(c->stream, p, K, f->ldd, L, P64, d_m.p, f->d_D, f->d_Vrows, d_x,
+                                               f->d_sample_pix, d_resp.p, d_t.p, d_Wp.p, d_YA.p));
+    if (M > 0) {
+        static const int emap[4] = {NLE_K_SINK_TABLES, NLE_K_APPLY_EXPAND, NLE_K_REDUCE, NLE_K_REDUCE};
+        for (int l = 0; l < L; ++l) {
+            ProfObserver obs(c, emap);
+            HIP_OK(nlek::apply_hist_layer(c->stream, lum, f->gs, p, f->row0, nrows_local, f->d_er, f->d_ecT, f->d_Ep,
+                                          d_Wp.p + (size_t)l * P64, f->d_c, d_ws.p, d_y + (size_t)l * M, &obs));
+        }
+        PROFILED(c, NLE_K_SMALL, nlek::scatter_samples(c->stream, p, L, f->d_sample_loc, d_YA.p, d_y, M));
+    }
+    HIP_OK(hipStreamSynchronize(c->stream));
+    prof_flush(c);
 }
 
 nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, int nCol, double hx,
@@ -1121,6 +1232,11 @@ void apply_impl(nle_filter* f, const float* d_x, int H, int W, const double* h_g
         throw Fail{NLE_ERR_INVALID, "Number of values in channel must match that of training image."};
     if (L < 1 || L > 64) throw Fail{NLE_ERR_INVALID, "number of layers must be in [1, 64]"};
     HIP_OK(hipSetDevice(c->device));
+    if (f->lazy && std::getenv("NLE_APPLY_WITH_V") == nullptr) {
+        apply_sample_space(f, d_x, h_g, L, d_y);
+        return;
+    }
+    ensure_V(f);
     const int ld = f->ldv;
     const long long M = f->n_local;
     const long long pix0 = (long long)f->row0 * f->W;
@@ -1502,6 +1618,7 @@ void nle_filter_destroy(nle_filter* f) {
     if (!f) return;
     if (f->ctx) f->ctx->filters.erase(f);
     if (f->d_V) arena_release(f->ctx, f->d_V, f->v_bytes);  // back to the ctx's workspace cache (or hipFree)
+    for (auto& b : f->owned) arena_release(f->ctx, b.first, b.second);
     delete f;
 }
 
@@ -1527,6 +1644,7 @@ int nle_filter_eigvec_range(const nle_filter* f, int ncols, double* h_min, doubl
     return guard(f->ctx, [&] {
         nle_ctx* c = f->ctx;
         HIP_OK(hipSetDevice(c->device));
+        ensure_V(const_cast<nle_filter*>(f));
         const int nb = 256;
         DevBuf<float> d_out((size_t)nb * 2 * ncols);
         HIP_OK(nlek::col_range(c->stream, f->d_V, f->n_local, f->ldv, ncols, d_out.p, nb));
@@ -1546,7 +1664,12 @@ int nle_filter_eigvec_range(const nle_filter* f, int ncols, double* h_min, doubl
 }
 
 int nle_filter_eigvecs(const nle_filter* f, const float** d_V, int* ld) {
-    if (!f || !d_V || !ld) return NLE_ERR_INVALID;
+    if (!f || !f->ctx || !d_V || !ld) return NLE_ERR_INVALID;
+    const int st = guard(f->ctx, [&] {
+        HIP_OK(hipSetDevice(f->ctx->device));
+        ensure_V(const_cast<nle_filter*>(f));
+    });
+    if (st != NLE_OK) return st;
     *d_V = f->d_V;
     *ld = f->ldv;
     return NLE_OK;
@@ -1556,6 +1679,7 @@ int nle_filter_copy_eigvecs(const nle_filter* f, float* d_out) {
     if (!f || !f->ctx || !d_out) return NLE_ERR_INVALID;
     return guard(f->ctx, [&] {
         HIP_OK(hipSetDevice(f->ctx->device));
+        ensure_V(const_cast<nle_filter*>(f));
         HIP_OK(hipMemcpyAsync(d_out, f->d_V, (size_t)f->n_local * f->ldv * sizeof(float), hipMemcpyDeviceToDevice,
                               f->ctx->stream));
         HIP_OK(hipStreamSynchronize(f->ctx->stream));
