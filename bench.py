@@ -99,13 +99,22 @@ def load_traffic():
     return out
 
 
-KERNEL_SYMBOLS = {  # bench kernel name -> substring of the HIP kernel symbol (for the PMC table)
-    "project": ("k_project64_res", "k_project64", "k_tsgemm<2, false>"),
-    "sinkhorn_pass": ("k_hist_pix", "k_sink_pass", "k_rowpass<8"),
-    "gram_gemm": ("k_ghist_gemm",), "gram_rows": ("k_ghist_rows",), "sink_tables": ("k_hist_g",),
-    "gram": ("k_gram64", "k_gram("), "nystrom_extend": ("k_tsgemm<7, true>",),
-    "apply_expand": ("k_apply_expand",), "apply_reduce": ("k_rowpass<4",),
-}
+def kernel_symbols(form, lazy):
+    """bench kernel name -> substrings of the HIP kernel symbol that ran for it (for the PMC table)"""
+    if form == "materialised":
+        return {"nystrom_extend": ("k_tsgemm<7, true>",), "sinkhorn_pass": ("k_rowpass<8",), "gram": ("k_gram(",),
+                "project": ("k_tsgemm<2, false>",), "apply_expand": ("k_apply_expand",),
+                "apply_reduce": ("k_rowpass<4",), "affinity": ("k_affinity",)}
+    sym = {"project": ("k_project64_res", "k_project64"), "apply_expand": ("k_apply_expand",),
+           "apply_reduce": ("k_rowpass<4",)}
+    if form == "phi_free_exp":
+        sym.update({"sinkhorn_pass": ("k_sink_pass",), "gram": ("k_gram64",)})
+    else:
+        sym.update({"sinkhorn_pass": ("k_hist_pix",), "sink_tables": ("k_hist_g",), "gram_rows": ("k_ghist_rows",),
+                    "gram_gemm": ("k_ghist_gemm",)})
+        if lazy:  # the apply's reduce half is k_hist_pix in its XVEC mode: same symbol as the Sinkhorn pass
+            sym.update({"apply_expand": ("k_hist_dot",), "apply_reduce": ("k_hist_pix",)})
+    return sym
 
 
 def main():
@@ -215,7 +224,7 @@ def main():
             if name == "sinkhorn_pass" and form != "materialised":
                 rec["hbm_equivalent_GBs"] = info["n_local"] * info["r"] * 4.0 / (avg_ms * 1e-3) / 1e9
             rec["traffic"] = None
-            for sym in KERNEL_SYMBOLS.get(name, ()):
+            for sym in kernel_symbols(form, lazy).get(name, ()):
                 hit = [v for k, v in traffic.items() if sym in k]
                 if hit:
                     rec["traffic"] = hit[0]

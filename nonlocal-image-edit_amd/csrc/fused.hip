@@ -724,6 +724,54 @@ constexpr int kLevels = 256;
 
 int sink_hist_max_cols() { return 36; }  // 2 * 256 * nC doubles of LDS
 
+// ---- wave-level pre-reduction for the LDS histograms
+// Flat image regions put many lanes of a wave on ONE histogram level, and same-address LDS atomics
+// serialise (a flat row ran the pass 4.5x slower than a noisy one).  Before the atomics, up to
+// kGroupRounds levels that at least kGroupMin lanes of the wave share are summed across the wave on
+// the VALU (DPP) and added once by lane 63; the remaining lanes use their own atomics.
+constexpr int kGroupMin = 12;
+constexpr int kGroupRounds = 3;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {  // lanes without a source (or masked rows) read 0
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, valid in lane 63 (all lanes must be active)
+__device__ __forceinline__ double wave_sum63(double v) {
+    v += dpp_f64<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_f64<0x140, 0xf>(v);  // row_mirror: every lane holds its row's sum
+    v += dpp_f64<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
+    return v;
+}
+// Calls grouped(level, mine) for each level handled by a wave sum (wave-uniform call, `mine` marks the
+// lanes of that level) and returns whether this lane still has to add its own value.
+template <class G>
+__device__ __forceinline__ bool wave_group_levels(bool active, int x, G&& grouped) {
+    bool pend = active, tried = false;
+#pragma unroll 1
+    for (int round = 0; round < kGroupRounds; ++round) {
+        const unsigned long long cand = __ballot(pend && !tried);
+        if (cand == 0) break;
+        const int lx = __builtin_amdgcn_readlane(x, __ffsll((long long)cand) - 1);
+        const bool mine = pend && x == lx;
+        const int cnt = __popcll(__ballot(mine));
+        if (cnt >= kGroupMin) {
+            grouped(lx, mine);
+            if (mine) pend = false;
+        } else {
+            if (cnt < 3) break;  // a noisy stretch: no point in trying further leaders
+            if (mine) tried = true;
+        }
+    }
+    return pend;
+}
+
 __global__ __launch_bounds__(256) void k_check_levels(const float* __restrict__ lum, long long n,
                                                       int* __restrict__ flag) {
     bool bad = false;
@@ -924,12 +972,14 @@ __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restr
     __syncthreads();
     const int dr = r - gs.rowOff;
     const bool sample_row = dr >= 0 && (dr % gs.rowStep) == 0 && (dr / gs.rowStep) < gs.nSelRows;
-    for (int c = tid; c < W; c += 256) {
+    for (int c0 = 0; c0 < W; c0 += 256) {  // wave-uniform trip count: the body uses cross-lane sums
+        const bool inside = c0 + tid < W;
+        const int c = inside ? c0 + tid : W - 1;
         const int x = (int)lum[(size_t)r * W + c];
-        bool smp = false;
+        bool smp = !inside;
         if (sample_row) {
             const int dc = c - gs.colOff;
-            smp = dc >= 0 && (dc % gs.colStep) == 0 && (dc / gs.colStep) < NC;
+            smp = smp || (dc >= 0 && (dc % gs.colStep) == 0 && (dc / gs.colStep) < NC);
         }
         double e[NC];
 #pragma unroll
@@ -950,8 +1000,15 @@ __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restr
             y = recip_or_zero_d(s0 + s1, eps);
         }
         if (smp) y = 0.0;
-        if (ybuf != nullptr) ybuf[(size_t)lrow * W + c] = y;
-        if (y != 0.0) {
+        if (ybuf != nullptr && inside) ybuf[(size_t)lrow * W + c] = y;
+        const bool own = wave_group_levels(y != 0.0, x, [&](int lx, bool mine) {
+#pragma unroll
+            for (int b = 0; b < NC; ++b) {
+                const double t = wave_sum63(mine ? e[b] * y : 0.0);
+                if ((tid & 63) == 63) atomicAdd(&sh[lx * NS + b], t);
+            }
+        });
+        if (own) {
 #pragma unroll
             for (int b = 0; b < NC; ++b) atomicAdd(&sh[x * NS + b], e[b] * y);
         }
@@ -1247,20 +1304,36 @@ __global__ __launch_bounds__(256) void k_ghist_rows(const float* __restrict__ lu
     const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
     for (int i = tid; i < kLevels * NP; i += 256) A[i] = 0.0;
     __syncthreads();
-    for (int c = tid; c < W; c += 256) {
-        const double cf = cvec[(size_t)lrow * W + c];  // 0 at sample pixels
-        if (cf == 0.0) continue;
+    for (int c0 = 0; c0 < W; c0 += 256) {  // wave-uniform trip count: the body uses cross-lane sums
+        const bool inside = c0 + tid < W;
+        const int c = inside ? c0 + tid : W - 1;
+        const double cf = inside ? cvec[(size_t)lrow * W + c] : 0.0;  // 0 at sample pixels
         const int x = (int)lum[(size_t)r * W + c];
         double q[11];
 #pragma unroll
         for (int b = 0; b < 11; ++b) q[b] = (b < nC) ? cf * ecT[(size_t)b * W + c] : 0.0;
-        double* Ax = A + (size_t)x * NP;
-        int idx = 0;
+        const bool own = wave_group_levels(cf != 0.0, x, [&](int lx, bool mine) {
+            double* Al = A + (size_t)lx * NP;
+            int idx = 0;
 #pragma unroll
-        for (int b = 0; b < 11; ++b)
+            for (int b = 0; b < 11; ++b)
 #pragma unroll
-            for (int b2 = b; b2 < 11; ++b2)
-                if (b2 < nC) atomicAdd(&Ax[idx++], q[b] * q[b2]);
+                for (int b2 = b; b2 < 11; ++b2)
+                    if (b2 < nC) {
+                        const double t = wave_sum63(mine ? q[b] * q[b2] : 0.0);
+                        if ((tid & 63) == 63) atomicAdd(&Al[idx], t);
+                        ++idx;
+                    }
+        });
+        if (own) {
+            double* Ax = A + (size_t)x * NP;
+            int idx = 0;
+#pragma unroll
+            for (int b = 0; b < 11; ++b)
+#pragma unroll
+                for (int b2 = b; b2 < 11; ++b2)
+                    if (b2 < nC) atomicAdd(&Ax[idx++], q[b] * q[b2]);
+        }
     }
     __syncthreads();
     double* out = Aout + (size_t)lrow * kLevels * NP;
@@ -1284,21 +1357,40 @@ __global__ __launch_bounds__(256) void k_ghist_rows_chunk(const float* __restric
     const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
     for (int i = tid; i < kLevels * npairs; i += 256) A[i] = 0.0;
     __syncthreads();
-    for (int c = tid; c < W; c += 256) {
-        const double cf = cvec[(size_t)lrow * W + c];  // 0 at sample pixels
-        if (cf == 0.0) continue;
+    for (int c0 = 0; c0 < W; c0 += 256) {  // wave-uniform trip count: the body uses cross-lane sums
+        const bool inside = c0 + tid < W;
+        const int c = inside ? c0 + tid : W - 1;
+        const double cf = inside ? cvec[(size_t)lrow * W + c] : 0.0;  // 0 at sample pixels
         const int x = (int)lum[(size_t)r * W + c];
         double q[kGhistMaxCols];
 #pragma unroll
         for (int b = 0; b < kGhistMaxCols; ++b) q[b] = (b < nC) ? cf * ecT[(size_t)b * W + c] : 0.0;
-        double* Ax = A + (size_t)x * npairs;
-        int idx = 0;
+        const bool own = wave_group_levels(cf != 0.0, x, [&](int lx, bool mine) {
+            double* Al = A + (size_t)lx * npairs;
+            int idx = 0;
 #pragma unroll
-        for (int b = 0; b < kGhistMaxCols; ++b) {
-            if (b >= b0 && b < b1) {  // wave-uniform
+            for (int b = 0; b < kGhistMaxCols; ++b) {
+                if (b >= b0 && b < b1) {  // wave-uniform
 #pragma unroll
-                for (int b2 = b; b2 < kGhistMaxCols; ++b2)
-                    if (b2 < nC) atomicAdd(&Ax[idx++], q[b] * q[b2]);
+                    for (int b2 = b; b2 < kGhistMaxCols; ++b2)
+                        if (b2 < nC) {
+                            const double t = wave_sum63(mine ? q[b] * q[b2] : 0.0);
+                            if ((tid & 63) == 63) atomicAdd(&Al[idx], t);
+                            ++idx;
+                        }
+                }
+            }
+        });
+        if (own) {
+            double* Ax = A + (size_t)x * npairs;
+            int idx = 0;
+#pragma unroll
+            for (int b = 0; b < kGhistMaxCols; ++b) {
+                if (b >= b0 && b < b1) {  // wave-uniform
+#pragma unroll
+                    for (int b2 = b; b2 < kGhistMaxCols; ++b2)
+                        if (b2 < nC) atomicAdd(&Ax[idx++], q[b] * q[b2]);
+                }
             }
         }
     }
