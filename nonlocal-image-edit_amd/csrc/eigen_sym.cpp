@@ -179,7 +179,110 @@ NLE_SIMD_CLONES bool ql_implicit(int n, double* V, double* d, double* e) {
     return true;
 }
 
+// right-looking Cholesky on the lower triangle, column-major (all inner loops unit stride)
+NLE_SIMD_CLONES bool cholesky_lower(int n, double* A) {
+    for (int j = 0; j < n; ++j) {
+        const double djj = at(A, n, j, j);
+        if (!(djj > 0.0)) return false;
+        const double d = std::sqrt(djj), inv = 1.0 / d;
+        double* cj = &at(A, n, 0, j);
+        cj[j] = d;
+#pragma omp simd
+        for (int i = j + 1; i < n; ++i) cj[i] *= inv;
+        for (int k = j + 1; k < n; ++k) {
+            const double l = cj[k];
+            double* ck = &at(A, n, 0, k);
+#pragma omp simd
+            for (int i = k; i < n; ++i) ck[i] -= l * cj[i];
+        }
+    }
+    return true;
+}
+
+// X = L^-1 by column-oriented forward substitution (X lower triangular)
+NLE_SIMD_CLONES void lower_inverse(int n, const double* L, double* X) {
+    for (int j = 0; j < n; ++j) {
+        double* x = X + (size_t)j * n;
+        for (int i = 0; i < n; ++i) x[i] = 0.0;
+        x[j] = 1.0;
+        for (int k = j; k < n; ++k) {
+            const double* lk = L + (size_t)k * n;
+            const double xk = x[k] / lk[k];
+            x[k] = xk;
+#pragma omp simd
+            for (int i = k + 1; i < n; ++i) x[i] -= xk * lk[i];
+        }
+    }
+}
+
 }  // namespace
+
+NLE_SIMD_CLONES void gemm_nn_cols(const double* A, const double* B, double* C, int m, int k, int n, int j0, int j1) {
+    (void)n;
+    for (int j = j0; j < j1; ++j) {
+        double* cc = C + (size_t)j * m;
+        std::fill(cc, cc + m, 0.0);
+        int l = 0;
+        for (; l + 3 < k; l += 4) {  // four columns of A per sweep over the output column
+            const double b0 = B[(size_t)j * k + l], b1 = B[(size_t)j * k + l + 1], b2 = B[(size_t)j * k + l + 2],
+                         b3 = B[(size_t)j * k + l + 3];
+            const double *a0 = A + (size_t)l * m, *a1 = a0 + m, *a2 = a1 + m, *a3 = a2 + m;
+#pragma omp simd
+            for (int i = 0; i < m; ++i) cc[i] += (a0[i] * b0 + a1[i] * b1) + (a2[i] * b2 + a3[i] * b3);
+        }
+        for (; l < k; ++l) {
+            const double b = B[(size_t)j * k + l];
+            const double* a = A + (size_t)l * m;
+#pragma omp simd
+            for (int i = 0; i < m; ++i) cc[i] += a[i] * b;
+        }
+    }
+}
+
+NLE_SIMD_CLONES void gemm_nt_cols(const double* A, const double* B, double* C, int m, int k, int n, int j0, int j1) {
+    for (int j = j0; j < j1; ++j) {
+        double* cc = C + (size_t)j * m;
+        std::fill(cc, cc + m, 0.0);
+        int l = 0;
+        for (; l + 3 < k; l += 4) {
+            const double b0 = B[(size_t)l * n + j], b1 = B[(size_t)(l + 1) * n + j], b2 = B[(size_t)(l + 2) * n + j],
+                         b3 = B[(size_t)(l + 3) * n + j];
+            const double *a0 = A + (size_t)l * m, *a1 = a0 + m, *a2 = a1 + m, *a3 = a2 + m;
+#pragma omp simd
+            for (int i = 0; i < m; ++i) cc[i] += (a0[i] * b0 + a1[i] * b1) + (a2[i] * b2 + a3[i] * b3);
+        }
+        for (; l < k; ++l) {
+            const double b = B[(size_t)l * n + j];
+            const double* a = A + (size_t)l * m;
+#pragma omp simd
+            for (int i = 0; i < m; ++i) cc[i] += a[i] * b;
+        }
+    }
+}
+
+NLE_SIMD_CLONES void gemm_tn_cols(const double* A, const double* B, double* C, int m, int k, int n, int j0, int j1) {
+    (void)n;
+    for (int j = j0; j < j1; ++j)
+        for (int l = 0; l < k; ++l) {
+            const double* a = A + (size_t)l * m;
+            const double* b = B + (size_t)j * m;
+            double s = 0.0;
+#pragma omp simd reduction(+ : s)
+            for (int i = 0; i < m; ++i) s += a[i] * b[i];
+            C[(size_t)j * k + l] = s;
+        }
+}
+
+bool cholesky_with_inverse(const double* M, int n, double* L, double* Linv, double* inv_trace) {
+    for (int c = 0; c < n; ++c)
+        for (int r = 0; r < n; ++r) L[(size_t)c * n + r] = (r >= c) ? M[(size_t)c * n + r] : 0.0;
+    if (!cholesky_lower(n, L)) return false;
+    lower_inverse(n, L, Linv);
+    double t = 0.0;
+    for (size_t i = 0; i < (size_t)n * n; ++i) t += Linv[i] * Linv[i];
+    *inv_trace = t;
+    return std::isfinite(t);
+}
 
 bool sym_eigen(const double* M, int n, double* U, double* D) {
     if (n <= 0) return true;

@@ -12,4 +12,16 @@ bool sym_eigen(const double* M, int n, double* U, double* D);
 // filled but not part of the result).
 bool eigen_decomposition(const double* M, int n, double eps, double* U, double* D, int* r);
 
+// Cholesky factor of a symmetric positive definite matrix (lower triangle of M read): L is n x n
+// column-major lower triangular (zeros above the diagonal), Linv = L^-1 likewise.  Returns false if
+// a pivot is not positive.  *inv_trace = trace(M^-1) = ||Linv||_F^2, so every eigenvalue of M is at
+// least 1 / *inv_trace: the caller's proof that the reference's eigenvalue cut at eps removes nothing.
+bool cholesky_with_inverse(const double* M, int n, double* L, double* Linv, double* inv_trace);
+
+// Column ranges [j0, j1) of small column-major products (the caller splits columns over threads):
+//   nn: C (m x n) = A (m x k) B (k x n);  nt: C (m x n) = A (m x k) B^T (B n x k);  tn: C (k x n) = A^T B (A m x k, B m x n)
+void gemm_nn_cols(const double* A, const double* B, double* C, int m, int k, int n, int j0, int j1);
+void gemm_nt_cols(const double* A, const double* B, double* C, int m, int k, int n, int j0, int j1);
+void gemm_tn_cols(const double* A, const double* B, double* C, int m, int k, int n, int j0, int j1);
+
 }  // namespace nleh

@@ -1420,20 +1420,24 @@ __global__ void k_ghist_ee(const double* __restrict__ er, int nrows, int nR, int
     }
 }
 
-// C (ldm x N) = EE^T (K x ldm) * A (K x N); one 16-column tile per wave, MT m-tiles per wave
+// C[z] (ldm x N) = EE^T (rows [z ksplit, (z+1) ksplit) of K x ldm) * A (same rows of K x N); one 16-column
+// tile per wave, MT m-tiles per wave.  The image rows are split over gridDim.z so that the launch fills the
+// chip (N/64 blocks alone are fewer than the CUs); k_ghist_final adds the gridDim.z partial products in order.
 template <int MT>
 __global__ __launch_bounds__(256) void k_ghist_gemm(const double* __restrict__ EE, int ldm, const double* __restrict__ A,
-                                                    long long N, int K, double* __restrict__ C) {
+                                                    long long N, int Ktot, int ksplit, double* __restrict__ Cz) {
     constexpr int KB = 16;
     __shared__ __attribute__((aligned(16))) double sE[KB][MT * 16 + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const long long n0 = ((long long)blockIdx.x * 4 + wave) * 16;
     const int m0 = blockIdx.y * MT * 16;
     const bool ncol_ok = n0 + l15 < N;
+    const int kbeg = blockIdx.z * ksplit, K = min(Ktot, kbeg + ksplit);
+    double* C = Cz + (size_t)blockIdx.z * ldm * N;
     f64x4 acc[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[j] = f64x4{0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < K; k0 += KB) {
+    for (int k0 = kbeg; k0 < K; k0 += KB) {
         __syncthreads();
         for (int idx = tid; idx < KB * MT * 16; idx += 256) {
             const int kk = idx / (MT * 16), mm = idx % (MT * 16);
@@ -1460,8 +1464,9 @@ __global__ __launch_bounds__(256) void k_ghist_gemm(const double* __restrict__ E
     }
 }
 
-__global__ __launch_bounds__(256) void k_ghist_final(const double* __restrict__ C, long long N, const double* __restrict__ Ep,
-                                                     int p, int nR, int nC, double* __restrict__ Gk) {
+__global__ __launch_bounds__(256) void k_ghist_final(const double* __restrict__ C, long long N, int nsplit, size_t zstride,
+                                                     const double* __restrict__ Ep, int p, int nR, int nC,
+                                                     double* __restrict__ Gk) {
     const int NP = nC * (nC + 1) / 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)p * p) return;
@@ -1472,17 +1477,34 @@ __global__ __launch_bounds__(256) void k_ghist_final(const double* __restrict__ 
     const double* Cm = C + (size_t)m * N + pc;
     double t0 = 0.0, t1 = 0.0;
     for (int x = 0; x < kLevels; x += 2) {
-        t0 += Ep[(size_t)x * p + s1] * Ep[(size_t)x * p + s2] * Cm[(size_t)x * NP];
-        t1 += Ep[(size_t)(x + 1) * p + s1] * Ep[(size_t)(x + 1) * p + s2] * Cm[(size_t)(x + 1) * NP];
+        double c0 = 0.0, c1 = 0.0;
+        for (int z = 0; z < nsplit; ++z) {  // fixed order
+            c0 += Cm[z * zstride + (size_t)x * NP];
+            c1 += Cm[z * zstride + (size_t)(x + 1) * NP];
+        }
+        t0 += Ep[(size_t)x * p + s1] * Ep[(size_t)x * p + s2] * c0;
+        t1 += Ep[(size_t)(x + 1) * p + s1] * Ep[(size_t)(x + 1) * p + s2] * c1;
     }
     Gk[idx] = t0 + t1;  // column-major == row-major (symmetric)
 }
 
 int ghist_ldm(int nR) { return ((nR * (nR + 1) / 2) + 15) & ~15; }
+constexpr int kGhistMT = 14;
+// image rows per GEMM split (a multiple of the 16-row k step) and the number of splits: ~4 workgroups per CU
+static void ghist_split(long long N, int ldm, int nrows_local, int* ksplit, int* nsplit) {
+    const long long base = ((N / 16 + 3) / 4) * ((ldm / 16 + kGhistMT - 1) / kGhistMT);
+    int ns = (int)std::min<long long>(16, std::max<long long>(1, (1024 + base - 1) / base));
+    int ks = (((nrows_local + ns - 1) / ns) + 15) & ~15;
+    ks = std::max(ks, 16);
+    *ksplit = ks;
+    *nsplit = std::max(1, (nrows_local + ks - 1) / ks);
+}
 size_t ghist_workspace_elems(GridSpec gs, int nrows_local) {
     const size_t NP = (size_t)gs.nSelCols * (gs.nSelCols + 1) / 2, N = 256 * NP;
     const size_t ldm = (size_t)ghist_ldm(gs.nSelRows);
-    return (size_t)nrows_local * N + (size_t)nrows_local * ldm + ldm * N;
+    int ks, ns;
+    ghist_split((long long)N, (int)ldm, nrows_local, &ks, &ns);
+    return (size_t)nrows_local * N + (size_t)nrows_local * ldm + (size_t)ns * ldm * N;
 }
 
 // d_ws: ghist_workspace_elems doubles; d_Gk: p x p doubles (full symmetric matrix of this rank's rows)
@@ -1526,13 +1548,15 @@ hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int 
     }
     if (obs) obs->end(), obs->begin(SUB_GHIST_EE);
     hipLaunchKernelGGL(k_ghist_ee, dim3(512), dim3(256), 0, s, d_er, nrows_local, nR, ldm, d_EE);
-    constexpr int MT = 14;
-    const dim3 grid((unsigned)((N / 16 + 3) / 4), (unsigned)((ldm / 16 + MT - 1) / MT));
+    constexpr int MT = kGhistMT;
+    int ksplit, nsplit;
+    ghist_split(N, ldm, nrows_local, &ksplit, &nsplit);
+    const dim3 grid((unsigned)((N / 16 + 3) / 4), (unsigned)((ldm / 16 + MT - 1) / MT), (unsigned)nsplit);
     if (obs) obs->end(), obs->begin(SUB_GHIST_GEMM);
-    hipLaunchKernelGGL((k_ghist_gemm<MT>), grid, dim3(256), 0, s, d_EE, ldm, d_A, N, nrows_local, d_C);
+    hipLaunchKernelGGL((k_ghist_gemm<MT>), grid, dim3(256), 0, s, d_EE, ldm, d_A, N, nrows_local, ksplit, d_C);
     if (obs) obs->end(), obs->begin(SUB_GHIST_FINAL);
-    hipLaunchKernelGGL(k_ghist_final, dim3((unsigned)(((long long)p * p + 255) / 256)), dim3(256), 0, s, d_C, N, d_Ep, p,
-                       nR, nC, d_Gk);
+    hipLaunchKernelGGL(k_ghist_final, dim3((unsigned)(((long long)p * p + 255) / 256)), dim3(256), 0, s, d_C, N, nsplit,
+                       (size_t)ldm * N, d_Ep, p, nR, nC, d_Gk);
     if (obs) obs->end();
     return hipGetLastError();
 }

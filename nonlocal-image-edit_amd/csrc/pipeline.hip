@@ -363,13 +363,43 @@ std::vector<double> build_Ka(const SampleSet& s, double hx, double hy) {
     return Ka;
 }
 
+// What the later stages need of Ka.  The literal form is the reference's: Ka's eigenpairs with the
+// cut at 1e-10 (VA = V_r, lam, B = V_r / lam).  The Phi-free path uses them only through
+//   VA diag(lam) VA^T (= Ka restricted to its range),  B diag(lam) VA^T (= the projector P on that range)
+//   and B diag(lam) B^T (= pinv(Ka)),
+// so when Ka is provably full rank at the reference's threshold (every eigenvalue >= 1e-10, certified
+// by 1 / trace(Ka^-1)) the Cholesky factor serves as well: VA = L, lam = 1, B = L^-T (P = I) -- a
+// p^3/3 factorisation instead of a p x p eigensolve.  The materialised path keeps the eigenpairs.
 struct Nystrom {
     int r = 0, ldr = 0;
+    bool chol = false;
     std::vector<double> VA;   // p x r col-major
     std::vector<double> lam;  // r
+    std::vector<double> B;    // p x r col-major
+    std::vector<double> Ka;   // p x p (kept for the W blocks)
 };
 
-Nystrom solve_Ka(const std::vector<double>& Ka, int p) {
+// every eigenvalue of an SPD matrix with trace(M^-1) <= kCholMaxInvTrace is >= 1e-9 > NLE_EPS
+constexpr double kCholMaxInvTrace = 1e9;
+
+Nystrom solve_Ka(const std::vector<double>& Ka, int p, bool allow_chol) {
+    Nystrom n;
+    if (allow_chol && std::getenv("NLE_FORCE_EIG") == nullptr) {
+        std::vector<double> L((size_t)p * p), Li((size_t)p * p);
+        double inv_trace = 0.0;
+        if (nleh::cholesky_with_inverse(Ka.data(), p, L.data(), Li.data(), &inv_trace) && inv_trace <= kCholMaxInvTrace) {
+            n.chol = true;
+            n.r = p;
+            n.ldr = ld4(p);
+            n.VA = std::move(L);
+            n.lam.assign(p, 1.0);
+            n.B.resize((size_t)p * p);
+            for (int k = 0; k < p; ++k)
+                for (int a = 0; a < p; ++a) n.B[(size_t)k * p + a] = Li[(size_t)a * p + k];  // L^-T
+            n.Ka = Ka;
+            return n;
+        }
+    }
     // nystromApproximation, reference src/filter.cpp:262-271
     std::vector<double> U((size_t)p * p), D(p);
     int r = 0;
@@ -380,11 +410,15 @@ Nystrom solve_Ka(const std::vector<double>& Ka, int p) {
         if (std::fabs(D[k]) >= NLE_EPS) ++nnz;  // inplaceReciprocal count (:266)
     r = std::min(r, nnz);
     if (r <= 0) throw Fail{NLE_ERR_NUMERIC, "Ka has no eigenvalue >= 1e-10"};
-    Nystrom n;
     n.r = r;
     n.ldr = ld4(r);
     n.VA.assign(U.begin(), U.begin() + (size_t)p * r);
     n.lam.assign(D.begin(), D.begin() + r);
+    n.B.resize((size_t)p * r);
+    for (int k = 0; k < r; ++k) {
+        const double inv = recip0(n.lam[k]);  // :265-268
+        for (int a = 0; a < p; ++a) n.B[(size_t)k * p + a] = n.VA[(size_t)k * p + a] * inv;
+    }
     return n;
 }
 
@@ -538,44 +572,15 @@ void par_cols(int n, long long work_per_col, F&& body) {
 }
 // C (m x n) = A (m x k) * B (k x n)
 void mm(const double* A, const double* B, double* C, int m, int k, int n) {
-    par_cols(n, (long long)m * k, [&](int j0, int j1) {
-        for (int j = j0; j < j1; ++j) {
-            double* cc = C + (size_t)j * m;
-            std::fill(cc, cc + m, 0.0);
-            for (int l = 0; l < k; ++l) {
-                const double b = B[(size_t)j * k + l];
-                const double* a = A + (size_t)l * m;
-                for (int i = 0; i < m; ++i) cc[i] += a[i] * b;
-            }
-        }
-    });
+    par_cols(n, (long long)m * k, [&](int j0, int j1) { nleh::gemm_nn_cols(A, B, C, m, k, n, j0, j1); });
 }
 // C (m x n) = A (m x k) * B^T (B is n x k)
 void mm_nt(const double* A, const double* B, double* C, int m, int k, int n) {
-    par_cols(n, (long long)m * k, [&](int j0, int j1) {
-        for (int j = j0; j < j1; ++j) {
-            double* cc = C + (size_t)j * m;
-            std::fill(cc, cc + m, 0.0);
-            for (int l = 0; l < k; ++l) {
-                const double b = B[(size_t)l * n + j];
-                const double* a = A + (size_t)l * m;
-                for (int i = 0; i < m; ++i) cc[i] += a[i] * b;
-            }
-        }
-    });
+    par_cols(n, (long long)m * k, [&](int j0, int j1) { nleh::gemm_nt_cols(A, B, C, m, k, n, j0, j1); });
 }
 // C (k x n) = A^T (A is m x k) * B (m x n)
 void mm_tn(const double* A, const double* B, double* C, int m, int k, int n) {
-    par_cols(n, (long long)m * k, [&](int j0, int j1) {
-        for (int j = j0; j < j1; ++j)
-            for (int l = 0; l < k; ++l) {
-                const double* a = A + (size_t)l * m;
-                const double* b = B + (size_t)j * m;
-                double s = 0.0;
-                for (int i = 0; i < m; ++i) s += a[i] * b[i];
-                C[(size_t)j * k + l] = s;
-            }
-    });
+    par_cols(n, (long long)m * k, [&](int j0, int j1) { nleh::gemm_tn_cols(A, B, C, m, k, n, j0, j1); });
 }
 
 double now_ms();
@@ -702,7 +707,7 @@ struct OrthoSS {
     std::vector<double> Sq, D, Vrows;  // D: p x K, Vrows: p x K (col-major)
     // state between the two halves
     int p = 0, r = 0;
-    std::vector<double> cA, rA, Kr, P, Wa, S;
+    std::vector<double> cA, rA, Kr, P, Wa, S, St, A2;  // Q = A2 + S^T (Wab Wab^T) S,  St = S^T
 };
 
 // first half: everything that does not depend on the Gram matrix (runs on the host while the GPU
@@ -725,29 +730,58 @@ void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<do
         o.cA[a] = recip0(sc);
         o.rA[a] = recip0(sr);
     }
-    std::vector<double> VL((size_t)p * r);
-    o.Kr.resize((size_t)p * p);
-    for (int k = 0; k < r; ++k)
-        for (int a = 0; a < p; ++a) VL[(size_t)k * p + a] = ny.VA[(size_t)k * p + a] * ny.lam[k];
-    mm_nt(VL.data(), ny.VA.data(), o.Kr.data(), p, r, p);
-    if (r < p) {
-        o.P.resize((size_t)p * p);
-        mm_nt(ny.VA.data(), ny.VA.data(), o.P.data(), p, r, p);
+    if (ny.chol) {
+        o.Kr = ny.Ka;  // r == p: Kr = Ka, P = I
+    } else {
+        std::vector<double> VL((size_t)p * r);
+        o.Kr.resize((size_t)p * p);
+        for (int k = 0; k < r; ++k)
+            for (int a = 0; a < p; ++a) VL[(size_t)k * p + a] = ny.VA[(size_t)k * p + a] * ny.lam[k];
+        mm_nt(VL.data(), ny.VA.data(), o.Kr.data(), p, r, p);
+        if (r < p) {
+            o.P.resize((size_t)p * p);
+            mm_nt(ny.VA.data(), ny.VA.data(), o.P.data(), p, r, p);
+        }
     }
     o.Wa.resize((size_t)q * q);
     for (int b = 0; b < q; ++b)
         for (int a = 0; a < q; ++a) o.Wa[(size_t)b * q + a] = o.rA[a] * o.Kr[(size_t)b * p + a] * o.cA[b];  // :249
+    // S with S S^T = A^-1, A = the symmetric matrix the reference's solver sees (lower triangle of Wa).
+    // The reference takes the symmetric root A^-1/2 (:287-292); any other root F gives the similar matrix
+    // G^T Q G (G = A^1/2 F orthogonal) with the same eigenvalues and the same product S Vq, hence the same
+    // eigenvectors V (:327).  When A is provably free of eigenvalues below the cut, F = L^-T (Cholesky).
+    o.S.resize((size_t)q * q);
+    if (std::getenv("NLE_FORCE_EIG") == nullptr) {
+        std::vector<double> L((size_t)q * q), Li((size_t)q * q);
+        double inv_trace = 0.0;
+        if (nleh::cholesky_with_inverse(o.Wa.data(), q, L.data(), Li.data(), &inv_trace) && inv_trace <= kCholMaxInvTrace) {
+            std::vector<double> Lt((size_t)q * q);
+            for (int k = 0; k < q; ++k)
+                for (int a = 0; a < q; ++a) {
+                    o.S[(size_t)k * q + a] = Li[(size_t)a * q + k];  // L^-T
+                    Lt[(size_t)k * q + a] = L[(size_t)a * q + k];
+                }
+            o.St = std::move(Li);
+            o.A2.resize((size_t)q * q);
+            mm(Lt.data(), L.data(), o.A2.data(), q, q, q);  // F^T A^2 F = L^T L
+            return;
+        }
+    }
     std::vector<double> U2((size_t)q * q), l2(q);
     int r2 = 0;
     if (!nleh::eigen_decomposition(o.Wa.data(), q, NLE_EPS, U2.data(), l2.data(), &r2))
         throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Wa"};
     std::vector<double> Us((size_t)q * std::max(r2, 1));
-    o.S.resize((size_t)q * q);
     for (int k = 0; k < r2; ++k) {
         const double sv = std::sqrt(recip0(l2[k]));
         for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * sv;
     }
     mm_nt(Us.data(), U2.data(), o.S.data(), q, r2, q);  // :287-292
+    if (std::getenv("NLE_TRACE"))
+        fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e)\n", r2, q, l2[0],
+                r2 > 0 ? l2[r2 - 1] : 0.0);
+    o.St = o.S;
+    o.A2 = o.Wa;  // :296 (the solver reads the lower triangle of the sum)
 }
 
 // second half: needs Gk
@@ -771,9 +805,9 @@ void ortho_ss_finish(OrthoSS& o, std::vector<double> Gk, int n_eig) {
     for (int b = 0; b < q; ++b)
         for (int a = 0; a < q; ++a) WW[(size_t)b * q + a] = rA[a] * Gk[(size_t)b * p + a] * rA[b];  // Wab Wab^T, :296
     std::vector<double> T1((size_t)q * q), Qm((size_t)q * q);
-    mm(S.data(), WW.data(), T1.data(), q, q, q);
+    mm(o.St.data(), WW.data(), T1.data(), q, q, q);
     mm(T1.data(), S.data(), Qm.data(), q, q, q);
-    for (size_t i = 0; i < Qm.size(); ++i) Qm[i] += Wa[i];  // :296
+    for (size_t i = 0; i < Qm.size(); ++i) Qm[i] += o.A2[i];  // :296
     std::vector<double> Vq((size_t)q * q), Sq(q);
     int rq = 0;
     if (!nleh::eigen_decomposition(Qm.data(), q, NLE_EPS, Vq.data(), Sq.data(), &rq))
@@ -910,11 +944,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     DevBuf<float4> d_samples(P64);
     HIP_OK(hipMemsetAsync(d_samples.p, 0, P64 * sizeof(float4), c->stream));
     HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), p * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    std::vector<double> Bh((size_t)p * r);
-    for (int k = 0; k < r; ++k) {
-        const double inv = recip0(ny.lam[k]);  // :265-268
-        for (int a = 0; a < p; ++a) Bh[(size_t)k * p + a] = ny.VA[(size_t)k * p + a] * inv;
-    }
+    const std::vector<double>& Bh = ny.B;
     constexpr int kZS = 8;  // slices of the block partials, summed by k_sink_update
     DevBuf<double> d_B(Bh.size()), d_VA(Bh.size()), d_lam(r), d_z((size_t)kZS * P64), d_w(P64), d_uh((size_t)2 * T * r),
         d_partial((size_t)nlek::sink_pass_rows(std::max<long long>(M, 1)) * P64);
@@ -1199,8 +1229,8 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         double h0 = now_ms();
         std::vector<double> Ka = build_Ka(ss, hx, hy);
         tr.mark("build_Ka");
-        Nystrom ny = solve_Ka(Ka, ss.p);
-        tr.mark("eig(Ka)");
+        Nystrom ny = solve_Ka(Ka, ss.p, fuse);
+        tr.mark(ny.chol ? "chol(Ka)" : "eig(Ka)");
         sm.host += now_ms() - h0;
         f->r = ny.r;
         tm_a.stop();
@@ -1525,7 +1555,7 @@ int nle_nystrom(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_sample
         HIP_OK(hipSetDevice(ctx->device));
         SampleSet ss = fetch_samples(ctx, d_lum, gs);
         std::vector<double> Ka = build_Ka(ss, hx, hy);
-        Nystrom ny = solve_Ka(Ka, ss.p);
+        Nystrom ny = solve_Ka(Ka, ss.p, false);
         int row0, row1;
         slab(H, ctx->rank, ctx->world, &row0, &row1);
         build_phi(ctx, d_lum, ss, ny, hx, hy, (long long)row0 * W, (long long)(row1 - row0) * W, d_phi);
