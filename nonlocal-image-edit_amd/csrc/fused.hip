@@ -190,64 +190,81 @@ hipError_t sink_pass(hipStream_t s, int mode, const float* d_lum, GridSpec gs, c
 }
 
 // ------------------------------------------------------------------ Sinkhorn update (p-, r-sized)
-// After the pass with scaling vector u (and w = B u):  y_a = 1 or recip(V_A[a] . u) for the
-// p sample pixels (exact fp64 rows, :275 top block), t = B^T z + V_A^T y_A, u' = lambda o t,
-// w' = B u'.  One workgroup; B, V_A are p x r column-major fp64.
-__global__ __launch_bounds__(1024) void k_sink_update(int mode, int p, int r, const double* __restrict__ Bm,
-                                                      const double* __restrict__ VA,
-                                                      const double* __restrict__ lam,
-                                                      const double* __restrict__ z, int zrows, int zld,
-                                                      const double* __restrict__ u_cur, double eps,
-                                                      double* __restrict__ u_next, double* __restrict__ w_next,
-                                                      int w_len) {
+// ---- the p-sized update between two passes
+// After the pass with scaling vector u (w = B u):  y_a = 1 or recip(V_A[a] . u) for the p sample pixels
+// (exact fp64 rows, :275 top block), t = B^T z + V_A^T y_A, u' = lambda o t, w' = B u'.  The passes only
+// need w and s_A = V_A u (the samples' row sums), so u is eliminated:
+//     [w'; s_A'] = Mu [z; y_A],   Mu = [B; V_A] diag(lambda) [B; V_A]^T   (2p x 2p, built once per training)
+// -- one matrix-vector product whose outputs are independent, spread over ceil(2p / 8) workgroups.
+__global__ __launch_bounds__(256) void k_update_matrix(int p, int r, const double* __restrict__ Bm,
+                                                       const double* __restrict__ VA, const double* __restrict__ lam,
+                                                       double* __restrict__ Mu) {
+    const int n2 = 2 * p;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n2 * n2) return;
+    const int i = (int)(idx / n2), j = (int)(idx % n2);
+    const double* xi = (i < p) ? Bm + i : VA + (i - p);
+    const double* xj = (j < p) ? Bm + j : VA + (j - p);
+    double s0 = 0.0, s1 = 0.0;
+    int k = 0;
+    for (; k + 1 < r; k += 2) {
+        s0 += xi[(size_t)k * p] * lam[k] * xj[(size_t)k * p];
+        s1 += xi[(size_t)(k + 1) * p] * lam[k + 1] * xj[(size_t)(k + 1) * p];
+    }
+    if (k < r) s0 += xi[(size_t)k * p] * lam[k] * xj[(size_t)k * p];
+    Mu[idx] = s0 + s1;
+}
+
+hipError_t update_matrix(hipStream_t s, int p, int r, const double* d_B, const double* d_VA, const double* d_lam,
+                         double* d_Mu) {
+    const long long n = 4ll * p * p;
+    hipLaunchKernelGGL(k_update_matrix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, r, d_B, d_VA, d_lam, d_Mu);
+    return hipGetLastError();
+}
+
+// z: zrows slices of stride zld (summed here in a fixed order); sA_cur: s_A of the scaling the pass used
+// (ignored by the column-sum pass, where y_A = 1)
+__global__ __launch_bounds__(256) void k_sink_update(int mode, int p, const double* __restrict__ Mu,
+                                                     const double* __restrict__ z, int zrows, int zld,
+                                                     const double* __restrict__ sA_cur, double eps,
+                                                     double* __restrict__ sA_next, double* __restrict__ w_next) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* sz = reinterpret_cast<double*>(smem_raw);  // [p]
-    double* sy = sz + p;                               // [p]
-    double* su = sy + p;                               // [r]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    for (int k = tid; k < r; k += blockDim.x) su[k] = (mode == ROWPASS_COLSUM) ? 0.0 : u_cur[k];
-    for (int a = tid; a < p; a += blockDim.x) {
+    double* v = reinterpret_cast<double*>(smem_raw);  // [2p] = [z; y_A]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n2 = 2 * p;
+    for (int a = tid; a < p; a += 256) {
         double t = 0.0;
-        for (int q = 0; q < zrows; ++q) t += z[(size_t)q * zld + a];  // fixed order
-        sz[a] = t;
+        for (int q = 0; q < zrows; ++q) t += z[(size_t)q * zld + a];
+        v[a] = t;
+        v[p + a] = (mode == ROWPASS_COLSUM) ? 1.0 : recip_or_zero_d(sA_cur[a], eps);
     }
     __syncthreads();
-    for (int a = tid; a < p; a += blockDim.x) {
-        double y = 1.0;
-        if (mode != ROWPASS_COLSUM) {
-            double s = 0.0;
-            for (int k = 0; k < r; ++k) s += VA[(size_t)k * p + a] * su[k];
-            y = recip_or_zero_d(s, eps);
-        }
-        sy[a] = y;
-    }
-    __syncthreads();
-    for (int k = wave; k < r; k += nw) {
-        double s = 0.0;
-        for (int a = lane; a < p; a += 64) s += Bm[(size_t)k * p + a] * sz[a] + VA[(size_t)k * p + a] * sy[a];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) {
-            const double uk = lam[k] * s;
-            u_next[k] = uk;
-            su[k] = uk;  // su is not read between the two barriers around this loop by other waves
+    for (int j = 0; j < 2; ++j) {
+        const int o = (blockIdx.x * 4 + wave) * 2 + j;
+        if (o >= n2) break;  // wave-uniform
+        const double* row = Mu + (size_t)o * n2;
+        double s0 = 0.0, s1 = 0.0;
+        int i = lane;
+        for (; i + 64 < n2; i += 128) {
+            s0 += row[i] * v[i];
+            s1 += row[i + 64] * v[i + 64];
         }
-    }
-    __syncthreads();
-    for (int a = tid; a < w_len; a += blockDim.x) {
-        double s = 0.0;
-        if (a < p)
-            for (int k = 0; k < r; ++k) s += Bm[(size_t)k * p + a] * su[k];
-        w_next[a] = s;
+        if (i < n2) s0 += row[i] * v[i];
+        double sum = s0 + s1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        if (lane == 0) {
+            if (o < p) w_next[o] = sum;
+            else sA_next[o - p] = sum;
+        }
     }
 }
 
-hipError_t sink_update(hipStream_t s, int mode, int p, int r, const double* d_B, const double* d_VA,
-                       const double* d_lam, const double* d_z, int zrows, int zld, const double* d_u_cur,
-                       double eps, double* d_u_next, double* d_w_next, int w_len) {
-    const size_t shm = (size_t)(2 * p + r) * sizeof(double);
-    hipLaunchKernelGGL(k_sink_update, dim3(1), dim3(1024), shm, s, mode, p, r, d_B, d_VA, d_lam, d_z, zrows, zld,
-                       d_u_cur, eps, d_u_next, d_w_next, w_len);
+hipError_t sink_update(hipStream_t s, int mode, int p, const double* d_Mu, const double* d_z, int zrows, int zld,
+                       const double* d_sA_cur, double eps, double* d_sA_next, double* d_w_next) {
+    const size_t shm = (size_t)2 * p * sizeof(double);
+    hipLaunchKernelGGL(k_sink_update, dim3((unsigned)((2 * p + 7) / 8)), dim3(256), shm, s, mode, p, d_Mu, d_z, zrows,
+                       zld, d_sA_cur, eps, d_sA_next, d_w_next);
     return hipGetLastError();
 }
 
@@ -919,36 +936,60 @@ hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, i
 //   k_hist_pix : per image row: d_i, y_i, h[r][x,b] += ec y      (g row and h row in LDS)
 //   k_hist_hh  : HH[slab][x,b][a] = sum_{r in slab} er[r][a] h[r][x,b]
 //   k_hist_z   : z[a,b] = sum_x Ep[x][a,b] sum_slab HH[slab][x,b][a]
-__global__ __launch_bounds__(256) void k_hist_g(GridSpec gs, int p, int nrows, const double* __restrict__ er,
-                                                const double* __restrict__ Ep, const double* __restrict__ w,
-                                                double* __restrict__ g) {
-    constexpr int RT = 32, XT = 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int nC = gs.nSelCols, nR = gs.nSelRows;
-    double* sQ = reinterpret_cast<double*>(smem_raw);  // [XT][p]   w o Ep
-    double* sE = sQ + XT * p;                           // [RT][nR]
-    const int tid = threadIdx.x, r0 = blockIdx.x * RT, x0 = blockIdx.y * XT;
-    for (int i = tid; i < XT * p; i += 256) sQ[i] = w[i % p] * Ep[(size_t)x0 * p + i];
-    for (int i = tid; i < RT * nR; i += 256) {
-        const int rr = r0 + i / nR;
-        sE[i] = rr < nrows ? er[(size_t)rr * nR + i % nR] : 0.0;
+// G (nrows x 256 nC) = er (nrows x nR) * WE (nR x 256 nC), WE[a][x,b] = w[a,b] Ep[x][a,b], on the fp64
+// MFMA: a wave keeps the WE operands of its 16 columns in registers (nR <= 32: 8 k-steps of 4) and walks
+// down `tiles_per_wave` 16-row tiles -- five loads, five MFMAs and one 16 x 16 store per tile at cfg4, so
+// the kernel runs at the speed of its 8 B/element output stream.
+__global__ __launch_bounds__(256) void k_hist_g(GridSpec gs, int p, int nrows, int tiles_per_wave,
+                                                const double* __restrict__ er, const double* __restrict__ Ep,
+                                                const double* __restrict__ w, double* __restrict__ g) {
+    const int nC = gs.nSelCols, nR = gs.nSelRows, n = kLevels * nC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int n0 = (blockIdx.x * 4 + wave) * 16;
+    if (n0 >= n) return;  // wave-uniform
+    const int col = n0 + l15;
+    const bool col_ok = col < n;
+    const int x = col_ok ? col / nC : 0, b = col_ok ? col - x * nC : 0;
+    double bop[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int a = ks * 4 + kq;
+        bop[ks] = (col_ok && a < nR) ? w[a * nC + b] * Ep[(size_t)x * p + a * nC + b] : 0.0;
     }
-    __syncthreads();
-    const int ncol = XT * nC;
-    for (int o = tid; o < RT * ncol; o += 256) {
-        const int rl = o / ncol, col = o - rl * ncol, xl = col / nC, b = col - xl * nC;
-        if (r0 + rl >= nrows) continue;
-        const double* q = sQ + xl * p + b;
-        const double* e = sE + rl * nR;
-        double s0 = 0.0, s1 = 0.0;
-        int a = 0;
-        for (; a + 1 < nR; a += 2) {
-            s0 += e[a] * q[a * nC];
-            s1 += e[a + 1] * q[(a + 1) * nC];
+    const int ksteps = (nR + 3) >> 2;
+    const int t0 = blockIdx.y * tiles_per_wave, ntiles = (nrows + 15) >> 4;
+    for (int t = t0; t < min(ntiles, t0 + tiles_per_wave); ++t) {
+        const int r = t * 16 + l15;
+        double aop[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int a = ks * 4 + kq;
+            aop[ks] = (ks < ksteps && r < nrows && a < nR) ? er[(size_t)r * nR + a] : 0.0;
         }
-        if (a < nR) s0 += e[a] * q[a * nC];
-        g[(size_t)(r0 + rl) * (kLevels * nC) + (size_t)(x0 + xl) * nC + b] = s0 + s1;
+        f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            if (ks < ksteps) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ks], bop[ks], acc, 0, 0, 0);
+        if (col_ok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ro = t * 16 + kq + 4 * e;
+                if (ro < nrows) g[(size_t)ro * n + col] = acc[e];
+            }
+        }
     }
+}
+
+static hipError_t launch_hist_g(hipStream_t s, GridSpec gs, int p, int nrows_local, const double* d_er, const double* d_Ep,
+                                const double* d_w, double* d_g) {
+    const int n = kLevels * gs.nSelCols, ntiles = (nrows_local + 15) / 16;
+    const int gx = (n / 16 + 3) / 4;
+    // ~2560 waves on the chip (or one row tile per wave if the slab is short)
+    const int chunks = std::max(1, std::min(ntiles, (640 + gx - 1) / gx));
+    const int tpw = (ntiles + chunks - 1) / chunks;
+    hipLaunchKernelGGL(k_hist_g, dim3((unsigned)gx, (unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, s, gs, p,
+                       nrows_local, tpw, d_er, d_Ep, d_w, d_g);
+    return hipGetLastError();
 }
 
 template <int NC>  // NC = nSelCols: compile-time so that the per-pixel loops carry no branches
@@ -1100,36 +1141,48 @@ __global__ void k_scatter_samples(int p, int L, const long long* __restrict__ lo
     if (loc[a] >= 0) Y[(size_t)l * ystride + loc[a]] = (float)YA[o];
 }
 
-// grid (ceil(256 nC / 256), nslabs): HH[slab][col][a], col = x*nC + b
+// HH[slab][a][col] = sum over the slab's image rows of er[r][a] h[r][col], col = x*nC + b: per slab a
+// (nR x slab_rows) x (slab_rows x 256 nC) product on the fp64 MFMA.  One wave per 16 columns and slab; the
+// slab's 16 row loads of a lane are independent, so they are all in flight together.
+// grid (ceil(16 nC / 4), nslabs), slab_rows == 64.
 __global__ __launch_bounds__(256) void k_hist_hh(int nC, int nR, int nrows, int slab_rows, const double* __restrict__ er,
                                                  const double* __restrict__ h, double* __restrict__ HH) {
     const int n = kLevels * nC;
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    const int r0 = blockIdx.y * slab_rows, r1 = min(nrows, r0 + slab_rows);
-    double acc[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int n0 = (blockIdx.x * 4 + wave) * 16;
+    if (n0 >= n) return;  // wave-uniform
+    const int col = n0 + l15;
+    const bool col_ok = col < n;
+    const int r0 = blockIdx.y * slab_rows;
+    const bool two = nR > 16;
+    f64x4 acc0 = f64x4{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+    for (int k0 = 0; k0 < slab_rows; k0 += 32) {
+        double bop[8];
 #pragma unroll
-    for (int a = 0; a < 32; ++a) acc[a] = 0.0;
-    if (col < n) {
-        int r = r0;
-        for (; r + 3 < r1; r += 4) {  // four independent loads in flight
-            const double h0 = h[(size_t)r * n + col], h1 = h[(size_t)(r + 1) * n + col];
-            const double h2 = h[(size_t)(r + 2) * n + col], h3 = h[(size_t)(r + 3) * n + col];
-            const double* e = er + (size_t)r * nR;
-#pragma unroll
-            for (int a = 0; a < 32; ++a)
-                if (a < nR) acc[a] += (e[a] * h0 + e[nR + a] * h1) + (e[2 * nR + a] * h2 + e[3 * nR + a] * h3);
+        for (int ks = 0; ks < 8; ++ks) {
+            const int r = r0 + k0 + ks * 4 + kq;
+            bop[ks] = (col_ok && r < nrows) ? h[(size_t)r * n + col] : 0.0;
         }
-        for (; r < r1; ++r) {
-            const double hv = h[(size_t)r * n + col];
-            const double* e = er + (size_t)r * nR;
 #pragma unroll
-            for (int a = 0; a < 32; ++a)
-                if (a < nR) acc[a] += e[a] * hv;
+        for (int ks = 0; ks < 8; ++ks) {
+            const int r = r0 + k0 + ks * 4 + kq;
+            const bool rok = r < nrows;
+            const double a0 = (rok && l15 < nR) ? er[(size_t)r * nR + l15] : 0.0;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bop[ks], acc0, 0, 0, 0);
+            if (two) {
+                const double a1 = (rok && 16 + l15 < nR) ? er[(size_t)r * nR + 16 + l15] : 0.0;
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bop[ks], acc1, 0, 0, 0);
+            }
         }
+    }
+    if (col_ok) {
         double* out = HH + (size_t)blockIdx.y * n * nR + col;  // [slab][a][col]
 #pragma unroll
-        for (int a = 0; a < 32; ++a)
-            if (a < nR) out[(size_t)a * n] = acc[a];
+        for (int e = 0; e < 4; ++e) {
+            const int a = kq + 4 * e;
+            if (a < nR) out[(size_t)a * n] = acc0[e];
+            if (two && 16 + a < nR) out[(size_t)(16 + a) * n] = acc1[e];
+        }
     }
 }
 
@@ -1180,14 +1233,8 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
     double* d_HH = d_h + (size_t)nrows_local * n;
     if (mode == ROWPASS_RECIP) {
         Scope sc(obs, SUB_HIST_G);
-        const size_t shm_g = ((size_t)8 * p + (size_t)32 * nR) * sizeof(double);
-        if (shm_g > 48 * 1024) {
-            hipError_t eg = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_g),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_g);
-            if (eg != hipSuccess) return eg;
-        }
-        hipLaunchKernelGGL(k_hist_g, dim3((unsigned)((nrows_local + 31) / 32), kLevels / 8), dim3(256), shm_g, s, gs, p,
-                           nrows_local, d_er, d_Ep, d_w, d_g);
+        hipError_t eg = launch_hist_g(s, gs, p, nrows_local, d_er, d_Ep, d_w, d_g);
+        if (eg != hipSuccess) return eg;
     }
     {
         Scope sc(obs, SUB_HIST_PIX);
@@ -1219,7 +1266,7 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
 #undef NLE_HP
     }
     Scope sc(obs, SUB_HIST_HH);
-    hipLaunchKernelGGL(k_hist_hh, dim3((unsigned)((n + 255) / 256), (unsigned)nslabs), dim3(256), 0, s, nC, nR,
+    hipLaunchKernelGGL(k_hist_hh, dim3((unsigned)((n / 16 + 3) / 4), (unsigned)nslabs), dim3(256), 0, s, nC, nR,
                        nrows_local, slab_rows, d_er, d_h, d_HH);
     hipLaunchKernelGGL(k_hist_z, dim3((unsigned)ldp), dim3(kLevels), 0, s, p, ldp, nC, nR, nslabs, d_Ep, d_HH, d_z);
     return hipGetLastError();
@@ -1234,14 +1281,10 @@ hipError_t apply_hist_layer(hipStream_t s, const float* d_lum, GridSpec gs, int 
     const size_t n = (size_t)kLevels * nC;
     double* d_g = d_ws;
     if (obs) obs->begin(SUB_HIST_G);
-    const size_t shm_g = ((size_t)8 * p + (size_t)32 * nR) * sizeof(double);
-    if (shm_g > 48 * 1024) {
-        hipError_t eg = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_g),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_g);
+    {
+        hipError_t eg = launch_hist_g(s, gs, p, nrows_local, d_er, d_Ep, d_wl, d_g);
         if (eg != hipSuccess) return eg;
     }
-    hipLaunchKernelGGL(k_hist_g, dim3((unsigned)((nrows_local + 31) / 32), kLevels / 8), dim3(256), shm_g, s, gs, p,
-                       nrows_local, d_er, d_Ep, d_wl, d_g);
     if (obs) obs->end(), obs->begin(SUB_HIST_PIX);
 #define NLE_HD(NCV)                                                                                                  \
     case NCV: {                                                                                                      \

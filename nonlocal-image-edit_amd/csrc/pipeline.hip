@@ -712,23 +712,17 @@ struct OrthoSS {
 
 // first half: everything that does not depend on the Gram matrix (runs on the host while the GPU
 // computes Gk): sample scalings, Kr, P, Wa and S = Wa^-1/2 (:287-292)
-void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<double>& u_c,
-                      const std::vector<double>& u_r) {
+void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<double>& sA_c,
+                      const std::vector<double>& sA_r) {
     const int r = ny.r, q = ny.r;
     o.p = p;
     o.r = r;
     o.q = q;
     o.cA.resize(p);
     o.rA.resize(p);
-    for (int a = 0; a < p; ++a) {
-        double sc = 0.0, sr = 0.0;
-        for (int k = 0; k < r; ++k) {
-            const double v = ny.VA[(size_t)k * p + a];
-            sc += v * u_c[k];
-            sr += v * u_r[k];
-        }
-        o.cA[a] = recip0(sc);
-        o.rA[a] = recip0(sr);
+    for (int a = 0; a < p; ++a) {  // sA = V_A u: the samples' row sums under the two final scalings
+        o.cA[a] = recip0(sA_c[a]);
+        o.rA[a] = recip0(sA_r[a]);
     }
     if (ny.chol) {
         o.Kr = ny.Ka;  // r == p: Kr = Ka, P = I
@@ -946,8 +940,8 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), p * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     const std::vector<double>& Bh = ny.B;
     constexpr int kZS = 8;  // slices of the block partials, summed by k_sink_update
-    DevBuf<double> d_B(Bh.size()), d_VA(Bh.size()), d_lam(r), d_z((size_t)kZS * P64), d_w(P64), d_uh((size_t)2 * T * r),
-        d_partial((size_t)nlek::sink_pass_rows(std::max<long long>(M, 1)) * P64);
+    DevBuf<double> d_B(Bh.size()), d_VA(Bh.size()), d_lam(r), d_z((size_t)kZS * P64), d_w(P64), d_sAh((size_t)2 * T * p),
+        d_Mu((size_t)4 * p * p), d_partial((size_t)nlek::sink_pass_rows(std::max<long long>(M, 1)) * P64);
     DevBuf<double> d_cbuf((size_t)std::max<long long>(M, 1));
     // quantised luminance + Cartesian sample grid: table look-ups replace the exponentials (fused.hip)
     const bool hist = ss.quantised && c->mode != 3 && ss.gs.nSelCols <= nlek::sink_hist_max_cols() &&
@@ -967,12 +961,14 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     HIP_OK(hipMemcpyAsync(d_VA.p, ny.VA.data(), Bh.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemsetAsync(d_w.p, 0, P64 * sizeof(double), c->stream));
+    PROFILED(c, NLE_K_SMALL, nlek::update_matrix(c->stream, p, r, d_B.p, d_VA.p, d_lam.p, d_Mu.p));
     const bool hist_tiled = hist && ss.gs.nSelCols <= 36 && ss.gs.nSelRows <= 32 && std::getenv("NLE_HIST_UNTILED") == nullptr;
     DevBuf<double> d_hws;
     if (hist_tiled) d_hws.alloc(nlek::hist_tiled_workspace_elems(ss.gs, nrows_local));
     const int nrows = hist ? nrows_local : nlek::sink_pass_rows(std::max<long long>(M, 1));
     tr.mark("ss: alloc+upload");
-    // pass n uses u = uh[n-1] (w = B u) and produces uh[n]; pass 0 is the column sum Phi^T 1 (:234,239)
+    // pass n uses the scaling whose sample row sums are sAh[n-1] (and w) and produces sAh[n]; pass 0 is the
+    // column sum Phi^T 1 (:234,239)
     auto one_pass = [&](int n, int mode, double* ybuf) {
         if (M > 0 && hist_tiled) {
             // tiled table pass: writes the local column sums straight into slice 0 of d_z
@@ -995,17 +991,18 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         const int zrows = hist_tiled ? 1 : kZS;
         all_reduce(c, d_z.p, (size_t)zrows * P64);
         PROFILED(c, NLE_K_SMALL,
-                 nlek::sink_update(c->stream, mode, p, r, d_B.p, d_VA.p, d_lam.p, d_z.p, zrows, P64,
-                                   n > 0 ? d_uh.p + (size_t)(n - 1) * r : nullptr, NLE_EPS, d_uh.p + (size_t)n * r,
-                                   d_w.p, P64));
+                 nlek::sink_update(c->stream, mode, p, d_Mu.p, d_z.p, zrows, P64,
+                                   n > 0 ? d_sAh.p + (size_t)(n - 1) * p : nullptr, NLE_EPS, d_sAh.p + (size_t)n * p,
+                                   d_w.p));
     };
     one_pass(0, nlek::ROWPASS_COLSUM, nullptr);
     for (int n = 1; n < 2 * T; ++n) one_pass(n, nlek::ROWPASS_RECIP, n == 2 * T - 1 ? d_cbuf.p : nullptr);
-    // u_c = scaling that defines the final c (input of the last pass), u_r = output of the last pass
-    std::vector<double> u_c(r), u_r(r);
-    HIP_OK(hipMemcpyAsync(u_c.data(), d_uh.p + (size_t)(2 * T - 2) * r, r * sizeof(double), hipMemcpyDeviceToHost,
+    // sample row sums V_A u of the scaling that defines the final c (input of the last pass) and of the
+    // output of the last pass (the r scaling)
+    std::vector<double> sA_c(p), sA_r(p);
+    HIP_OK(hipMemcpyAsync(sA_c.data(), d_sAh.p + (size_t)(2 * T - 2) * p, p * sizeof(double), hipMemcpyDeviceToHost,
                           c->stream));
-    HIP_OK(hipMemcpyAsync(u_r.data(), d_uh.p + (size_t)(2 * T - 1) * r, r * sizeof(double), hipMemcpyDeviceToHost,
+    HIP_OK(hipMemcpyAsync(sA_r.data(), d_sAh.p + (size_t)(2 * T - 1) * p, p * sizeof(double), hipMemcpyDeviceToHost,
                           c->stream));
     tm_s.stop();
     tr.mark("ss: passes enqueued");
@@ -1035,7 +1032,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     }
     double h0 = now_ms();
     OrthoSS o;
-    ortho_ss_prepare(o, ny, p, u_c, u_r);  // host, while the Gram kernel runs
+    ortho_ss_prepare(o, ny, p, sA_c, sA_r);  // host, while the Gram kernel runs
     const double h_overlapped = now_ms() - h0;
     tr.mark("ss: ortho prepare (host)");
     // (a device-to-host copy into pageable memory blocks the host until the stream reaches it, so it

@@ -202,6 +202,30 @@ def test_rank_truncated_Ka(nle, oracle, ctx, mode):
         assert rel_l2(Y[j], Y_o[j]) < PER_LAYER_TOL, f"layer {j}"
 
 
+@pytest.mark.parametrize("case", [SMALL_CASES[1], SMALL_CASES[-1]])
+def test_cholesky_and_eigen_forms_of_Ka_agree(nle, oracle, ctx, case, monkeypatch):
+    """Full-rank Ka: the Phi-free path factors Ka (and Wa when the 1e-10 cut removes nothing) by Cholesky
+    instead of the eigensolver (pipeline.hip solve_Ka / ortho_ss_prepare); NLE_FORCE_EIG=1 keeps the
+    eigenpairs.  Both must match the oracle, and each other far below the parity bar."""
+    H, W, nr, nc, hx, hy, T, K, L = case
+    x = oracle.synthetic_luminance(H, W)
+    V_o, S_o = oracle.train_filter(x, nr, nc, hx, hy, T, K)
+    Y_o = oracle.apply_layers(V_o, S_o, x, L).reshape(L, -1)
+    ctx.set_mode(2)
+    try:
+        f_c, Y_c = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
+        monkeypatch.setenv("NLE_FORCE_EIG", "1")
+        f_e, Y_e = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
+    finally:
+        ctx.set_mode(0)
+    assert f_c.info()["K"] == f_e.info()["K"] == S_o.size
+    assert rel_l2(f_c.eigvals, f_e.eigvals) < 1e-8
+    tol = PER_LAYER_TOL if H * W >= 64 * nr * nc else 5e-4
+    for j in range(L):
+        assert rel_l2(Y_c[j], Y_o[j]) < tol and rel_l2(Y_e[j], Y_o[j]) < tol, f"layer {j}"
+        assert rel_l2(Y_c[j], Y_e[j]) < 1e-5, f"layer {j}"
+
+
 def test_errors_mirror_reference(nle, oracle, ctx):
     x = oracle.synthetic_luminance(20, 30).astype(np.float32)
     with pytest.raises(nle.NLEError, match="Number of samples per row and col must be <= that of image"):

@@ -45,6 +45,38 @@ DRIVER = textwrap.dedent(r"""
                 }
             if (err > 1e-9) { std::printf("n=%d: reconstruction error %g\n", n, err); ++bad; }
         }
+        // Cholesky + inverse + the trace certificate, and the small products
+        for (int n : {1, 2, 7, 33, 100}) {
+            std::vector<double> B((size_t)n * n), A((size_t)n * n, 0.0), L((size_t)n * n), Li((size_t)n * n), P((size_t)n * n);
+            for (auto& v : B) v = N(g);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double s = (i == j) ? 0.5 : 0.0;
+                    for (int k = 0; k < n; ++k) s += B[i + (size_t)k * n] * B[j + (size_t)k * n];
+                    A[i + (size_t)j * n] = s / n;
+                }
+            double tr = 0;
+            if (!nleh::cholesky_with_inverse(A.data(), n, L.data(), Li.data(), &tr)) { std::printf("n=%d: cholesky failed\n", n); ++bad; continue; }
+            nleh::gemm_nt_cols(L.data(), L.data(), P.data(), n, n, n, 0, n);   // L L^T
+            double err = 0;
+            for (size_t i = 0; i < P.size(); ++i) err = std::fmax(err, std::fabs(P[i] - A[i]));
+            nleh::gemm_nn_cols(Li.data(), L.data(), P.data(), n, n, n, 0, n);  // L^-1 L
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) err = std::fmax(err, std::fabs(P[i + (size_t)j * n] - (i == j)));
+            nleh::gemm_tn_cols(Li.data(), Li.data(), P.data(), n, n, n, 0, n);  // A^-1 = L^-T L^-1
+            double t2 = 0;
+            for (int i = 0; i < n; ++i) t2 += P[i + (size_t)i * n];
+            if (err > 1e-9 || std::fabs(t2 - tr) > 1e-9 * tr) { std::printf("n=%d: cholesky error %g trace %g vs %g\n", n, err, tr, t2); ++bad; }
+            std::vector<double> U((size_t)n * n), D(n);
+            int r = 0;
+            nleh::eigen_decomposition(A.data(), n, 0.0, U.data(), D.data(), &r);
+            if (D[n - 1] < 1.0 / tr * (1 - 1e-9)) { std::printf("n=%d: lambda_min %g below the certificate %g\n", n, D[n - 1], 1.0 / tr); ++bad; }
+        }
+        {   // not positive definite: must be refused
+            std::vector<double> A = {1, 2, 2, 1}, L(4), Li(4);
+            double tr;
+            if (nleh::cholesky_with_inverse(A.data(), 2, L.data(), Li.data(), &tr)) { std::printf("indefinite matrix accepted\n"); ++bad; }
+        }
         std::printf("bad=%d\n", bad);
         return bad;
     }
