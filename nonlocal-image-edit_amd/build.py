@@ -56,7 +56,7 @@ def build_lib(force: bool = False) -> str:
             o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
             if force or _newer(o, deps):
                 if s.endswith(".cpp"):  # host-only fp64 algebra: plain g++ (needs function multiversioning)
-                    _run(["g++", "-O3", "-fopenmp-simd", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
+                    _run(["g++", "-O3", "-fopenmp-simd", "-std=c++17", "-fPIC", "-pthread", "-Wno-psabi", "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
                 else:
                     _run([_hipcc(), "-x", "hip", "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC",
                           "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])

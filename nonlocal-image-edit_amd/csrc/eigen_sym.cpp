@@ -11,8 +11,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
+#include <cstdlib>
 #include <numeric>
+#include <thread>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace nleh {
 
@@ -179,6 +185,247 @@ NLE_SIMD_CLONES bool ql_implicit(int n, double* V, double* d, double* e) {
     return true;
 }
 
+// ---- the same solver in three barrier-free phases (what sym_eigen_top runs)
+//   1. tridiag_reduce: the reduction half of `tridiagonalize` (Householder vectors u_i stay in column i,
+//      rows 0..i-1, with scale h_i in hs[i]); the orthogonal factor is never formed.
+//   2. ql_record: implicit QL on (d, e) alone, RECORDING the plane rotations of every sweep.
+//   3. The rotations are applied to Z = I by independent row blocks (one pass over a block per sweep, the
+//      shared column of consecutive rotations carried in registers), then only the wanted columns of Z are
+//      back-transformed with the Householder vectors, by independent column blocks.
+// Phases 3a/3b split over threads without any synchronisation, which the per-sweep update of the classic
+// loop does not allow.
+NLE_SIMD_CLONES void tridiag_reduce(int n, double* V, double* d, double* e, double* hs) {
+    for (int j = 0; j < n; ++j) d[j] = at(V, n, n - 1, j);
+    for (int i = n - 1; i > 0; --i) {
+        double scale = 0.0, h = 0.0;
+        for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
+            for (int j = 0; j < i; ++j) {
+                d[j] = at(V, n, i - 1, j);
+                at(V, n, i, j) = 0.0;
+                at(V, n, j, i) = 0.0;
+            }
+        } else {
+            for (int k = 0; k < i; ++k) {
+                d[k] /= scale;
+                h += d[k] * d[k];
+            }
+            double f = d[i - 1];
+            double g = std::sqrt(h);
+            if (f > 0) g = -g;
+            e[i] = scale * g;
+            h -= f * g;
+            d[i - 1] = f - g;
+            for (int j = 0; j < i; ++j) e[j] = 0.0;
+            for (int j = 0; j < i; ++j) {
+                f = d[j];
+                at(V, n, j, i) = f;
+                g = e[j] + at(V, n, j, j) * f;
+                const double* col = &at(V, n, 0, j);
+                double gs = 0.0;
+#pragma omp simd reduction(+ : gs)
+                for (int k = j + 1; k <= i - 1; ++k) {
+                    gs += col[k] * d[k];
+                    e[k] += col[k] * f;
+                }
+                e[j] = g + gs;
+            }
+            f = 0.0;
+            for (int j = 0; j < i; ++j) {
+                e[j] /= h;
+                f += e[j] * d[j];
+            }
+            const double hh = f / (h + h);
+            for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+            for (int j = 0; j < i; ++j) {
+                f = d[j];
+                g = e[j];
+                double* col = &at(V, n, 0, j);
+#pragma omp simd
+                for (int k = j; k <= i - 1; ++k) col[k] -= (f * e[k] + g * d[k]);
+                d[j] = at(V, n, i - 1, j);
+                at(V, n, i, j) = 0.0;
+            }
+        }
+        hs[i] = h;
+    }
+    hs[0] = 0.0;
+    for (int j = 0; j < n; ++j) d[j] = at(V, n, j, j);  // the diagonal of T
+    e[0] = 0.0;
+}
+
+struct Sweep {
+    int l, m;      // rotations act on columns (i, i+1) for i = m-1 .. l
+    size_t first;  // index of the i = m-1 rotation in the (c, s) lists
+};
+
+bool ql_record(int n, double* d, double* e, std::vector<Sweep>& sweeps, std::vector<double>& cs, std::vector<double>& sn) {
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = std::ldexp(1.0, -52);
+    for (int l = 0; l < n; ++l) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int m = l;
+        while (m < n) {
+            if (std::fabs(e[m]) <= eps * tst1) break;
+            ++m;
+        }
+        if (m > l) {
+            int iter = 0;
+            do {
+                if (++iter > 60) return false;
+                double g = d[l];
+                double p = (d[l + 1] - g) / (2.0 * e[l]);
+                double r = hyp(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r);
+                d[l + 1] = e[l] * (p + r);
+                const double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] -= h;
+                f += h;
+                p = d[m];
+                double c = 1.0, c2 = c, c3 = c;
+                const double el1 = e[l + 1];
+                double s = 0.0, s2 = 0.0;
+                sweeps.push_back(Sweep{l, m, cs.size()});
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2;
+                    c2 = c;
+                    s2 = s;
+                    g = c * e[i];
+                    h = c * p;
+                    r = hyp(p, e[i]);
+                    e[i + 1] = s * r;
+                    s = e[i] / r;
+                    c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    cs.push_back(c);
+                    sn.push_back(s);
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p;
+                d[l] = c * p;
+            } while (std::fabs(e[l]) > eps * tst1);
+        }
+        d[l] += f;
+        e[l] = 0.0;
+    }
+    return true;
+}
+
+// Rows [k0, k0 + 8 NV) of Z (column-major, leading dimension ldz, a multiple of 8): every sweep's rotations,
+// in order.  Consecutive rotations share a column; its running value stays in NV vector registers, so each
+// column is loaded and stored once per sweep, and NV independent dependency chains hide the FMA latency.
+typedef double v8d __attribute__((vector_size(64)));
+static inline __attribute__((always_inline)) v8d ld8(const double* p) {
+    v8d v;
+    __builtin_memcpy(&v, p, sizeof(v));
+    return v;
+}
+static inline __attribute__((always_inline)) void st8(double* p, v8d v) { __builtin_memcpy(p, &v, sizeof(v)); }
+
+template <int NV>
+static inline __attribute__((always_inline)) void rotate_rows(int ldz, double* Z, int k0, const Sweep* sweeps,
+                                                              size_t nsweeps, const double* cs, const double* sn) {
+    for (size_t q = 0; q < nsweeps; ++q) {
+        const Sweep sw = sweeps[q];
+        const double* c = cs + sw.first;
+        const double* s = sn + sw.first;
+        v8d carry[NV];
+        const double* top = Z + (size_t)sw.m * ldz + k0;
+#pragma GCC unroll 8
+        for (int v = 0; v < NV; ++v) carry[v] = ld8(top + 8 * v);
+        for (int i = sw.m - 1, t = 0; i >= sw.l; --i, ++t) {
+            const double ci = c[t], si = s[t];
+            double* vi = Z + (size_t)i * ldz + k0;
+            double* vi1 = vi + ldz;
+#pragma GCC unroll 8
+            for (int v = 0; v < NV; ++v) {
+                const v8d hk = carry[v], vk = ld8(vi + 8 * v);
+                st8(vi1 + 8 * v, si * vk + ci * hk);
+                carry[v] = ci * vk - si * hk;
+            }
+        }
+        double* bot = Z + (size_t)sw.l * ldz + k0;
+#pragma GCC unroll 8
+        for (int v = 0; v < NV; ++v) st8(bot + 8 * v, carry[v]);
+    }
+}
+
+// Z starts as the identity, so entries far from the diagonal are products of many sines and pass through the
+// denormal range on their way to zero; denormal operands cost ~100 cycles each on x86.  They are flushed
+// to zero for the duration of the phase (a change below 1e-307 in an orthogonal matrix).
+struct FlushDenormals {
+#if defined(__x86_64__)
+    unsigned saved = _mm_getcsr();
+    FlushDenormals() { _mm_setcsr(saved | 0x8040); }  // FTZ | DAZ
+    ~FlushDenormals() { _mm_setcsr(saved); }
+#endif
+};
+
+NLE_SIMD_CLONES void apply_rotations_rows(int ldz, double* Z, int k0, int nvec, const Sweep* sweeps, size_t nsweeps,
+                                          const double* cs, const double* sn) {
+    FlushDenormals ftz;
+    while (nvec > 0) {  // 8, 4, 2, 1 vectors of 8 rows
+        if (nvec >= 8) {
+            rotate_rows<8>(ldz, Z, k0, sweeps, nsweeps, cs, sn);
+            nvec -= 8, k0 += 64;
+        } else if (nvec >= 4) {
+            rotate_rows<4>(ldz, Z, k0, sweeps, nsweeps, cs, sn);
+            nvec -= 4, k0 += 32;
+        } else if (nvec >= 2) {
+            rotate_rows<2>(ldz, Z, k0, sweeps, nsweeps, cs, sn);
+            nvec -= 2, k0 += 16;
+        } else {
+            rotate_rows<1>(ldz, Z, k0, sweeps, nsweeps, cs, sn);
+            nvec -= 1, k0 += 8;
+        }
+    }
+}
+
+// Y (n x ncols, column-major, ld n) <- Q Y with Q = P_{n-1} ... P_1, P_i = I - u_i u_i^T / h_i on rows 0..i-1
+// (u_i = column i of V, rows 0..i-1): the product `tridiagonalize` accumulates, applied to a few columns.
+NLE_SIMD_CLONES void back_transform_cols(int n, const double* V, const double* hs, double* Y, int j0, int j1) {
+    constexpr int CB = 4;
+    for (int jb = j0; jb < j1; jb += CB) {
+        const int nb = std::min(CB, j1 - jb);
+        for (int i = 1; i < n; ++i) {
+            const double h = hs[i];
+            if (h == 0.0) continue;
+            const double* u = V + (size_t)i * n;
+            for (int jj = 0; jj < nb; ++jj) {
+                double* y = Y + (size_t)(jb + jj) * n;
+                double g = 0.0;
+#pragma omp simd reduction(+ : g)
+                for (int k = 0; k < i; ++k) g += u[k] * y[k];
+                g /= h;
+#pragma omp simd
+                for (int k = 0; k < i; ++k) y[k] -= g * u[k];
+            }
+        }
+    }
+}
+
+template <typename F>
+void run_split(int nparts, int nthreads, F&& body) {  // body(part) for part in [0, nparts), split over threads
+    nthreads = std::max(1, std::min(nthreads, nparts));
+    if (nthreads == 1) {
+        for (int q = 0; q < nparts; ++q) body(q);
+        return;
+    }
+    std::vector<std::thread> th;
+    auto work = [&](int t) {
+        for (int q = t; q < nparts; q += nthreads) body(q);
+    };
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+}
+
 // right-looking Cholesky on the lower triangle, column-major (all inner loops unit stride)
 NLE_SIMD_CLONES bool cholesky_lower(int n, double* A) {
     for (int j = 0; j < n; ++j) {
@@ -217,47 +464,75 @@ NLE_SIMD_CLONES void lower_inverse(int n, const double* L, double* X) {
 
 }  // namespace
 
-NLE_SIMD_CLONES void gemm_nn_cols(const double* A, const double* B, double* C, int m, int k, int n, int j0, int j1) {
-    (void)n;
-    for (int j = j0; j < j1; ++j) {
-        double* cc = C + (size_t)j * m;
-        std::fill(cc, cc + m, 0.0);
-        int l = 0;
-        for (; l + 3 < k; l += 4) {  // four columns of A per sweep over the output column
-            const double b0 = B[(size_t)j * k + l], b1 = B[(size_t)j * k + l + 1], b2 = B[(size_t)j * k + l + 2],
-                         b3 = B[(size_t)j * k + l + 3];
-            const double *a0 = A + (size_t)l * m, *a1 = a0 + m, *a2 = a1 + m, *a3 = a2 + m;
-#pragma omp simd
-            for (int i = 0; i < m; ++i) cc[i] += (a0[i] * b0 + a1[i] * b1) + (a2[i] * b2 + a3[i] * b3);
-        }
-        for (; l < k; ++l) {
-            const double b = B[(size_t)j * k + l];
-            const double* a = A + (size_t)l * m;
-#pragma omp simd
-            for (int i = 0; i < m; ++i) cc[i] += a[i] * b;
+// C[:, j0:j1) = A * op(B): register-blocked, 16 rows (two 8-wide vectors) x 6 columns of C per micro-tile,
+// the k loop innermost (2 vector loads of A and 6 scalar loads of B per 12 FMAs); rows beyond a multiple
+// of 16 fall back to 8-row and scalar tiles.  BT selects B^T (B stored n x k) for the nt form.
+template <bool BT, int NR>
+static inline __attribute__((always_inline)) void gemm_tile16(const double* A, const double* B, double* C, int m, int k,
+                                                              int n, int i0, int j) {
+    v8d acc0[NR], acc1[NR];
+#pragma GCC unroll 6
+    for (int q = 0; q < NR; ++q) acc0[q] = acc1[q] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int l = 0; l < k; ++l) {
+        const v8d a0 = ld8(A + (size_t)l * m + i0), a1 = ld8(A + (size_t)l * m + i0 + 8);
+#pragma GCC unroll 6
+        for (int q = 0; q < NR; ++q) {
+            const double b = BT ? B[(size_t)l * n + j + q] : B[(size_t)(j + q) * k + l];
+            acc0[q] += a0 * b;
+            acc1[q] += a1 * b;
         }
     }
+#pragma GCC unroll 6
+    for (int q = 0; q < NR; ++q) {
+        st8(C + (size_t)(j + q) * m + i0, acc0[q]);
+        st8(C + (size_t)(j + q) * m + i0 + 8, acc1[q]);
+    }
+}
+template <bool BT, int NR>
+static inline __attribute__((always_inline)) void gemm_tile8(const double* A, const double* B, double* C, int m, int k,
+                                                             int n, int i0, int j) {
+    v8d acc[NR];
+#pragma GCC unroll 6
+    for (int q = 0; q < NR; ++q) acc[q] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int l = 0; l < k; ++l) {
+        const v8d a0 = ld8(A + (size_t)l * m + i0);
+#pragma GCC unroll 6
+        for (int q = 0; q < NR; ++q) acc[q] += a0 * (BT ? B[(size_t)l * n + j + q] : B[(size_t)(j + q) * k + l]);
+    }
+#pragma GCC unroll 6
+    for (int q = 0; q < NR; ++q) st8(C + (size_t)(j + q) * m + i0, acc[q]);
+}
+template <bool BT, int NR>
+static inline __attribute__((always_inline)) void gemm_panel(const double* A, const double* B, double* C, int m, int k,
+                                                             int n, int j) {
+    int i0 = 0;
+    for (; i0 + 16 <= m; i0 += 16) gemm_tile16<BT, NR>(A, B, C, m, k, n, i0, j);
+    if (i0 + 8 <= m) {
+        gemm_tile8<BT, NR>(A, B, C, m, k, n, i0, j);
+        i0 += 8;
+    }
+    for (; i0 < m; ++i0)
+        for (int q = 0; q < NR; ++q) {
+            double sacc = 0.0;
+            for (int l = 0; l < k; ++l) sacc += A[(size_t)l * m + i0] * (BT ? B[(size_t)l * n + j + q] : B[(size_t)(j + q) * k + l]);
+            C[(size_t)(j + q) * m + i0] = sacc;
+        }
+}
+template <bool BT>
+static inline __attribute__((always_inline)) void gemm_cols(const double* A, const double* B, double* C, int m, int k,
+                                                            int n, int j0, int j1) {
+    int j = j0;
+    for (; j + 6 <= j1; j += 6) gemm_panel<BT, 6>(A, B, C, m, k, n, j);
+    for (; j + 2 <= j1; j += 2) gemm_panel<BT, 2>(A, B, C, m, k, n, j);
+    for (; j < j1; ++j) gemm_panel<BT, 1>(A, B, C, m, k, n, j);
+}
+
+NLE_SIMD_CLONES void gemm_nn_cols(const double* A, const double* B, double* C, int m, int k, int n, int j0, int j1) {
+    gemm_cols<false>(A, B, C, m, k, n, j0, j1);
 }
 
 NLE_SIMD_CLONES void gemm_nt_cols(const double* A, const double* B, double* C, int m, int k, int n, int j0, int j1) {
-    for (int j = j0; j < j1; ++j) {
-        double* cc = C + (size_t)j * m;
-        std::fill(cc, cc + m, 0.0);
-        int l = 0;
-        for (; l + 3 < k; l += 4) {
-            const double b0 = B[(size_t)l * n + j], b1 = B[(size_t)(l + 1) * n + j], b2 = B[(size_t)(l + 2) * n + j],
-                         b3 = B[(size_t)(l + 3) * n + j];
-            const double *a0 = A + (size_t)l * m, *a1 = a0 + m, *a2 = a1 + m, *a3 = a2 + m;
-#pragma omp simd
-            for (int i = 0; i < m; ++i) cc[i] += (a0[i] * b0 + a1[i] * b1) + (a2[i] * b2 + a3[i] * b3);
-        }
-        for (; l < k; ++l) {
-            const double b = B[(size_t)l * n + j];
-            const double* a = A + (size_t)l * m;
-#pragma omp simd
-            for (int i = 0; i < m; ++i) cc[i] += a[i] * b;
-        }
-    }
+    gemm_cols<true>(A, B, C, m, k, n, j0, j1);
 }
 
 NLE_SIMD_CLONES void gemm_tn_cols(const double* A, const double* B, double* C, int m, int k, int n, int j0, int j1) {
@@ -314,19 +589,82 @@ bool sym_eigen(const double* M, int n, double* U, double* D) {
     return true;
 }
 
-bool eigen_decomposition(const double* M, int n, double eps, double* U, double* D, int* r_out) {
-    std::vector<double> Ua((size_t)n * n), Da(n);
-    if (!sym_eigen(M, n, Ua.data(), Da.data())) return false;
-    // reference src/filter.cpp:209-216: reverse to descending, keep leading run >= eps
-    int r = 0;
-    for (int j = 0; j < n; ++j) {
-        const int src = n - 1 - j;
-        D[j] = Da[src];
-        std::copy(Ua.begin() + (size_t)src * n, Ua.begin() + (size_t)src * n + n, U + (size_t)j * n);
+// Threads for the two parallel phases.  Measured on the GPU box's host (EPYC 9575F, 16-CPU quota spread over
+// 256 logical CPUs): short-lived threads land on other core complexes and make n = 200 slower (1.3 -> 2.8 ms)
+// and n = 900 no faster, so the default is one thread; NLE_EIG_THREADS overrides.
+int default_threads(int) {
+    if (const char* e = std::getenv("NLE_EIG_THREADS")) return std::max(1, std::atoi(e));
+    return 1;
+}
+
+bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, double* D) {
+    if (n <= 0) return true;
+    ncols = std::max(0, std::min(ncols, n));
+    if (n == 1) {
+        D[0] = M[0];
+        if (ncols) U[0] = 1.0;
+        return true;
     }
+    if (nthreads <= 0) nthreads = default_threads(n);
+    std::vector<double> V((size_t)n * n), d(n), e(n), hs(n);
+    for (int c = 0; c < n; ++c)  // mirror the lower triangle (SelfAdjointEigenSolver reads only the lower one)
+        for (int r = 0; r < n; ++r) V[(size_t)c * n + r] = (r >= c) ? M[(size_t)c * n + r] : M[(size_t)r * n + c];
+    tridiag_reduce(n, V.data(), d.data(), e.data(), hs.data());
+    std::vector<Sweep> sweeps;
+    std::vector<double> cs, sn;
+    cs.reserve((size_t)n * n);
+    sn.reserve((size_t)n * n);
+    if (!ql_record(n, d.data(), e.data(), sweeps, cs, sn)) return false;
+    // descending order (stable on the ascending sort the classic path uses, reversed)
+    std::vector<int> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return d[a] < d[b]; });
+    std::reverse(idx.begin(), idx.end());
+    for (int j = 0; j < n; ++j) D[j] = d[idx[j]];
+    if (ncols == 0) return true;
+    const int ldz = (n + 7) & ~7;  // rows padded to whole 8-row vectors (the padding stays zero)
+    // (64-byte aligned: the 64-row blocks of different threads then never share a cache line)
+    std::vector<double> Zbuf((size_t)ldz * n + 8, 0.0);
+    double* Z = Zbuf.data();
+    while (reinterpret_cast<uintptr_t>(Z) & 63) ++Z;
+    for (int i = 0; i < n; ++i) Z[(size_t)i * ldz + i] = 1.0;
+    const int nvec = ldz / 8, nblocks = (nvec + 7) / 8;  // 64-row blocks
+    run_split(nblocks, nthreads, [&](int b) {
+        apply_rotations_rows(ldz, Z, b * 64, std::min(8, nvec - b * 8), sweeps.data(), sweeps.size(), cs.data(), sn.data());
+    });
+    for (int j = 0; j < ncols; ++j) std::copy(Z + (size_t)idx[j] * ldz, Z + (size_t)idx[j] * ldz + n, U + (size_t)j * n);
+    const int cparts = std::max(1, std::min(nthreads, (ncols + 3) / 4));
+    run_split(cparts, nthreads, [&](int q) {
+        const int j0 = (int)((long long)ncols * q / cparts), j1 = (int)((long long)ncols * (q + 1) / cparts);
+        back_transform_cols(n, V.data(), hs.data(), U, j0, j1);
+    });
+    return true;
+}
+
+bool eigen_decomposition_top(const double* M, int n, double eps, int kmax, double* U, double* D, int* r_out) {
+    kmax = std::max(0, std::min(kmax, n));
+    if (2 * kmax > n) {
+        // most eigenvectors wanted: accumulating the orthogonal factor (classic form) is cheaper than
+        // back-transforming them one by one (n = 200: 1.65 ms against 1.9 ms)
+        std::vector<double> Ua((size_t)n * n), Da(n);
+        if (!sym_eigen(M, n, Ua.data(), Da.data())) return false;
+        for (int j = 0; j < n; ++j) {  // ascending -> descending
+            const int src = n - 1 - j;
+            D[j] = Da[src];
+            if (j < kmax) std::copy(Ua.begin() + (size_t)src * n, Ua.begin() + (size_t)src * n + n, U + (size_t)j * n);
+        }
+    } else if (!sym_eigen_top(M, n, kmax, 0, U, D)) {
+        return false;
+    }
+    // reference src/filter.cpp:209-216: descending, keep the leading run >= eps
+    int r = 0;
     while (r < n && D[r] >= eps) ++r;
     *r_out = r;
     return true;
+}
+
+bool eigen_decomposition(const double* M, int n, double eps, double* U, double* D, int* r_out) {
+    return eigen_decomposition_top(M, n, eps, n, U, D, r_out);
 }
 
 }  // namespace nleh

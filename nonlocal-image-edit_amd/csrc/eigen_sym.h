@@ -12,6 +12,15 @@ bool sym_eigen(const double* M, int n, double* U, double* D);
 // filled but not part of the result).
 bool eigen_decomposition(const double* M, int n, double eps, double* U, double* D, int* r);
 
+// Same, but only the eigenvectors of the `kmax` largest eigenvalues are formed (U: n x min(kmax, n));
+// D still receives all n eigenvalues.  What orthogonalize needs (:314 keeps nEigVectors columns).
+bool eigen_decomposition_top(const double* M, int n, double eps, int kmax, double* U, double* D, int* r);
+
+// All eigenvalues DESCENDING in D and the first `ncols` eigenvectors in U (n x ncols); nthreads <= 0 picks the
+// default (1; NLE_EIG_THREADS overrides).  The rotation and back-transformation phases need no barriers and
+// can run on short-lived threads.
+bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, double* D);
+
 // Cholesky factor of a symmetric positive definite matrix (lower triangle of M read): L is n x n
 // column-major lower triangular (zeros above the diagonal), Linv = L^-1 likewise.  Returns false if
 // a pivot is not positive.  *inv_trace = trace(M^-1) = ||Linv||_F^2, so every eigenvalue of M is at

@@ -1408,22 +1408,9 @@ __global__ __launch_bounds__(256) void k_ghist_rows_chunk(const float* __restric
         double q[kGhistMaxCols];
 #pragma unroll
         for (int b = 0; b < kGhistMaxCols; ++b) q[b] = (b < nC) ? cf * ecT[(size_t)b * W + c] : 0.0;
-        const bool own = wave_group_levels(cf != 0.0, x, [&](int lx, bool mine) {
-            double* Al = A + (size_t)lx * npairs;
-            int idx = 0;
-#pragma unroll
-            for (int b = 0; b < kGhistMaxCols; ++b) {
-                if (b >= b0 && b < b1) {  // wave-uniform
-#pragma unroll
-                    for (int b2 = b; b2 < kGhistMaxCols; ++b2)
-                        if (b2 < nC) {
-                            const double t = wave_sum63(mine ? q[b] * q[b2] : 0.0);
-                            if ((tid & 63) == 63) atomicAdd(&Al[idx], t);
-                            ++idx;
-                        }
-                }
-            }
-        });
+        // (no wave-level pre-reduction here: with 36 x 36 unrolled products it would double an already large
+        // kernel and spill; flat regions cost this kernel their same-address serialisation)
+        const bool own = cf != 0.0;
         if (own) {
             double* Ax = A + (size_t)x * npairs;
             int idx = 0;

@@ -554,11 +554,12 @@ std::vector<double> gram_all(nle_ctx* c, const float* d_phi, long long M, int ld
 }
 
 // ---- small host algebra, column-major ----
-// The p x p products of the orthogonalisation are split by output columns over a few short-lived
-// threads (a 200^3 product is ~2 ms on one core; thread start-up is ~50 us).
+// The p x p products of the orthogonalisation run on the register-blocked kernels of eigen_sym.cpp (a 200^3
+// product is ~0.2 ms on one core); only products of more than ~80 MFLOP per thread are split by output
+// columns over short-lived threads (thread start-up and remote caches cost more than that on the GPU box).
 template <typename F>
 void par_cols(int n, long long work_per_col, F&& body) {
-    int nt = (int)std::min<long long>(work_per_col * n > 200000000ll ? 16 : 4, (work_per_col * n) / 2000000 + 1);
+    int nt = (int)std::min<long long>(16, (work_per_col * n) / 40000000 + 1);
     if (const char* e = std::getenv("NLE_HOST_THREADS")) nt = std::max(1, std::atoi(e));
     nt = std::min(nt, n);
     if (nt <= 1) {
@@ -670,9 +671,9 @@ Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_
     mm(S.data(), WW.data(), T1.data(), q, q, q);
     mm(T1.data(), S.data(), Qm.data(), q, q, q);
     for (size_t i = 0; i < Qm.size(); ++i) Qm[i] += o.Wa[i];
-    std::vector<double> Vq((size_t)q * q), Sq(q);
+    std::vector<double> Vq((size_t)q * std::min(q, std::max(n_eig, 1))), Sq(q);  // only the kept eigenvectors (:314)
     int rq = 0;
-    if (!nleh::eigen_decomposition(Qm.data(), q, NLE_EPS, Vq.data(), Sq.data(), &rq))
+    if (!nleh::eigen_decomposition_top(Qm.data(), q, NLE_EPS, n_eig, Vq.data(), Sq.data(), &rq))
         throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Q"};
     const int K = std::min(n_eig, rq);  // :314
     if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
@@ -802,9 +803,9 @@ void ortho_ss_finish(OrthoSS& o, std::vector<double> Gk, int n_eig) {
     mm(o.St.data(), WW.data(), T1.data(), q, q, q);
     mm(T1.data(), S.data(), Qm.data(), q, q, q);
     for (size_t i = 0; i < Qm.size(); ++i) Qm[i] += o.A2[i];  // :296
-    std::vector<double> Vq((size_t)q * q), Sq(q);
+    std::vector<double> Vq((size_t)q * std::min(q, std::max(n_eig, 1))), Sq(q);  // only the kept eigenvectors (:314)
     int rq = 0;
-    if (!nleh::eigen_decomposition(Qm.data(), q, NLE_EPS, Vq.data(), Sq.data(), &rq))
+    if (!nleh::eigen_decomposition_top(Qm.data(), q, NLE_EPS, n_eig, Vq.data(), Sq.data(), &rq))
         throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Q"};
     const int K = std::min(n_eig, rq);  // :314
     if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};

@@ -88,7 +88,7 @@ def test_eigensolver_under_asan_ubsan(tmp_path):
     drv = tmp_path / "drv.cpp"
     drv.write_text(DRIVER)
     exe = tmp_path / "drv"
-    cmd = ["g++", "-O1", "-g", "-fopenmp-simd", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+    cmd = ["g++", "-O1", "-g", "-fopenmp-simd", "-pthread", "-Wno-psabi", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
            "-I", CSRC, str(drv), os.path.join(CSRC, "eigen_sym.cpp"), "-o", str(exe)]
     b = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     if b.returncode != 0 and "sanitize" in b.stderr:
