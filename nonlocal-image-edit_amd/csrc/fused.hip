@@ -932,7 +932,7 @@ hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, i
 // -------------------------------------------------------------------- tiled form of the table pass
 // k_sink_hist re-reads the whole Ep table (256 x p doubles) twice per image row from L2, which is
 // what bounds it.  The tiled form splits the pass into three kernels so that Ep is read ~once:
-//   k_hist_g   : g[r][x,b] = sum_a er[r][a] w[a,b] Ep[x][a,b]   (32 rows x 8 levels per block)
+//   k_hist_g   : g[r][b,x] = sum_a er[r][a] w[a,b] Ep[x][a,b]   (fp64 MFMA; table columns are b-major)
 //   k_hist_pix : per image row: d_i, y_i, h[r][x,b] += ec y      (g row and h row in LDS)
 //   k_hist_hh  : HH[slab][x,b][a] = sum_{r in slab} er[r][a] h[r][x,b]
 //   k_hist_z   : z[a,b] = sum_x Ep[x][a,b] sum_slab HH[slab][x,b][a]
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(256) void k_hist_g(GridSpec gs, int p, int nrows, i
     if (n0 >= n) return;  // wave-uniform
     const int col = n0 + l15;
     const bool col_ok = col < n;
-    const int x = col_ok ? col / nC : 0, b = col_ok ? col - x * nC : 0;
+    const int b = col_ok ? col / kLevels : 0, x = col & (kLevels - 1);  // table columns are b-major: col = b*256 + x
     double bop[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restr
     const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
     const double* grow = g + (size_t)lrow * n;
     for (int i = tid; i < n; i += 256) {
-        const int xx = i / NC, bb = i - xx * NC;
+        const int bb = i / kLevels, xx = i & (kLevels - 1);  // global tables are b-major, the LDS copies level-major
         sh[xx * NS + bb] = 0.0;
         sg[xx * NS + bb] = (mode == ROWPASS_RECIP) ? grow[i] : 0.0;
     }
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restr
     __syncthreads();
     double* hrow = hout + (size_t)lrow * n;
     for (int i = tid; i < n; i += 256) {
-        const int xx = i / NC, bb = i - xx * NC;
+        const int bb = i / kLevels, xx = i & (kLevels - 1);
         hrow[i] = sh[xx * NS + bb];
     }
 }
@@ -1070,17 +1070,18 @@ __global__ __launch_bounds__(256) void k_hist_dot(const float* __restrict__ lum,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int n = kLevels * NC;
     const int W = gs.W;
-    double* sg = reinterpret_cast<double*>(smem_raw);  // [256][NC]
+    constexpr int NS = NC | 1;                          // odd row stride, as in k_hist_pix
+    double* sg = reinterpret_cast<double*>(smem_raw);  // [256][NS]
     const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
     const double* grow = g + (size_t)lrow * n;
-    for (int i = tid; i < n; i += 256) sg[i] = grow[i];
+    for (int i = tid; i < n; i += 256) sg[(i & (kLevels - 1)) * NS + i / kLevels] = grow[i];  // b-major -> level-major
     __syncthreads();
     for (int c = tid; c < W; c += 256) {
         const int x = (int)lum[(size_t)r * W + c];
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int b = 0; b < NC; ++b) {
-            const double t = ecT[(size_t)b * W + c] * sg[x * NC + b];
+            const double t = ecT[(size_t)b * W + c] * sg[x * NS + b];
             if (b & 1) s1 += t;
             else s0 += t;
         }
@@ -1197,7 +1198,7 @@ __global__ __launch_bounds__(256) void k_hist_z(int p, int ldp, int nC, int nR, 
     }
     const int a = sidx / nC, b = sidx - a * nC, n = kLevels * nC;
     double hs = 0.0;
-    for (int sl = 0; sl < nslabs; ++sl) hs += HH[((size_t)sl * nR + a) * n + (size_t)x * nC + b];
+    for (int sl = 0; sl < nslabs; ++sl) hs += HH[((size_t)sl * nR + a) * n + (size_t)b * kLevels + x];
     sm[x] = Ep[(size_t)x * p + sidx] * hs;
     __syncthreads();
     for (int off = kLevels / 2; off > 0; off >>= 1) {
@@ -1288,13 +1289,14 @@ hipError_t apply_hist_layer(hipStream_t s, const float* d_lum, GridSpec gs, int 
     if (obs) obs->end(), obs->begin(SUB_HIST_PIX);
 #define NLE_HD(NCV)                                                                                                  \
     case NCV: {                                                                                                      \
-        if (n * sizeof(double) > 48 * 1024) {                                                                        \
+        constexpr size_t shm_d = (size_t)kLevels * ((NCV) | 1) * sizeof(double);                                     \
+        if (shm_d > 48 * 1024) {                                                                                     \
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_dot<NCV>),                      \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(n * sizeof(double))); \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_d);             \
             if (ea != hipSuccess) return ea;                                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_hist_dot<NCV>), dim3((unsigned)nrows_local), dim3(256), n * sizeof(double), s, d_lum, gs, \
-                           row0, d_ecT, d_g, d_c, d_out);                                                            \
+        hipLaunchKernelGGL((k_hist_dot<NCV>), dim3((unsigned)nrows_local), dim3(256), shm_d, s, d_lum, gs, row0,     \
+                           d_ecT, d_g, d_c, d_out);                                                                  \
     } break;
     switch (nC) {
         NLE_HD(1) NLE_HD(2) NLE_HD(3) NLE_HD(4) NLE_HD(5) NLE_HD(6) NLE_HD(7) NLE_HD(8) NLE_HD(9) NLE_HD(10) NLE_HD(11)
@@ -1328,7 +1330,7 @@ hipError_t scatter_samples(hipStream_t s, int p, int L, const long long* d_loc, 
 // Gk[(a,b),(a',b')] = sum_r er[r][a] er[r][a'] sum_x Ep[x][a,b] Ep[x][a',b'] A_r[x][b,b'],
 // A_r[x][b,b'] = sum over the non-sample pixels of image row r with level x of c^2 ec[c][b] ec[c][b'].
 //   1. k_ghist_rows : A_r (256 x NP histogram in LDS, NP = nC(nC+1)/2 products per pixel) -> global
-//   2. k_ghist_gemm : C[(a,a')][x,(b,b')] = sum_r EE[r][(a,a')] A_r[x,(b,b')]   (fp64 MFMA GEMM,
+//   2. k_ghist_gemm : C[(a,a')][(b,b'),x] = sum_r EE[r][(a,a')] A_r[(b,b'),x]   (fp64 MFMA GEMM,
 //                     M = nR(nR+1)/2, N = 256 NP, K = local image rows)
 //   3. k_ghist_final: Gk[s][s'] = sum_x Ep[x][s] Ep[x][s'] C[(a,a')][x,(b,b')]
 // ~NP LDS adds per pixel plus a 46 GFLOP GEMM at cfg4, instead of p^2/2 = 20 kFLOP per pixel.
@@ -1338,16 +1340,18 @@ __device__ __forceinline__ int tri_index(int i, int j, int n) {  // i <= j < n, 
     return i * n - (i * (i - 1)) / 2 + (j - i);
 }
 
-__global__ __launch_bounds__(256) void k_ghist_rows(const float* __restrict__ lum, GridSpec gs, int row0,
+// (the histogram takes most of a CU's LDS, so one workgroup per CU: 512 threads keep 8 waves on it)
+constexpr int kGhistRowsThreads = 512;
+__global__ __launch_bounds__(kGhistRowsThreads) void k_ghist_rows(const float* __restrict__ lum, GridSpec gs, int row0,
                                                     const double* __restrict__ ecT,
                                                     const double* __restrict__ cvec, double* __restrict__ Aout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* A = reinterpret_cast<double*>(smem_raw);  // [256][NP]
     const int nC = gs.nSelCols, W = gs.W, NP = nC * (nC + 1) / 2;
     const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
-    for (int i = tid; i < kLevels * NP; i += 256) A[i] = 0.0;
+    for (int i = tid; i < kLevels * NP; i += kGhistRowsThreads) A[i] = 0.0;
     __syncthreads();
-    for (int c0 = 0; c0 < W; c0 += 256) {  // wave-uniform trip count: the body uses cross-lane sums
+    for (int c0 = 0; c0 < W; c0 += kGhistRowsThreads) {  // wave-uniform trip count: the body uses cross-lane sums
         const bool inside = c0 + tid < W;
         const int c = inside ? c0 + tid : W - 1;
         const double cf = inside ? cvec[(size_t)lrow * W + c] : 0.0;  // 0 at sample pixels
@@ -1379,8 +1383,8 @@ __global__ __launch_bounds__(256) void k_ghist_rows(const float* __restrict__ lu
         }
     }
     __syncthreads();
-    double* out = Aout + (size_t)lrow * kLevels * NP;
-    for (int i = tid; i < kLevels * NP; i += 256) out[i] = A[i];
+    double* out = Aout + (size_t)lrow * kLevels * NP;  // global layout [pair][level]: k_ghist_final streams levels
+    for (int i = tid; i < kLevels * NP; i += kGhistRowsThreads) out[i] = A[(i & (kLevels - 1)) * NP + i / kLevels];
 }
 
 // General form for 12 <= nC <= 36: the pair list does not fit in LDS at once, so a launch handles the
@@ -1425,10 +1429,10 @@ __global__ __launch_bounds__(256) void k_ghist_rows_chunk(const float* __restric
         }
     }
     __syncthreads();
-    double* out = Aout + (size_t)lrow * kLevels * NP + pair_off;
+    double* out = Aout + (size_t)lrow * kLevels * NP + (size_t)pair_off * kLevels;  // [pair][level]
     for (int i = tid; i < kLevels * npairs; i += 256) {
-        const int x = i / npairs, j = i - x * npairs;
-        out[(size_t)x * NP + j] = A[i];
+        const int j = i / kLevels, x = i & (kLevels - 1);
+        out[i] = A[x * npairs + j];
     }
 }
 
@@ -1497,20 +1501,19 @@ __global__ __launch_bounds__(256) void k_ghist_gemm(const double* __restrict__ E
 __global__ __launch_bounds__(256) void k_ghist_final(const double* __restrict__ C, long long N, int nsplit, size_t zstride,
                                                      const double* __restrict__ Ep, int p, int nR, int nC,
                                                      double* __restrict__ Gk) {
-    const int NP = nC * (nC + 1) / 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)p * p) return;
     const int s1 = (int)(idx / p), s2 = (int)(idx % p);
     int a1 = s1 / nC, b1 = s1 % nC, a2 = s2 / nC, b2 = s2 % nC;
     const int m = tri_index(min(a1, a2), max(a1, a2), nR);
     const int pc = tri_index(min(b1, b2), max(b1, b2), nC);
-    const double* Cm = C + (size_t)m * N + pc;
+    const double* Cm = C + (size_t)m * N + (size_t)pc * kLevels;  // columns are [pair][level]
     double t0 = 0.0, t1 = 0.0;
     for (int x = 0; x < kLevels; x += 2) {
         double c0 = 0.0, c1 = 0.0;
         for (int z = 0; z < nsplit; ++z) {  // fixed order
-            c0 += Cm[z * zstride + (size_t)x * NP];
-            c1 += Cm[z * zstride + (size_t)(x + 1) * NP];
+            c0 += Cm[z * zstride + x];
+            c1 += Cm[z * zstride + x + 1];
         }
         t0 += Ep[(size_t)x * p + s1] * Ep[(size_t)x * p + s2] * c0;
         t1 += Ep[(size_t)(x + 1) * p + s1] * Ep[(size_t)(x + 1) * p + s2] * c1;
@@ -1556,8 +1559,8 @@ hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int 
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ghist_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_ghist_rows, dim3((unsigned)nrows_local), dim3(256), shm, s, d_lum, gs, row0, d_ecT, d_c,
-                           d_A);
+        hipLaunchKernelGGL(k_ghist_rows, dim3((unsigned)nrows_local), dim3(kGhistRowsThreads), shm, s, d_lum, gs, row0,
+                           d_ecT, d_c, d_A);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ghist_rows_chunk),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLevels * kGhistChunkPairs * (int)sizeof(double));

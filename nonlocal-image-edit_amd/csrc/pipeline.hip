@@ -746,7 +746,10 @@ void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<do
     // G^T Q G (G = A^1/2 F orthogonal) with the same eigenvalues and the same product S Vq, hence the same
     // eigenvectors V (:327).  When A is provably free of eigenvalues below the cut, F = L^-T (Cholesky).
     o.S.resize((size_t)q * q);
-    if (std::getenv("NLE_FORCE_EIG") == nullptr) {
+    // (A^-1)_ii >= 1 / A_ii, so sum_i 1 / A_ii above the certificate's bound already rules the Cholesky form out
+    double inv_diag = 0.0;
+    for (int a = 0; a < q; ++a) inv_diag += o.Wa[(size_t)a * q + a] > 0.0 ? 1.0 / o.Wa[(size_t)a * q + a] : 1e300;
+    if (std::getenv("NLE_FORCE_EIG") == nullptr && inv_diag <= kCholMaxInvTrace) {
         std::vector<double> L((size_t)q * q), Li((size_t)q * q);
         double inv_trace = 0.0;
         if (nleh::cholesky_with_inverse(o.Wa.data(), q, L.data(), Li.data(), &inv_trace) && inv_trace <= kCholMaxInvTrace) {
