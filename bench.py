@@ -38,6 +38,7 @@ import __graft_entry__ as entry  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TF = 157.3        # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
 FP64_MFMA_PEAK_TF = 78.6    # MI355X FP64 matrix peak (spec; SURVEY.md section 8d quotes ~79 TFLOP/s fp64)
+LDS_F64_ATOMIC_PEAK = 1.49e12  # measured: tools/micro/lds_atomic_bench.hip, ds_add_f64 on a 256 x 11 histogram, random levels
 
 
 def roofline_models(info, L, form, grid, lazy=False):
@@ -127,6 +128,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--inflight", type=int, default=1, help="images in flight on one GPU (throughput mode, opt-in)")
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 materialised Phi, 2 Phi-free (NLE_MODE_*)")
     ap.add_argument("--cpu-sample", type=int, default=768, help="side of the CPU-baseline sample image")
     ap.add_argument("--cpu-threads", type=int, default=16, help="BLAS threads for the CPU baseline (<= visible cores)")
@@ -181,17 +183,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.profile(1)   # HIP events around the N-sized kernels of the timed region
+    # --inflight M (opt-in, single GPU): M images in flight, each on its own ctx/stream/host thread, so that one
+    # image's p-sized host algebra overlaps another's kernels.  Throughput mode; the default (1) is the latency
+    # of one image, which is what `value` is quoted on.
+    lanes = [(ctx, flt, out)]
+    for _ in range(1, args.inflight):
+        c2 = nle.Context(local_rank)
+        c2.set_mode(args.mode)
+        lanes.append((c2, nle.NLEFilter(c2), torch.empty_like(out)))
+
+    def run_steps(n):
+        if len(lanes) == 1:
+            for _ in range(n):
+                step()
+            return
+        import threading
+
+        def work(i):
+            torch.cuda.set_device(local_rank)
+            _, f_i, o_i = lanes[i]
+            for _ in range(i, n, len(lanes)):
+                f_i.train_filter(lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"])
+                f_i.apply_layers(lum, L, out=o_i)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(lanes))]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+
+    run_steps(args.warmup * len(lanes))
+    for c_, _, _ in lanes:
+        c_.profile(1)   # HIP events around the N-sized kernels of the timed region
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    stats = ctx.kernel_stats()
-    ctx.profile(False)
+    stats = {}
+    for c_, _, _ in lanes:
+        for k_, (n_, ms_) in c_.kernel_stats().items():
+            a_ = stats.get(k_, (0, 0.0))
+            stats[k_] = (a_[0] + n_, a_[1] + ms_)
+        c_.profile(False)
     info = flt.info()
     stage_ms = flt.timings()
     if dist is not None:
@@ -223,6 +256,14 @@ def main():
             rec.update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
             if name == "sinkhorn_pass" and form != "materialised":
                 rec["hbm_equivalent_GBs"] = info["n_local"] * info["r"] * 4.0 / (avg_ms * 1e-3) / 1e9
+            if form == "phi_free_tables" and name in ("sinkhorn_pass", "apply_reduce", "gram_rows"):
+                # what actually bounds the histogram kernels: LDS fp64 atomics (one per pixel and table column /
+                # column pair), against the chip's measured ds_add_f64 rate on this histogram shape
+                # (tools/micro/lds_atomic_bench.hip, profiles/r1_lds_atomic_micro.jsonl: random levels)
+                per_px = g["n_sel_cols"] if name != "gram_rows" else g["n_sel_cols"] * (g["n_sel_cols"] + 1) // 2
+                rate = info["n_local"] * per_px / (avg_ms * 1e-3)
+                rec["lds_atomics"] = {"achieved": rate, "measured_peak": LDS_F64_ATOMIC_PEAK, "unit": "lane-atomics/s",
+                                      "frac": rate / LDS_F64_ATOMIC_PEAK}
             rec["traffic"] = None
             for sym in kernel_symbols(form, lazy).get(name, ()):
                 hit = [v for k, v in traffic.items() if sym in k]
@@ -235,6 +276,8 @@ def main():
     roofline = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
                 "frac": d["frac"], "traffic": d.get("traffic"), "avg_launch_ms": d["avg_ms"],
                 "launches_per_step": d["launches_per_step"]}
+    if "lds_atomics" in d:
+        roofline["lds_atomics"] = d["lds_atomics"]
 
     # ---- CPU baseline: the fp64 numpy oracle on a bounded sample (rank 0, N = 1 only)
     cpu = None
@@ -257,6 +300,17 @@ def main():
         cpu = {"value": (Hs * Ws / 1e6) / tc, "unit": "MP/s", "cores": ncores, "kind": "port",
                "sample": f"{Hs}x{Ws} synthetic image, same samples/K/T/L as the workload (all N-sized work is linear "
                          f"in N), streaming fp64 numpy oracle with {ncores} BLAS threads, {tc:.1f} s"}
+        # the reference itself is single-threaded (Eigen without OpenMP, CMakeLists.txt:40-46): same oracle on one
+        # thread, on a quarter of the sample
+        H1 = W1 = max(128, args.cpu_sample // 2)
+        x1 = synth.synthetic_luminance(H1, W1)
+        with threadpool_limits(limits=1):
+            tc0 = time.perf_counter()
+            V_1, S_1 = oracle.train_filter_streaming(x1, cfg["n_row"], cfg["n_col"], W1 / 4.0, cfg["hy"], cfg["T"], cfg["K"])
+            oracle.apply_layers_streaming(V_1, S_1, x1, L)
+            t1 = time.perf_counter() - tc0
+        cpu["single_thread"] = {"value": (H1 * W1 / 1e6) / t1, "unit": "MP/s", "cores": 1,
+                                "sample": f"{H1}x{W1}, same oracle, 1 BLAS thread, {t1:.1f} s"}
 
     if rank == 0:
         line = {
@@ -266,9 +320,11 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {H}x{W} synthetic luminance, {cfg['n_row']}x{cfg['n_col']} samples "
                                    f"(p={p}), K={cfg['K']}, T={cfg['T']}, L={L} layers; input resident in HBM",
-                       "parallelism": f"row-slab x{world}" if world > 1 else "single GPU",
+                       "parallelism": (f"row-slab x{world}" if world > 1 else "single GPU")
+                       + (f", {args.inflight} images in flight" if args.inflight > 1 else ""),
                        "formulation": form + (" (V implicit, apply in sample space)" if lazy else ""),
-                       "storage": "fp64 tables, reductions and MFMA; fp32 affinities in the projection; V and outputs fp32"},
+                       "storage": ("fp64 tables, histograms, reductions and MFMA; fp32 output planes; V implicit" if lazy else
+                                   "fp64 reductions and Gram/projection MFMA; fp32 affinities, V and outputs")},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": per_kernel,
