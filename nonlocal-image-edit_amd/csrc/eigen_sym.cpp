@@ -590,11 +590,11 @@ bool sym_eigen(const double* M, int n, double* U, double* D) {
 }
 
 // Threads for the two parallel phases.  Measured on the GPU box's host (EPYC 9575F, 16-CPU quota spread over
-// 256 logical CPUs): short-lived threads land on other core complexes and make n = 200 slower (1.3 -> 2.8 ms)
-// and n = 900 no faster, so the default is one thread; NLE_EIG_THREADS overrides.
-int default_threads(int) {
+// 256 logical CPUs): short-lived threads land on other core complexes and make n = 200 slower (1.3 -> 2.8 ms),
+// while n = 900 gains (124 -> 74 ms with 4 threads, 62 ms with 16).  NLE_EIG_THREADS overrides.
+int default_threads(int n) {
     if (const char* e = std::getenv("NLE_EIG_THREADS")) return std::max(1, std::atoi(e));
-    return 1;
+    return n >= 512 ? 8 : 1;
 }
 
 bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, double* D) {
@@ -643,9 +643,10 @@ bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, d
 
 bool eigen_decomposition_top(const double* M, int n, double eps, int kmax, double* U, double* D, int* r_out) {
     kmax = std::max(0, std::min(kmax, n));
-    if (2 * kmax > n) {
-        // most eigenvectors wanted: accumulating the orthogonal factor (classic form) is cheaper than
-        // back-transforming them one by one (n = 200: 1.65 ms against 1.9 ms)
+    if (2 * kmax > n && default_threads(n) == 1) {
+        // most eigenvectors wanted, one thread: accumulating the orthogonal factor (classic form) is cheaper
+        // than back-transforming them one by one (n = 200: 1.65 ms against 1.9 ms; n = 900: 116 against 124 ms,
+        // but 62-74 ms once the two phases are threaded)
         std::vector<double> Ua((size_t)n * n), Da(n);
         if (!sym_eigen(M, n, Ua.data(), Da.data())) return false;
         for (int j = 0; j < n; ++j) {  // ascending -> descending

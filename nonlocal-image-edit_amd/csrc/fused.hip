@@ -1393,7 +1393,7 @@ __global__ __launch_bounds__(kGhistRowsThreads) void k_ghist_rows(const float* _
 constexpr int kGhistMaxCols = 36;
 constexpr int kGhistChunkPairs = 72;  // 256 * 72 * 8 B = 147 KB of LDS
 
-__global__ __launch_bounds__(256) void k_ghist_rows_chunk(const float* __restrict__ lum, GridSpec gs, int row0, int b0,
+__global__ __launch_bounds__(kGhistRowsThreads) void k_ghist_rows_chunk(const float* __restrict__ lum, GridSpec gs, int row0, int b0,
                                                           int b1, int pair_off, int npairs,
                                                           const double* __restrict__ ecT,
                                                           const double* __restrict__ cvec,
@@ -1402,9 +1402,9 @@ __global__ __launch_bounds__(256) void k_ghist_rows_chunk(const float* __restric
     double* A = reinterpret_cast<double*>(smem_raw);  // [256][npairs]
     const int nC = gs.nSelCols, W = gs.W, NP = nC * (nC + 1) / 2;
     const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
-    for (int i = tid; i < kLevels * npairs; i += 256) A[i] = 0.0;
+    for (int i = tid; i < kLevels * npairs; i += kGhistRowsThreads) A[i] = 0.0;
     __syncthreads();
-    for (int c0 = 0; c0 < W; c0 += 256) {  // wave-uniform trip count: the body uses cross-lane sums
+    for (int c0 = 0; c0 < W; c0 += kGhistRowsThreads) {  // wave-uniform trip count: the body uses cross-lane sums
         const bool inside = c0 + tid < W;
         const int c = inside ? c0 + tid : W - 1;
         const double cf = inside ? cvec[(size_t)lrow * W + c] : 0.0;  // 0 at sample pixels
@@ -1430,7 +1430,7 @@ __global__ __launch_bounds__(256) void k_ghist_rows_chunk(const float* __restric
     }
     __syncthreads();
     double* out = Aout + (size_t)lrow * kLevels * NP + (size_t)pair_off * kLevels;  // [pair][level]
-    for (int i = tid; i < kLevels * npairs; i += 256) {
+    for (int i = tid; i < kLevels * npairs; i += kGhistRowsThreads) {
         const int j = i / kLevels, x = i & (kLevels - 1);
         out[i] = A[x * npairs + j];
     }
@@ -1573,7 +1573,7 @@ hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int 
                 ++b1;
             }
             if (b1 == b0) return hipErrorInvalidValue;  // cannot happen for nC <= 36 < 72
-            hipLaunchKernelGGL(k_ghist_rows_chunk, dim3((unsigned)nrows_local), dim3(256),
+            hipLaunchKernelGGL(k_ghist_rows_chunk, dim3((unsigned)nrows_local), dim3(kGhistRowsThreads),
                                (size_t)kLevels * np * sizeof(double), s, d_lum, gs, row0, b0, b1, off, np, d_ecT, d_c, d_A);
             off += np;
             b0 = b1;
