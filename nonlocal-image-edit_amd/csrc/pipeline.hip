@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -52,6 +53,9 @@ struct nle_ctx {
     };
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> prof_pool;
+    // side stream for small device-to-host copies that must not wait for kernels queued after their data is ready
+    hipStream_t aux = nullptr;
+    hipEvent_t aux_ev = nullptr;
     long long prof_launches[NLE_KERNEL_COUNT] = {0};
     double prof_ms[NLE_KERNEL_COUNT] = {0};
 };
@@ -104,6 +108,21 @@ struct CurCtx {
     explicit CurCtx(nle_ctx* c) : prev(g_cur) { g_cur = c; }
     ~CurCtx() { g_cur = prev; }
 };
+
+hipStream_t aux_stream(nle_ctx* c) {
+    if (!c->aux) {
+        hipError_t e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
+        if (e != hipSuccess) throw Fail{NLE_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)};
+    }
+    return c->aux;
+}
+hipEvent_t aux_event(nle_ctx* c) {
+    if (!c->aux_ev) {
+        hipError_t e = hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming);
+        if (e != hipSuccess) throw Fail{NLE_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)};
+    }
+    return c->aux_ev;
+}
 
 void* arena_alloc(nle_ctx* c, size_t bytes) {
     if (c) {
@@ -929,9 +948,12 @@ void train_materialised(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
 }
 
 // (2) Phi-free: every N-sized pass regenerates its affinity rows (fused.hip)
-void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const SampleSet& ss, const Nystrom& ny,
-                        double hx, double hy, int T, int n_eig, long long pix0, long long M, StageMs* ms) {
-    const int p = ss.p, r = ny.r;
+// `solve` factors Ka on the host (solve_Ka); it is called only after the first pass -- the column sum, which
+// needs nothing of it -- is on the stream, so the factorisation runs under that pass.
+void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const SampleSet& ss,
+                        const std::function<Nystrom()>& solve, double hx, double hy, int T, int n_eig, long long pix0,
+                        long long M, StageMs* ms) {
+    const int p = ss.p;
     const int P64 = nlek::sink_pass_ld(p);
     const float nsw = nsw_of(hx), npw = nsw_of(hy);
     Trace tr;
@@ -942,10 +964,9 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     DevBuf<float4> d_samples(P64);
     HIP_OK(hipMemsetAsync(d_samples.p, 0, P64 * sizeof(float4), c->stream));
     HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), p * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    const std::vector<double>& Bh = ny.B;
     constexpr int kZS = 8;  // slices of the block partials, summed by k_sink_update
-    DevBuf<double> d_B(Bh.size()), d_VA(Bh.size()), d_lam(r), d_z((size_t)kZS * P64), d_w(P64), d_sAh((size_t)2 * T * p),
-        d_Mu((size_t)4 * p * p), d_partial((size_t)nlek::sink_pass_rows(std::max<long long>(M, 1)) * P64);
+    DevBuf<double> d_z((size_t)kZS * P64), d_w(P64), d_sAh((size_t)2 * T * p), d_Mu((size_t)4 * p * p),
+        d_partial((size_t)nlek::sink_pass_rows(std::max<long long>(M, 1)) * P64);
     DevBuf<double> d_cbuf((size_t)std::max<long long>(M, 1));
     // quantised luminance + Cartesian sample grid: table look-ups replace the exponentials (fused.hip)
     const bool hist = ss.quantised && c->mode != 3 && ss.gs.nSelCols <= nlek::sink_hist_max_cols() &&
@@ -961,11 +982,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         PROFILED(c, NLE_K_SMALL, nlek::hist_tables(c->stream, ss.gs, d_samples.p, p, hx, hy, row0, nrows_local, d_er.p,
                                                    d_ecT.p, d_Ep.p));
     }
-    HIP_OK(hipMemcpyAsync(d_B.p, Bh.data(), Bh.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipMemcpyAsync(d_VA.p, ny.VA.data(), Bh.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipMemsetAsync(d_w.p, 0, P64 * sizeof(double), c->stream));
-    PROFILED(c, NLE_K_SMALL, nlek::update_matrix(c->stream, p, r, d_B.p, d_VA.p, d_lam.p, d_Mu.p));
     const bool hist_tiled = hist && ss.gs.nSelCols <= 36 && ss.gs.nSelRows <= 32 && std::getenv("NLE_HIST_UNTILED") == nullptr;
     DevBuf<double> d_hws;
     if (hist_tiled) d_hws.alloc(nlek::hist_tiled_workspace_elems(ss.gs, nrows_local));
@@ -973,7 +990,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     tr.mark("ss: alloc+upload");
     // pass n uses the scaling whose sample row sums are sAh[n-1] (and w) and produces sAh[n]; pass 0 is the
     // column sum Phi^T 1 (:234,239)
-    auto one_pass = [&](int n, int mode, double* ybuf) {
+    auto pass_pixels = [&](int mode, double* ybuf) {  // the N-sized half: z = sum over this rank's pixels
         if (M > 0 && hist_tiled) {
             // tiled table pass: writes the local column sums straight into slice 0 of d_z
             static const int kmap[4] = {NLE_K_SINK_TABLES, NLE_K_SINKHORN_PASS, NLE_K_REDUCE, NLE_K_REDUCE};
@@ -992,26 +1009,35 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         } else {
             HIP_OK(hipMemsetAsync(d_z.p, 0, (size_t)kZS * P64 * sizeof(double), c->stream));
         }
-        const int zrows = hist_tiled ? 1 : kZS;
+    };
+    const int zrows = hist_tiled ? 1 : kZS;
+    auto pass_update = [&](int n, int mode) {  // the p-sized half: all-reduce, then [w; s_A] = Mu [z; y_A]
         all_reduce(c, d_z.p, (size_t)zrows * P64);
         PROFILED(c, NLE_K_SMALL,
                  nlek::sink_update(c->stream, mode, p, d_Mu.p, d_z.p, zrows, P64,
                                    n > 0 ? d_sAh.p + (size_t)(n - 1) * p : nullptr, NLE_EPS, d_sAh.p + (size_t)n * p,
                                    d_w.p));
     };
-    one_pass(0, nlek::ROWPASS_COLSUM, nullptr);
-    for (int n = 1; n < 2 * T; ++n) one_pass(n, nlek::ROWPASS_RECIP, n == 2 * T - 1 ? d_cbuf.p : nullptr);
-    // sample row sums V_A u of the scaling that defines the final c (input of the last pass) and of the
-    // output of the last pass (the r scaling)
-    std::vector<double> sA_c(p), sA_r(p);
-    HIP_OK(hipMemcpyAsync(sA_c.data(), d_sAh.p + (size_t)(2 * T - 2) * p, p * sizeof(double), hipMemcpyDeviceToHost,
-                          c->stream));
-    HIP_OK(hipMemcpyAsync(sA_r.data(), d_sAh.p + (size_t)(2 * T - 1) * p, p * sizeof(double), hipMemcpyDeviceToHost,
-                          c->stream));
+    pass_pixels(nlek::ROWPASS_COLSUM, nullptr);
+    // factor Ka on the host while the column-sum pass runs, then build the update matrix
+    const Nystrom ny = solve();
+    const int r = ny.r;
+    f->r = r;
+    {
+        DevBuf<double> d_B(ny.B.size()), d_VA(ny.VA.size()), d_lam(r);
+        HIP_OK(hipMemcpyAsync(d_B.p, ny.B.data(), ny.B.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_VA.p, ny.VA.data(), ny.VA.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        PROFILED(c, NLE_K_SMALL, nlek::update_matrix(c->stream, p, r, d_B.p, d_VA.p, d_lam.p, d_Mu.p));
+    }  // (the arena keeps the three buffers alive until the stream has used them: frees are stream-ordered)
+    pass_update(0, nlek::ROWPASS_COLSUM);
+    for (int n = 1; n < 2 * T; ++n) {
+        pass_pixels(nlek::ROWPASS_RECIP, n == 2 * T - 1 ? d_cbuf.p : nullptr);
+        pass_update(n, nlek::ROWPASS_RECIP);
+    }
+    HIP_OK(hipEventRecord(aux_event(c), c->stream));  // the scalings are final here
     tm_s.stop();
     tr.mark("ss: passes enqueued");
-    HIP_OK(hipStreamSynchronize(c->stream));
-    tr.mark("ss: sinkhorn sync");
 
     // Gram in sample space, enqueued; the host half that does not need it runs meanwhile.
     // Quantised luminance: histogram + fp64 GEMM over the look-up tables (k_ghist_*); otherwise
@@ -1034,6 +1060,17 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         PROFILED(c, NLE_K_GRAM, nlek::gram64(c->stream, d_lum, ss.gs, d_samples.p, p, nsw, npw, pix0, M, d_cbuf.p,
                                              d_gpart.p, d_tiles.p));
     }
+    // sample row sums V_A u of the scaling that defines the final c (input of the last pass) and of the
+    // output of the last pass (the r scaling): fetched on the side stream as soon as the passes are done,
+    // with the Gram kernels already queued behind them on the main stream
+    std::vector<double> sA_c(p), sA_r(p);
+    HIP_OK(hipStreamWaitEvent(aux_stream(c), aux_event(c), 0));
+    HIP_OK(hipMemcpyAsync(sA_c.data(), d_sAh.p + (size_t)(2 * T - 2) * p, p * sizeof(double), hipMemcpyDeviceToHost,
+                          aux_stream(c)));
+    HIP_OK(hipMemcpyAsync(sA_r.data(), d_sAh.p + (size_t)(2 * T - 1) * p, p * sizeof(double), hipMemcpyDeviceToHost,
+                          aux_stream(c)));
+    HIP_OK(hipStreamSynchronize(aux_stream(c)));
+    tr.mark("ss: sinkhorn sync");
     double h0 = now_ms();
     OrthoSS o;
     ortho_ss_prepare(o, ny, p, sA_c, sA_r);  // host, while the Gram kernel runs
@@ -1230,15 +1267,22 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         double h0 = now_ms();
         std::vector<double> Ka = build_Ka(ss, hx, hy);
         tr.mark("build_Ka");
-        Nystrom ny = solve_Ka(Ka, ss.p, fuse);
-        tr.mark(ny.chol ? "chol(Ka)" : "eig(Ka)");
         sm.host += now_ms() - h0;
-        f->r = ny.r;
+        auto solve = [&](bool allow_chol) {
+            const double t0 = now_ms();
+            Nystrom ny = solve_Ka(Ka, ss.p, allow_chol);
+            tr.mark(ny.chol ? "chol(Ka)" : "eig(Ka)");
+            sm.host += now_ms() - t0;
+            return ny;
+        };
         tm_a.stop();
-        if (fuse)
-            train_sample_space(c, f, d_lum, ss, ny, hx, hy, T, n_eig, pix0, M, &sm);
-        else
+        if (fuse) {
+            train_sample_space(c, f, d_lum, ss, [&] { return solve(true); }, hx, hy, T, n_eig, pix0, M, &sm);
+        } else {
+            const Nystrom ny = solve(false);
+            f->r = ny.r;
             train_materialised(c, f, d_lum, ss, ny, hx, hy, T, n_eig, pix0, M, &sm);
+        }
         tr.mark("train path");
         prof_flush(c);
         f->ms[0] = tm_a.ms();
@@ -1364,6 +1408,8 @@ void nle_ctx_destroy(nle_ctx* ctx) {
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     for (auto& kv : ctx->arena_free) (void)hipFree(kv.second);
     ctx->arena_free.clear();
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+    if (ctx->aux_ev) (void)hipEventDestroy(ctx->aux_ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
