@@ -82,7 +82,8 @@ def roofline_models(info, L, form, grid, lazy=False):
             m["gram_gemm"] = ("mfma", 2.0 * ldm * 256.0 * npair * rows, FP64_MFMA_PEAK_TF)
             if lazy:  # V stays implicit: apply runs on the tables too (bytes the two kernels really move)
                 m["apply_reduce"] = ("hbm", n * (s + 8.0 + s) + tab, HBM_PEAK_GBS)        # luminance, c, x in; h out
-                m["apply_expand"] = ("hbm", n * (s + 8.0 + s) + tab, HBM_PEAK_GBS)        # luminance, c, g in; y out
+                lb = max(1, min(L, 4, (144 * 1024) // (256 * (nC | 1) * 8)))             # layers per k_hist_dot launch
+                m["apply_expand"] = ("hbm", n * (s + 8.0) + lb * (tab + n * s), HBM_PEAK_GBS)  # luminance, c; per layer g in, y out
     return m
 
 

@@ -1063,29 +1063,44 @@ __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restr
 }
 
 // apply, expand half: out[i] = (float)(c_i * sum_b ec[c_i][b] g_r[x_i][b]) with g built from w' = D (f o t)
+// Up to kDotLayers layers per launch: the tables of the launch's layers sit side by side in LDS, so the pixel's
+// level, its nC column factors and c_i are loaded once for all of them.
+constexpr int kDotLayers = 4;
+constexpr int kDotThreads = 512;
 template <int NC>
-__global__ __launch_bounds__(256) void k_hist_dot(const float* __restrict__ lum, GridSpec gs, int row0,
-                                                  const double* __restrict__ ecT, const double* __restrict__ g,
-                                                  const double* __restrict__ cvec, float* __restrict__ out) {
+__global__ __launch_bounds__(kDotThreads) void k_hist_dot(const float* __restrict__ lum, GridSpec gs, int row0,
+                                                          const double* __restrict__ ecT, const double* __restrict__ g,
+                                                          size_t gstride, int nl, const double* __restrict__ cvec,
+                                                          float* __restrict__ out, long long ostride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int n = kLevels * NC;
+    constexpr int NS = NC | 1;  // odd row stride, as in k_hist_pix
+    constexpr int TS = kLevels * NS;
     const int W = gs.W;
-    constexpr int NS = NC | 1;                          // odd row stride, as in k_hist_pix
-    double* sg = reinterpret_cast<double*>(smem_raw);  // [256][NS]
+    double* sg = reinterpret_cast<double*>(smem_raw);  // [nl][256][NS]
     const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
-    const double* grow = g + (size_t)lrow * n;
-    for (int i = tid; i < n; i += 256) sg[(i & (kLevels - 1)) * NS + i / kLevels] = grow[i];  // b-major -> level-major
+    for (int l = 0; l < nl; ++l) {
+        const double* grow = g + (size_t)l * gstride + (size_t)lrow * n;
+        for (int i = tid; i < n; i += kDotThreads) sg[l * TS + (i & (kLevels - 1)) * NS + i / kLevels] = grow[i];  // b-major -> level-major
+    }
     __syncthreads();
-    for (int c = tid; c < W; c += 256) {
+    for (int c = tid; c < W; c += kDotThreads) {
         const int x = (int)lum[(size_t)r * W + c];
-        double s0 = 0.0, s1 = 0.0;
+        const double cv = cvec[(size_t)lrow * W + c];
+        double e[NC];
 #pragma unroll
-        for (int b = 0; b < NC; ++b) {
-            const double t = ecT[(size_t)b * W + c] * sg[x * NS + b];
-            if (b & 1) s1 += t;
-            else s0 += t;
+        for (int b = 0; b < NC; ++b) e[b] = ecT[(size_t)b * W + c];
+#pragma unroll 1
+        for (int l = 0; l < nl; ++l) {
+            const double* t = sg + l * TS + x * NS;
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int b = 0; b < NC; ++b) {
+                if (b & 1) s1 += e[b] * t[b];
+                else s0 += e[b] * t[b];
+            }
+            out[(size_t)l * ostride + (size_t)lrow * W + c] = (float)(cv * (s0 + s1));
         }
-        out[(size_t)lrow * W + c] = (float)(cvec[(size_t)lrow * W + c] * (s0 + s1));
     }
 }
 
@@ -1273,30 +1288,39 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
     return hipGetLastError();
 }
 
-// expand half of the sample-space apply for one layer: g tables from w' (ldp doubles), then the dot kernel
-hipError_t apply_hist_layer(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
-                            const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_wl,
-                            const double* d_c, double* d_ws, float* d_out, LaunchObserver* obs) {
+// layers of the sample-space apply's expand half that one k_hist_dot launch handles (LDS: one table each)
+int apply_layers_per_launch(GridSpec gs) {
+    const size_t table = (size_t)kLevels * (gs.nSelCols | 1) * sizeof(double);
+    return (int)std::max<size_t>(1, std::min<size_t>(kDotLayers, (size_t)(144 * 1024) / table));
+}
+
+// expand half of the sample-space apply for `nl` <= apply_layers_per_launch layers: the g tables from the w' vectors
+// (d_wl: nl vectors, stride ldw), then one dot kernel; d_ws: nl * nrows_local * 256 nC doubles;
+// d_out: layer l at d_out + l * ostride
+hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
+                             const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_wl, int ldw,
+                             int nl, const double* d_c, double* d_ws, float* d_out, long long ostride,
+                             LaunchObserver* obs) {
     const int nC = gs.nSelCols, nR = gs.nSelRows;
     if (nC > 36 || nR > 32 || nrows_local <= 0) return nrows_local <= 0 ? hipSuccess : hipErrorInvalidValue;
-    const size_t n = (size_t)kLevels * nC;
-    double* d_g = d_ws;
+    if (nl < 1 || nl > apply_layers_per_launch(gs)) return hipErrorInvalidValue;
+    const size_t n = (size_t)kLevels * nC, gstride = (size_t)nrows_local * n;
     if (obs) obs->begin(SUB_HIST_G);
-    {
-        hipError_t eg = launch_hist_g(s, gs, p, nrows_local, d_er, d_Ep, d_wl, d_g);
+    for (int l = 0; l < nl; ++l) {
+        hipError_t eg = launch_hist_g(s, gs, p, nrows_local, d_er, d_Ep, d_wl + (size_t)l * ldw, d_ws + (size_t)l * gstride);
         if (eg != hipSuccess) return eg;
     }
     if (obs) obs->end(), obs->begin(SUB_HIST_PIX);
 #define NLE_HD(NCV)                                                                                                  \
     case NCV: {                                                                                                      \
-        constexpr size_t shm_d = (size_t)kLevels * ((NCV) | 1) * sizeof(double);                                     \
+        const size_t shm_d = (size_t)nl * kLevels * ((NCV) | 1) * sizeof(double);                                    \
         if (shm_d > 48 * 1024) {                                                                                     \
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_dot<NCV>),                      \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_d);             \
             if (ea != hipSuccess) return ea;                                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_hist_dot<NCV>), dim3((unsigned)nrows_local), dim3(256), shm_d, s, d_lum, gs, row0,     \
-                           d_ecT, d_g, d_c, d_out);                                                                  \
+        hipLaunchKernelGGL((k_hist_dot<NCV>), dim3((unsigned)nrows_local), dim3(kDotThreads), shm_d, s, d_lum, gs,   \
+                           row0, d_ecT, d_ws, gstride, nl, d_c, d_out, ostride);                                     \
     } break;
     switch (nC) {
         NLE_HD(1) NLE_HD(2) NLE_HD(3) NLE_HD(4) NLE_HD(5) NLE_HD(6) NLE_HD(7) NLE_HD(8) NLE_HD(9) NLE_HD(10) NLE_HD(11)

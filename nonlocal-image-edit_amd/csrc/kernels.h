@@ -138,9 +138,11 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
                            LaunchObserver* obs = nullptr, const double* d_cvec = nullptr,
                            const float* d_xvec = nullptr);  // mode XVEC: y_i = cvec_i * xvec_i (apply, reduce half)
 // sample-space apply (tables): expand half for one layer, the p/K-sized middle, and the sample-pixel outputs
-hipError_t apply_hist_layer(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
-                            const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_wl,
-                            const double* d_c, double* d_ws, float* d_out, LaunchObserver* obs = nullptr);
+int apply_layers_per_launch(GridSpec gs);
+hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
+                             const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_wl, int ldw,
+                             int nl, const double* d_c, double* d_ws, float* d_out, long long ostride,
+                             LaunchObserver* obs);
 hipError_t apply_small(hipStream_t s, int p, int K, int ldk, int L, int ldw, const double* d_m, const double* d_D,
                        const double* d_Vrows, const float* d_x, const long long* d_sample_pix, const double* d_resp,
                        double* d_t, double* d_Wp, double* d_YA);

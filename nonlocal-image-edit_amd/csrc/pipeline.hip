@@ -1208,10 +1208,13 @@ void apply_sample_space(nle_filter* f, const float* d_x, const double* h_g /* L 
                                                f->d_sample_pix, d_resp.p, d_t.p, d_Wp.p, d_YA.p));
     if (M > 0) {
         static const int emap[4] = {NLE_K_SINK_TABLES, NLE_K_APPLY_EXPAND, NLE_K_REDUCE, NLE_K_REDUCE};
-        for (int l = 0; l < L; ++l) {
+        const int lb = std::min(L, nlek::apply_layers_per_launch(f->gs));
+        DevBuf<double> d_gws((size_t)lb * nrows_local * 256 * f->gs.nSelCols);
+        for (int l = 0; l < L; l += lb) {
             ProfObserver obs(c, emap);
-            HIP_OK(nlek::apply_hist_layer(c->stream, lum, f->gs, p, f->row0, nrows_local, f->d_er, f->d_ecT, f->d_Ep,
-                                          d_Wp.p + (size_t)l * P64, f->d_c, d_ws.p, d_y + (size_t)l * M, &obs));
+            HIP_OK(nlek::apply_hist_layers(c->stream, lum, f->gs, p, f->row0, nrows_local, f->d_er, f->d_ecT, f->d_Ep,
+                                           d_Wp.p + (size_t)l * P64, P64, std::min(lb, L - l), f->d_c, d_gws.p,
+                                           d_y + (size_t)l * M, M, &obs));
         }
         PROFILED(c, NLE_K_SMALL, nlek::scatter_samples(c->stream, p, L, f->d_sample_loc, d_YA.p, d_y, M));
     }
