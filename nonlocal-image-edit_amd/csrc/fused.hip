@@ -1522,27 +1522,56 @@ __global__ __launch_bounds__(256) void k_ghist_gemm(const double* __restrict__ E
     }
 }
 
+// One wave per (row pair m = (a1 <= a2), column pair pc = (b1 <= b2)): its 256-level vector of C (summed over the
+// GEMM's row splits in a fixed order) is read once, coalesced, and contracted with Ep for the one or two entries of
+// Gk it feeds -- (a1,b1)x(a2,b2) and, when both pairs are off-diagonal, (a1,b2)x(a2,b1) -- plus their transposes.
 __global__ __launch_bounds__(256) void k_ghist_final(const double* __restrict__ C, long long N, int nsplit, size_t zstride,
                                                      const double* __restrict__ Ep, int p, int nR, int nC,
                                                      double* __restrict__ Gk) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)p * p) return;
-    const int s1 = (int)(idx / p), s2 = (int)(idx % p);
-    int a1 = s1 / nC, b1 = s1 % nC, a2 = s2 / nC, b2 = s2 % nC;
-    const int m = tri_index(min(a1, a2), max(a1, a2), nR);
-    const int pc = tri_index(min(b1, b2), max(b1, b2), nC);
-    const double* Cm = C + (size_t)m * N + (size_t)pc * kLevels;  // columns are [pair][level]
-    double t0 = 0.0, t1 = 0.0;
-    for (int x = 0; x < kLevels; x += 2) {
-        double c0 = 0.0, c1 = 0.0;
-        for (int z = 0; z < nsplit; ++z) {  // fixed order
-            c0 += Cm[z * zstride + x];
-            c1 += Cm[z * zstride + x + 1];
-        }
-        t0 += Ep[(size_t)x * p + s1] * Ep[(size_t)x * p + s2] * c0;
-        t1 += Ep[(size_t)(x + 1) * p + s1] * Ep[(size_t)(x + 1) * p + s2] * c1;
+    const int NP = nC * (nC + 1) / 2, NM = nR * (nR + 1) / 2;
+    const int lane = threadIdx.x & 63;
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (long long)NM * NP) return;  // wave-uniform
+    const int m = (int)(w / NP), pc = (int)(w % NP);
+    int a1 = 0, t = m;
+    while (t >= nR - a1) {
+        t -= nR - a1;
+        ++a1;
     }
-    Gk[idx] = t0 + t1;  // column-major == row-major (symmetric)
+    const int a2 = a1 + t;
+    int b1 = 0;
+    t = pc;
+    while (t >= nC - b1) {
+        t -= nC - b1;
+        ++b1;
+    }
+    const int b2 = b1 + t;
+    const int s11 = a1 * nC + b1, s22 = a2 * nC + b2, s12 = a1 * nC + b2, s21 = a2 * nC + b1;
+    const bool two = (a1 != a2) && (b1 != b2);
+    const double* Cm = C + (size_t)m * N + (size_t)pc * kLevels;  // columns are [pair][level]
+    double u = 0.0, v = 0.0;
+#pragma unroll
+    for (int j = 0; j < kLevels / 64; ++j) {
+        const int x = j * 64 + lane;
+        double cx = 0.0;
+        for (int z = 0; z < nsplit; ++z) cx += Cm[z * zstride + x];  // fixed order
+        const double* e = Ep + (size_t)x * p;
+        u += e[s11] * e[s22] * cx;
+        if (two) v += e[s12] * e[s21] * cx;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        u += __shfl_xor(u, off);
+        v += __shfl_xor(v, off);
+    }
+    if (lane == 0) {
+        Gk[(size_t)s11 * p + s22] = u;
+        Gk[(size_t)s22 * p + s11] = u;
+        if (two) {
+            Gk[(size_t)s12 * p + s21] = v;
+            Gk[(size_t)s21 * p + s12] = v;
+        }
+    }
 }
 
 int ghist_ldm(int nR) { return ((nR * (nR + 1) / 2) + 15) & ~15; }
@@ -1612,7 +1641,8 @@ hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int 
     if (obs) obs->end(), obs->begin(SUB_GHIST_GEMM);
     hipLaunchKernelGGL((k_ghist_gemm<MT>), grid, dim3(256), 0, s, d_EE, ldm, d_A, N, nrows_local, ksplit, d_C);
     if (obs) obs->end(), obs->begin(SUB_GHIST_FINAL);
-    hipLaunchKernelGGL(k_ghist_final, dim3((unsigned)(((long long)p * p + 255) / 256)), dim3(256), 0, s, d_C, N, nsplit,
+    const long long nwaves = (long long)(nR * (nR + 1) / 2) * NP;
+    hipLaunchKernelGGL(k_ghist_final, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, d_C, N, nsplit,
                        (size_t)ldm * N, d_Ep, p, nR, nC, d_Gk);
     if (obs) obs->end();
     return hipGetLastError();
