@@ -992,8 +992,9 @@ static hipError_t launch_hist_g(hipStream_t s, GridSpec gs, int p, int nrows_loc
     return hipGetLastError();
 }
 
+constexpr int kPixThreads = 512;
 template <int NC>  // NC = nSelCols: compile-time so that the per-pixel loops carry no branches
-__global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restrict__ lum, GridSpec gs, int row0,
+__global__ __launch_bounds__(kPixThreads) void k_hist_pix(int mode, const float* __restrict__ lum, GridSpec gs, int row0,
                                                   const double* __restrict__ ecT, const double* __restrict__ g,
                                                   double eps, double* __restrict__ ybuf, double* __restrict__ hout,
                                                   const double* __restrict__ cvec, const float* __restrict__ xvec) {
@@ -1005,7 +1006,7 @@ __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restr
     double* sh = sg + kLevels * NS;                     // [256][NS]
     const int tid = threadIdx.x, lrow = blockIdx.x, r = row0 + lrow;
     const double* grow = g + (size_t)lrow * n;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += kPixThreads) {
         const int bb = i / kLevels, xx = i & (kLevels - 1);  // global tables are b-major, the LDS copies level-major
         sh[xx * NS + bb] = 0.0;
         sg[xx * NS + bb] = (mode == ROWPASS_RECIP) ? grow[i] : 0.0;
@@ -1013,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restr
     __syncthreads();
     const int dr = r - gs.rowOff;
     const bool sample_row = dr >= 0 && (dr % gs.rowStep) == 0 && (dr / gs.rowStep) < gs.nSelRows;
-    for (int c0 = 0; c0 < W; c0 += 256) {  // wave-uniform trip count: the body uses cross-lane sums
+    for (int c0 = 0; c0 < W; c0 += kPixThreads) {  // wave-uniform trip count: the body uses cross-lane sums
         const bool inside = c0 + tid < W;
         const int c = inside ? c0 + tid : W - 1;
         const int x = (int)lum[(size_t)r * W + c];
@@ -1056,7 +1057,7 @@ __global__ __launch_bounds__(256) void k_hist_pix(int mode, const float* __restr
     }
     __syncthreads();
     double* hrow = hout + (size_t)lrow * n;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += kPixThreads) {
         const int bb = i / kLevels, xx = i & (kLevels - 1);
         hrow[i] = sh[xx * NS + bb];
     }
@@ -1256,7 +1257,7 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
         Scope sc(obs, SUB_HIST_PIX);
 #define NLE_HP(NCV)                                                                                                 \
     case NCV:                                                                                                       \
-        hipLaunchKernelGGL((k_hist_pix<NCV>), dim3((unsigned)nrows_local), dim3(256),                              \
+        hipLaunchKernelGGL((k_hist_pix<NCV>), dim3((unsigned)nrows_local), dim3(kPixThreads),                      \
                            (size_t)2 * kLevels * ((NCV) | 1) * sizeof(double), s, mode,                            \
                            d_lum, gs, row0, d_ecT, d_g, eps, d_ybuf, d_h, d_cvec, d_xvec);                          \
         break;
