@@ -72,6 +72,47 @@ DRIVER = textwrap.dedent(r"""
             nleh::eigen_decomposition(A.data(), n, 0.0, U.data(), D.data(), &r);
             if (D[n - 1] < 1.0 / tr * (1 - 1e-9)) { std::printf("n=%d: lambda_min %g below the certificate %g\n", n, D[n - 1], 1.0 / tr); ++bad; }
         }
+        // the three-phase solver (recorded rotations, back-transformed top-k) against the classic one, 1 and 3 threads
+        for (int n : {2, 5, 17, 64, 130, 200}) {
+            std::vector<double> B((size_t)n * n), A((size_t)n * n, 0.0), U((size_t)n * n), D(n), Ut((size_t)n * n), Dt(n);
+            for (auto& v : B) v = N(g);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double s = 0;
+                    for (int k = 0; k < n; ++k) s += B[i + (size_t)k * n] * B[j + (size_t)k * n] * std::exp(-0.2 * k);
+                    A[i + (size_t)j * n] = s;
+                }
+            int r = 0;
+            nleh::eigen_decomposition(A.data(), n, 0.0, U.data(), D.data(), &r);
+            for (int threads : {1, 3}) {
+                const int k = n > 2 ? n / 3 : n;
+                if (!nleh::sym_eigen_top(A.data(), n, k, threads, Ut.data(), Dt.data())) { ++bad; continue; }
+                double ev = 0, res = 0, orth = 0;
+                for (int j = 0; j < n; ++j) ev = std::fmax(ev, std::fabs(D[j] - Dt[j]));
+                for (int j = 0; j < k; ++j) {
+                    for (int i = 0; i < n; ++i) {
+                        double s = 0;
+                        for (int l = 0; l < n; ++l) s += A[i + (size_t)l * n] * Ut[l + (size_t)j * n];
+                        res = std::fmax(res, std::fabs(s - Dt[j] * Ut[i + (size_t)j * n]));
+                    }
+                    for (int j2 = 0; j2 <= j; ++j2) {
+                        double s = 0;
+                        for (int i = 0; i < n; ++i) s += Ut[i + (size_t)j * n] * Ut[i + (size_t)j2 * n];
+                        orth = std::fmax(orth, std::fabs(s - (j == j2)));
+                    }
+                }
+                const double scale = std::fabs(D[0]) + 1e-300;
+                if (ev > 1e-11 * scale || res > 1e-10 * scale || orth > 1e-11) {
+                    std::printf("n=%d threads=%d: top-k solver ev %g res %g orth %g\n", n, threads, ev, res, orth);
+                    ++bad;
+                }
+            }
+            // the reference's post-processing on the top-k form
+            int rt = 0;
+            std::vector<double> Uk((size_t)n * n), Dk(n);
+            if (!nleh::eigen_decomposition_top(A.data(), n, 1e-10, std::max(1, n / 4), Uk.data(), Dk.data(), &rt) || rt < 1) ++bad;
+            for (int j = 1; j < n; ++j) if (Dk[j] > Dk[j - 1] + 1e-12 * std::fabs(Dk[0])) ++bad;
+        }
         {   // not positive definite: must be refused
             std::vector<double> A = {1, 2, 2, 1}, L(4), Li(4);
             double tr;
