@@ -198,6 +198,24 @@ int nle_bgr2lab8(nle_ctx* ctx, const unsigned char* d_bgr, long long n, unsigned
 /* max(0) / min(255) / convertTo(CV_8U) / merge / cvtColor(COLOR_Lab2BGR) (src/filter.cpp:434-440): the L
  * channel is taken from d_L (clamped, rounded half to even) when given, else from d_lab. */
 int nle_lab2bgr8(nle_ctx* ctx, const unsigned char* d_lab, const float* d_L, long long n, unsigned char* d_bgr);
+/* the same with any of the three channels replaced by an fp32 plane (NULL = keep d_lab's), each clamped and
+ * rounded like :391-399 -- the tail of NLEFilter::denoise (src/filter.cpp:391-409) */
+int nle_lab2bgr8_planes(nle_ctx* ctx, const unsigned char* d_lab, const float* d_L, const float* d_a, const float* d_b,
+                        long long n, unsigned char* d_bgr);
+/* cv::split + convertTo of one channel (0, 1, 2) of an interleaved 8-bit 3-channel image (:363,376-378) */
+int nle_lab8_channel(nle_ctx* ctx, const unsigned char* d_lab, long long n, int channel, float* d_out);
+
+/* ---- denoise wrapper (src/denoise.cpp, src/filter.cpp:349-410,521-538): the bilateral prefilter ------------- */
+/* cv::bilateralFilter(src, dst, -1, sigmaColor, sigmaSpace, BORDER_DEFAULT) on a single-channel 8-bit plane, as
+ * OpenCV documents it for CV_8UC1: radius = round(1.5 sigmaSpace) >= 1, circular window, fp32 weights
+ * space[dy,dx] * colour[|v - v0|], fp32 sums in row-major window order, round-half-even of sum / wsum,
+ * BORDER_REFLECT_101.  Planes are fp32 holding integers 0..255 (what nle_bgr2lab8 / nle_lab8_channel produce and
+ * nle_train consumes); d_dst must not alias d_src.  OpenCV's own build (SIMD summation order, version) is not
+ * available here, so agreement with it is unpinned beyond the documented formula. */
+int nle_bilateral8(nle_ctx* ctx, const float* d_src, int H, int W, double sigma_color, double sigma_space, float* d_dst);
+/* the two weight tables of that filter (host): *radius always; h_space_w (2 radius + 1)^2 floats with 0 outside
+ * the circle and h_colour_w 256 floats when both are non-NULL */
+int nle_bilateral_tables(double sigma_color, double sigma_space, int* radius, float* h_space_w, float* h_colour_w);
 
 /* leading dimension used for a logical width n: (n + 3) & ~3 */
 int nle_ld(int n);

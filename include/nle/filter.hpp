@@ -161,6 +161,12 @@ Image lab2bgr8(const Image& lab);
 Image bgr2lab8_device(const Image& bgr);
 Image lab2bgr8_device(const Image& lab);
 
+// cv::bilateralFilter(src, dst, -1, sigmaColor, sigmaSpace, BORDER_DEFAULT) on one 8-bit channel, as the denoise
+// wrapper calls it (src/filter.cpp:371,535): host form and device form (bit-identical: same fp32 tables, same
+// summation order); see nle_bilateral8 in nle.h for what "as OpenCV documents it" covers
+Image bilateralFilter8(const Image& plane, double sigmaColor, double sigmaSpace);
+Image bilateralFilter8_device(const Image& plane, double sigmaColor, double sigmaSpace);
+
 // include/filter.hpp:35-54.  The trained state (m_eigvecs N x K', m_eigvals) lives on the GPU.
 class NLEFilter {
 public:
@@ -173,6 +179,11 @@ public:
     void trainForEnhancement(const Image& image, int nRowSamples, int nColSamples, DType hx, DType hy,
                              int nSinkhornIter = 10, int nEigenVectors = 5);
     Image enhance(const Image& I, const std::vector<DType>& weights) const;
+    // include/filter.hpp:40-45: the filter is trained on the bilateral-filtered L channel; denoise shrinks the
+    // eigenvalues to min(lambda, 1)^k on the a and b channels (src/filter.cpp:349-410, 521-538)
+    void trainForDenoise(const Image& image, int nRowSamples, int nColSamples, DType hx, DType hy, int nSinkhornIter,
+                         int nEigenVectors, int sigmaColor = 10, int sigmaSpace = 10);
+    Image denoise(const Image& I, DType k, int sigmaColor = 10, int sigmaSpace = 10) const;
 
     // private in the reference (include/filter.hpp:47-50); public here so tests and other hosts can
     // drive the hot path on a luminance plane directly

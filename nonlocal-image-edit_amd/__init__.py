@@ -70,6 +70,10 @@ _SIGNATURES = {
     "nle_apply_layers_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "nle_bgr2lab8": (C.c_int, [_P, _P, C.c_longlong, _P, _P]),
     "nle_lab2bgr8": (C.c_int, [_P, _P, _P, C.c_longlong, _P]),
+    "nle_lab2bgr8_planes": (C.c_int, [_P, _P, _P, _P, _P, C.c_longlong, _P]),
+    "nle_lab8_channel": (C.c_int, [_P, _P, C.c_longlong, C.c_int, _P]),
+    "nle_bilateral8": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P]),
+    "nle_bilateral_tables": (C.c_int, [C.c_double, C.c_double, _P, _P, _P]),
     "nle_ld": (C.c_int, [C.c_int]),
     "nle_kernel_name": (C.c_char_p, [C.c_int]),
     "nle_ctx_profile": (C.c_int, [_P, C.c_int]),
@@ -368,6 +372,49 @@ class Context:
         out = torch.empty(M, dtype=torch.float64, device=phi.device)
         _check(lib().nle_row_scalings(self._h, C.c_void_p(phi.data_ptr()), M, ldp, r, _np_ptr(u),
                                       C.c_void_p(out.data_ptr())), self._h)
+        return out
+
+    # ---- colour / denoise wrapper pieces (device tensors) ----
+    def bgr2lab8(self, bgr):
+        """`cvtColor(COLOR_BGR2Lab)` on an H x W x 3 uint8 image: (lab uint8 H x W x 3, L float32 H x W)"""
+        torch = _torch()
+        t = torch.as_tensor(bgr, dtype=torch.uint8, device=f"cuda:{self.device}").contiguous()
+        self._sync_in()
+        H, W = t.shape[:2]
+        lab = torch.empty_like(t)
+        L = torch.empty((H, W), dtype=torch.float32, device=t.device)
+        _check(lib().nle_bgr2lab8(self._h, C.c_void_p(t.data_ptr()), H * W, C.c_void_p(lab.data_ptr()),
+                                  C.c_void_p(L.data_ptr())), self._h)
+        return lab, L
+
+    def lab8_channel(self, lab, channel):
+        torch = _torch()
+        self._sync_in()
+        H, W = lab.shape[:2]
+        out = torch.empty((H, W), dtype=torch.float32, device=lab.device)
+        _check(lib().nle_lab8_channel(self._h, C.c_void_p(lab.data_ptr()), H * W, int(channel),
+                                      C.c_void_p(out.data_ptr())), self._h)
+        return out
+
+    def lab2bgr8(self, lab, L=None, a=None, b=None):
+        """`max/min/convertTo(CV_8U)/merge/cvtColor(COLOR_Lab2BGR)` with optional float32 replacement planes"""
+        torch = _torch()
+        self._sync_in()
+        H, W = lab.shape[:2]
+        out = torch.empty_like(lab)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        _check(lib().nle_lab2bgr8_planes(self._h, C.c_void_p(lab.data_ptr()), ptr(L), ptr(a), ptr(b), H * W,
+                                         C.c_void_p(out.data_ptr())), self._h)
+        return out
+
+    def bilateral8(self, plane, sigma_color, sigma_space):
+        """`cv::bilateralFilter(plane, -1, sigmaColor, sigmaSpace)` on an integer-valued float32 plane"""
+        torch = _torch()
+        src = self._lum(plane)
+        H, W = src.shape
+        out = torch.empty_like(src)
+        _check(lib().nle_bilateral8(self._h, C.c_void_p(src.data_ptr()), H, W, float(sigma_color), float(sigma_space),
+                                    C.c_void_p(out.data_ptr())), self._h)
         return out
 
     def bench_affinity(self, lum, n_row_samples, n_col_samples, hx, hy, reps=10):

@@ -45,11 +45,15 @@ __global__ __launch_bounds__(256) void k_bgr2lab8(const unsigned char* __restric
 }
 
 // L from Lf when given (clamped to [0,255] and rounded half-to-even like :434-436), else lab's own
+// (the denoise wrapper also replaces a and b by filtered planes, clamped and rounded the same way, :391-399)
 __global__ __launch_bounds__(256) void k_lab2bgr8(const unsigned char* __restrict__ lab, const float* __restrict__ Lf,
+                                                  const float* __restrict__ af, const float* __restrict__ bf,
                                                   long long n, unsigned char* __restrict__ bgr) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const double L8 = Lf != nullptr ? (double)sat8((double)Lf[i]) : (double)lab[3 * i + 0];
-        const double L = L8 * 100.0 / 255.0, a = (double)lab[3 * i + 1] - 128.0, b = (double)lab[3 * i + 2] - 128.0;
+        const double a8 = af != nullptr ? (double)sat8((double)af[i]) : (double)lab[3 * i + 1];
+        const double b8 = bf != nullptr ? (double)sat8((double)bf[i]) : (double)lab[3 * i + 2];
+        const double L = L8 * 100.0 / 255.0, a = a8 - 128.0, b = b8 - 128.0;
         double fy = (L + 16.0) / 116.0, y;
         if (L > 7.9996248) {
             y = fy * fy * fy;
@@ -77,10 +81,94 @@ hipError_t bgr2lab8(hipStream_t s, const unsigned char* d_bgr, long long n, cons
     return hipGetLastError();
 }
 
-hipError_t lab2bgr8(hipStream_t s, const unsigned char* d_lab, const float* d_L, long long n, unsigned char* d_bgr) {
+hipError_t lab2bgr8(hipStream_t s, const unsigned char* d_lab, const float* d_L, const float* d_a, const float* d_b,
+                    long long n, unsigned char* d_bgr) {
     if (n <= 0) return hipSuccess;
     const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_lab2bgr8, dim3(grid), dim3(256), 0, s, d_lab, d_L, n, d_bgr);
+    hipLaunchKernelGGL(k_lab2bgr8, dim3(grid), dim3(256), 0, s, d_lab, d_L, d_a, d_b, n, d_bgr);
+    return hipGetLastError();
+}
+
+// split + convertTo(float) of one channel of an interleaved 8-bit 3-channel image (src/filter.cpp:363,376-378)
+__global__ __launch_bounds__(256) void k_channel8(const unsigned char* __restrict__ img, long long n, int ch,
+                                                  float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = (float)img[3 * i + ch];
+}
+
+hipError_t channel8(hipStream_t s, const unsigned char* d_img, long long n, int ch, float* d_out) {
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_channel8, dim3(grid), dim3(256), 0, s, d_img, n, ch, d_out);
+    return hipGetLastError();
+}
+
+// ---- cv::bilateralFilter on a single-channel 8-bit plane (d = -1, BORDER_DEFAULT), as the denoise wrapper
+// calls it (src/filter.cpp:371,535).  OpenCV's documented algorithm for CV_8UC1: radius = round(1.5 sigma_space)
+// (at least 1), circular window, weight = space[dy,dx] * colour[|v - v0|] from two fp32 tables, fp32 sums in
+// row-major window order, result round-half-even of sum / wsum; the border is reflected without repeating the
+// edge pixel (BORDER_REFLECT_101).  The tables are built on the host so that host and device forms agree bit
+// for bit; products and sums are kept unfused for the same reason.  Planes are fp32 holding integers 0..255.
+constexpr int kBfTx = 32, kBfTy = 8;
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    const int period = 2 * n - 2;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - i;
+}
+
+__global__ __launch_bounds__(kBfTx* kBfTy) void k_bilateral8(const float* __restrict__ src, int H, int W, int radius,
+                                                              const float* __restrict__ space_w,
+                                                              const float* __restrict__ colour_w,
+                                                              float* __restrict__ dst) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int d = 2 * radius + 1, tw = kBfTx + 2 * radius, th = kBfTy + 2 * radius;
+    float* tile = reinterpret_cast<float*>(smem_raw);  // [th][tw]
+    float* sw = tile + tw * th;                         // [d][d], 0 outside the circle
+    float* cw = sw + d * d;                             // [256]
+    const int tid = threadIdx.y * kBfTx + threadIdx.x, nthr = kBfTx * kBfTy;
+    const int x0 = blockIdx.x * kBfTx - radius, y0 = blockIdx.y * kBfTy - radius;
+    for (int i = tid; i < tw * th; i += nthr) {
+        const int ty = i / tw, tx = i - ty * tw;
+        tile[i] = src[(size_t)reflect101(y0 + ty, H) * W + reflect101(x0 + tx, W)];
+    }
+    for (int i = tid; i < d * d; i += nthr) sw[i] = space_w[i];
+    for (int i = tid; i < 256; i += nthr) cw[i] = colour_w[i];
+    __syncthreads();
+    const int x = blockIdx.x * kBfTx + threadIdx.x, y = blockIdx.y * kBfTy + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const float v0 = tile[(threadIdx.y + radius) * tw + threadIdx.x + radius];
+    float sum = 0.f, wsum = 0.f;
+    for (int dy = 0; dy < d; ++dy) {
+        const float* trow = tile + (threadIdx.y + dy) * tw + threadIdx.x;
+        const float* srow = sw + dy * d;
+        for (int dx = 0; dx < d; ++dx) {
+            const float s = srow[dx];
+            if (s == 0.f) continue;  // outside the circular window
+            const float v = trow[dx];
+            const float w = __fmul_rn(s, cw[(int)fabsf(v - v0)]);
+            sum = __fadd_rn(sum, __fmul_rn(v, w));
+            wsum = __fadd_rn(wsum, w);
+        }
+    }
+    dst[(size_t)y * W + x] = rintf(__fdiv_rn(sum, wsum));
+}
+
+int bilateral8_max_radius() { return 64; }
+
+hipError_t bilateral8(hipStream_t s, const float* d_src, int H, int W, int radius, const float* d_space_w,
+                      const float* d_colour_w, float* d_dst) {
+    if (H <= 0 || W <= 0) return hipSuccess;
+    if (radius < 1 || radius > bilateral8_max_radius()) return hipErrorInvalidValue;
+    const int d = 2 * radius + 1;
+    const size_t shm = ((size_t)(kBfTx + 2 * radius) * (kBfTy + 2 * radius) + (size_t)d * d + 256) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bilateral8),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_bilateral8, dim3((unsigned)((W + kBfTx - 1) / kBfTx), (unsigned)((H + kBfTy - 1) / kBfTy)),
+                       dim3(kBfTx, kBfTy), shm, s, d_src, H, W, radius, d_space_w, d_colour_w, d_dst);
     return hipGetLastError();
 }
 

@@ -165,7 +165,14 @@ hipError_t project_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, i
 // 8-bit BGR <-> Lab (colour.hip): d_lut = 256 sRGB-decoded doubles; d_lab / d_L optional outputs
 hipError_t bgr2lab8(hipStream_t s, const unsigned char* d_bgr, long long n, const double* d_lut, unsigned char* d_lab,
                     float* d_L);
-hipError_t lab2bgr8(hipStream_t s, const unsigned char* d_lab, const float* d_L, long long n, unsigned char* d_bgr);
+hipError_t lab2bgr8(hipStream_t s, const unsigned char* d_lab, const float* d_L, const float* d_a, const float* d_b,
+                    long long n, unsigned char* d_bgr);
+hipError_t channel8(hipStream_t s, const unsigned char* d_img, long long n, int ch, float* d_out);
+// single-channel 8-bit bilateral filter (fp32 planes holding integers); tables from the host: space_w (2r+1)^2 with 0
+// outside the circle, colour_w 256 entries
+int bilateral8_max_radius();
+hipError_t bilateral8(hipStream_t s, const float* d_src, int H, int W, int radius, const float* d_space_w,
+                      const float* d_colour_w, float* d_dst);
 
 // out[block][2*ncols] = {min, max} of the first ncols columns of X over the block's rows
 hipError_t col_range(hipStream_t s, const float* d_X, long long M, int ld, int ncols, float* d_out, int nblocks);

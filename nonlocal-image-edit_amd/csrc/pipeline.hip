@@ -1483,10 +1483,63 @@ int nle_bgr2lab8(nle_ctx* ctx, const unsigned char* d_bgr, long long n, unsigned
 }
 
 int nle_lab2bgr8(nle_ctx* ctx, const unsigned char* d_lab, const float* d_L, long long n, unsigned char* d_bgr) {
+    return nle_lab2bgr8_planes(ctx, d_lab, d_L, nullptr, nullptr, n, d_bgr);
+}
+
+int nle_lab2bgr8_planes(nle_ctx* ctx, const unsigned char* d_lab, const float* d_L, const float* d_a, const float* d_b,
+                        long long n, unsigned char* d_bgr) {
     if (!ctx || !d_lab || !d_bgr || n < 0) return NLE_ERR_INVALID;
     return guard(ctx, [&] {
         HIP_OK(hipSetDevice(ctx->device));
-        HIP_OK(nlek::lab2bgr8(ctx->stream, d_lab, d_L, n, d_bgr));
+        HIP_OK(nlek::lab2bgr8(ctx->stream, d_lab, d_L, d_a, d_b, n, d_bgr));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int nle_lab8_channel(nle_ctx* ctx, const unsigned char* d_lab, long long n, int channel, float* d_out) {
+    if (!ctx || !d_lab || !d_out || n < 0 || channel < 0 || channel > 2) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        HIP_OK(nlek::channel8(ctx->stream, d_lab, n, channel, d_out));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int nle_bilateral_tables(double sigma_color, double sigma_space, int* radius, float* h_space_w, float* h_colour_w) {
+    // cv::bilateralFilter with d <= 0 (the reference passes -1, src/filter.cpp:366,371,535)
+    if (!radius) return NLE_ERR_INVALID;
+    if (sigma_color <= 0) sigma_color = 1;
+    if (sigma_space <= 0) sigma_space = 1;
+    const double cc = -0.5 / (sigma_color * sigma_color), sc = -0.5 / (sigma_space * sigma_space);
+    const int r = std::max((int)std::lrint(sigma_space * 1.5), 1);
+    *radius = r;
+    if (!h_space_w && !h_colour_w) return NLE_OK;
+    if (!h_space_w || !h_colour_w) return NLE_ERR_INVALID;
+    for (int i = 0; i < 256; ++i) h_colour_w[i] = (float)std::exp((double)i * i * cc);
+    const int d = 2 * r + 1;
+    for (int i = -r; i <= r; ++i)
+        for (int j = -r; j <= r; ++j) {
+            const double rr = std::sqrt((double)i * i + (double)j * j);
+            h_space_w[(i + r) * d + (j + r)] = rr > r ? 0.f : (float)std::exp(rr * rr * sc);
+        }
+    return NLE_OK;
+}
+
+int nle_bilateral8(nle_ctx* ctx, const float* d_src, int H, int W, double sigma_color, double sigma_space, float* d_dst) {
+    if (!ctx || !d_src || !d_dst || H < 1 || W < 1 || d_src == d_dst) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        int r = 0;
+        nle_bilateral_tables(sigma_color, sigma_space, &r, nullptr, nullptr);
+        if (r > nlek::bilateral8_max_radius())
+            throw Fail{NLE_ERR_INVALID, "bilateral filter: sigma_space above 42 (radius > 64) is not supported"};
+        const int d = 2 * r + 1;
+        std::vector<float> sw((size_t)d * d), cw(256);
+        nle_bilateral_tables(sigma_color, sigma_space, &r, sw.data(), cw.data());
+        DevBuf<float> d_sw(sw.size()), d_cw(cw.size());
+        HIP_OK(hipMemcpyAsync(d_sw.p, sw.data(), sw.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(hipMemcpyAsync(d_cw.p, cw.data(), cw.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(nlek::bilateral8(ctx->stream, d_src, H, W, r, d_sw.p, d_cw.p, d_dst));
         HIP_OK(hipStreamSynchronize(ctx->stream));
     });
 }

@@ -443,6 +443,114 @@ void NLEFilter::trainForEnhancement(const Image& image, int nRowSamples, int nCo
     trainOnDevice(d_L.f(), image.rows, image.cols, nRowSamples, nColSamples, hx, hy, nSinkhornIter, nEigenVectors);
 }
 
+// ---- denoise wrapper (src/filter.cpp:349-410, 521-538) ----
+namespace {
+int reflect101(int i, int n) {  // cv::BORDER_DEFAULT
+    if (n == 1) return 0;
+    const int period = 2 * n - 2;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - i;
+}
+}  // namespace
+
+Image bilateralFilter8(const Image& plane, double sigmaColor, double sigmaSpace) {
+    if (plane.channels() != 1 || plane.depth() != NLE_8U) throw std::runtime_error("bilateralFilter8: 8UC1 image expected");
+    int radius = 0;
+    nle_bilateral_tables(sigmaColor, sigmaSpace, &radius, nullptr, nullptr);
+    const int d = 2 * radius + 1, H = plane.rows, W = plane.cols;
+    std::vector<float> sw((size_t)d * d), cw(256);
+    nle_bilateral_tables(sigmaColor, sigmaSpace, &radius, sw.data(), cw.data());
+    Image out(H, W, NLE_8U, 1);
+    std::vector<int> ry(d), rx(d);
+    for (int y = 0; y < H; ++y) {
+        for (int i = 0; i < d; ++i) ry[i] = reflect101(y - radius + i, H);
+        for (int x = 0; x < W; ++x) {
+            for (int j = 0; j < d; ++j) rx[j] = reflect101(x - radius + j, W);
+            const float v0 = (float)plane.at<unsigned char>(y, x);
+            volatile float sum = 0.f, wsum = 0.f;  // volatile: one rounding per operation, like the device kernel
+            for (int i = 0; i < d; ++i)
+                for (int j = 0; j < d; ++j) {
+                    const float s = sw[(size_t)i * d + j];
+                    if (s == 0.f) continue;
+                    const float v = (float)plane.at<unsigned char>(ry[i], rx[j]);
+                    volatile float w = s * cw[(int)std::fabs(v - v0)];
+                    volatile float vw = v * w;
+                    sum = sum + vw;
+                    wsum = wsum + w;
+                }
+            volatile float q = sum / wsum;
+            out.at<unsigned char>(y, x) = (unsigned char)std::nearbyint((float)q);
+        }
+    }
+    return out;
+}
+
+Image bilateralFilter8_device(const Image& plane, double sigmaColor, double sigmaSpace) {
+    if (plane.channels() != 1 || plane.depth() != NLE_8U) throw std::runtime_error("bilateralFilter8: 8UC1 image expected");
+    nle_ctx* c = shared_ctx();
+    const size_t n = plane.total();
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = (float)plane.ptr<unsigned char>()[i];
+    Dev d_in(c, n * 4), d_out(c, n * 4);
+    check(nle_dev_upload(c, d_in.p, h.data(), n * 4), c);
+    check(nle_bilateral8(c, d_in.f(), plane.rows, plane.cols, sigmaColor, sigmaSpace, d_out.f()), c);
+    check(nle_dev_download(c, h.data(), d_out.p, n * 4), c);
+    Image out(plane.rows, plane.cols, NLE_8U, 1);
+    for (size_t i = 0; i < n; ++i) out.ptr<unsigned char>()[i] = (unsigned char)h[i];
+    return out;
+}
+
+void NLEFilter::trainForDenoise(const Image& image, int nRowSamples, int nColSamples, DType hx, DType hy,
+                                int nSinkhornIter, int nEigenVectors, int sigmaColor, int sigmaSpace) {  // :521-538
+    if (image.channels() != 3 || image.depth() != NLE_8U) throw std::runtime_error("Can only enchance RGB image.");
+    if (nRowSamples > image.rows || nColSamples > image.cols)
+        throw std::runtime_error("Number of samples per row and col must be <= that of image.");
+    // BGR -> Lab, L, bilateral filter (8 bit), convertTo(double), trainFilter -- all on the device
+    ctx_ = shared_ctx();
+    const size_t n = image.total();
+    Dev d_bgr(ctx_, n * 3), d_L(ctx_, n * 4), d_Y(ctx_, n * 4);
+    check(nle_dev_upload(ctx_, d_bgr.p, image.ptr<unsigned char>(), n * 3), ctx_);
+    check(nle_bgr2lab8(ctx_, static_cast<unsigned char*>(d_bgr.p), (long long)n, nullptr, d_L.f()), ctx_);
+    check(nle_bilateral8(ctx_, d_L.f(), image.rows, image.cols, sigmaColor, sigmaSpace, d_Y.f()), ctx_);
+    trainOnDevice(d_Y.f(), image.rows, image.cols, nRowSamples, nColSamples, hx, hy, nSinkhornIter, nEigenVectors);
+}
+
+Image NLEFilter::denoise(const Image& image, DType k, int sigmaColor, int sigmaSpace) const {  // :349-410
+    if (image.channels() != 3) throw std::runtime_error("Can only enchance RGB image.");  // (sic) :351-353
+    long long n = 0;
+    if (f_) nle_filter_info(f_, &n, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (!f_ || (long long)image.total() != n)
+        throw std::runtime_error(
+            "Cannot apply filter on image with different size from the image filter was trained on.");
+    if (image.depth() != NLE_8U) throw std::runtime_error("Can only enchance RGB image.");
+    const size_t np = image.total();
+    Dev d_bgr(ctx_, np * 3), d_lab(ctx_, np * 3), d_L(ctx_, np * 4), d_Y(ctx_, np * 4), d_c(ctx_, np * 4),
+        d_a(ctx_, np * 4), d_b(ctx_, np * 4);
+    check(nle_dev_upload(ctx_, d_bgr.p, image.ptr<unsigned char>(), np * 3), ctx_);
+    check(nle_bgr2lab8(ctx_, static_cast<unsigned char*>(d_bgr.p), (long long)np, static_cast<unsigned char*>(d_lab.p),
+                       d_L.f()), ctx_);
+    // the L channel becomes its bilateral-filtered version (:370-373; `apply` on it is commented out, :389)
+    check(nle_bilateral8(ctx_, d_L.f(), image.rows, image.cols, sigmaColor, sigmaSpace, d_Y.f()), ctx_);
+    Vec t = eigvals();
+    for (int i = 0; i < t.size(); ++i) {  // :380-387
+        const DType ev = std::min(t(i), 1.0);
+        if (verbose) std::cout << "eig " << i << " val: " << ev << std::endl;
+        t(i) = std::pow(ev, k);
+    }
+    for (int ch = 1; ch <= 2; ++ch) {  // :390-391
+        float* d_out = ch == 1 ? d_a.f() : d_b.f();
+        check(nle_lab8_channel(ctx_, static_cast<unsigned char*>(d_lab.p), (long long)np, ch, d_c.f()), ctx_);
+        check(nle_apply(f_, d_c.f(), image.rows, image.cols, t.data(), d_out), ctx_);
+    }
+    // max(0) / min(255) / convertTo(CV_8U) of the three planes, merge, Lab -> BGR (:393-409)
+    check(nle_lab2bgr8_planes(ctx_, static_cast<unsigned char*>(d_lab.p), d_Y.f(), d_a.f(), d_b.f(), (long long)np,
+                              static_cast<unsigned char*>(d_bgr.p)), ctx_);
+    Image out(image.rows, image.cols, NLE_8U, 3);
+    check(nle_dev_download(ctx_, out.ptr<unsigned char>(), d_bgr.p, np * 3), ctx_);
+    return out;
+}
+
 Image NLEFilter::apply(const Image& channel, const Vec& transformedEigVals) const {  // :445-458
     long long n = 0;
     if (f_) nle_filter_info(f_, &n, nullptr, nullptr, nullptr, nullptr, nullptr);

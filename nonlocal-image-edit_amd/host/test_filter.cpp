@@ -196,6 +196,65 @@ int main() {
         CHECK(bad_lab * 1000 <= img.total() * 3);            // and at most 0.1 % of the values
         CHECK(bad_bgr * 1000 <= img.total() * 3);
     }
+    {  // denoise wrapper: the bilateral prefilter, device kernel against the host restatement (same fp32 tables and
+       // summation order: bit-identical), on a smooth-plus-noise plane with ragged sizes and radius > width
+        std::uniform_int_distribution<int> noise(-12, 12);
+        for (auto dims : {std::pair<int, int>{45, 70}, std::pair<int, int>{7, 5}}) {
+            nle::Image pl(dims.first, dims.second, nle::NLE_8U, 1);
+            for (int y = 0; y < pl.rows; ++y)
+                for (int x = 0; x < pl.cols; ++x)
+                    pl.at<unsigned char>(y, x) =
+                        (unsigned char)std::min(255, std::max(0, 128 + (int)(70 * std::sin(0.13 * x + 0.07 * y)) + noise(gen)));
+            for (auto sig : {std::pair<int, int>{10, 10}, std::pair<int, int>{25, 3}}) {
+                nle::Image h = nle::bilateralFilter8(pl, sig.first, sig.second);
+                nle::Image d = nle::bilateralFilter8_device(pl, sig.first, sig.second);
+                size_t bad = 0;
+                double moved = 0;
+                for (size_t i = 0; i < pl.total(); ++i) {
+                    bad += h.ptr<unsigned char>()[i] != d.ptr<unsigned char>()[i];
+                    moved += std::abs((int)h.ptr<unsigned char>()[i] - (int)pl.ptr<unsigned char>()[i]);
+                }
+                CHECK(bad == 0);
+                CHECK(moved > 0);  // the filter does something
+            }
+        }
+        nle::Image flat(9, 11, nle::NLE_8U, 1);
+        for (size_t i = 0; i < flat.total(); ++i) flat.ptr<unsigned char>()[i] = 77;
+        nle::Image ff = nle::bilateralFilter8_device(flat, 10, 10);
+        bool same = true;
+        for (size_t i = 0; i < flat.total(); ++i) same = same && ff.ptr<unsigned char>()[i] == 77;
+        CHECK(same);
+    }
+    {  // trainForDenoise / denoise: errors and shape (src/filter.cpp:351-357)
+        std::uniform_int_distribution<int> u8(0, 255);
+        nle::Image img(48, 64, nle::NLE_8U, 3);
+        for (int y = 0; y < img.rows; ++y)
+            for (int x = 0; x < img.cols; ++x)
+                for (int ch = 0; ch < 3; ++ch)
+                    img.ptr<unsigned char>(y)[3 * x + ch] =
+                        (unsigned char)std::min(255, std::max(0, 120 + 40 * ch + (int)(60 * std::sin(0.2 * x + 0.1 * y + ch)) + u8(gen) % 9));
+        nle::NLEFilter f;
+        f.verbose = false;
+        f.trainForDenoise(img, 4, 5, 20.0, 30.0, 10, 8, 10, 3);
+        nle::Image out = f.denoise(img, 2.0, 10, 3);
+        CHECK(out.rows == img.rows && out.cols == img.cols && out.channels() == 3);
+        bool threw = false;
+        try {
+            nle::Image small(10, 10, nle::NLE_8U, 3);
+            f.denoise(small, 2.0);
+        } catch (const std::runtime_error& e) {
+            threw = std::string(e.what()).find("different size") != std::string::npos;
+        }
+        CHECK(threw);
+        threw = false;
+        try {
+            nle::Image grey(48, 64, nle::NLE_8U, 1);
+            f.denoise(grey, 2.0);
+        } catch (const std::runtime_error&) {
+            threw = true;
+        }
+        CHECK(threw);
+    }
     std::printf("%d checks, %d failed\n", g_total, g_fail);
     return g_fail == 0 ? 0 : 1;
 }

@@ -454,3 +454,74 @@ def enhance_image(bgr: np.ndarray, n_row_samples, n_col_samples, hx, hy,
     lab2 = lab.copy()
     lab2[..., 0] = np.rint(y).astype(np.uint8)  # convertTo(CV_8U): round-half-even, :436
     return lab8_to_bgr(lab2)
+
+
+# --------------------------------------------------------------------------- denoise wrapper
+def _reflect101(idx: np.ndarray, n: int) -> np.ndarray:
+    """cv::BORDER_DEFAULT = BORDER_REFLECT_101: gfedcb|abcdefgh|gfedcba"""
+    if n == 1:
+        return np.zeros_like(idx)
+    period = 2 * n - 2
+    i = np.mod(idx, period)
+    return np.where(i < n, i, period - i)
+
+
+def bilateral_tables(sigma_color: float, sigma_space: float):
+    """radius and the two fp32 weight tables of cv::bilateralFilter (CV_8UC1, d <= 0), as OpenCV documents them.
+    OpenCV itself is not in this image: third-party arithmetic restated from its documentation, unpinned."""
+    if sigma_color <= 0:
+        sigma_color = 1.0
+    if sigma_space <= 0:
+        sigma_space = 1.0
+    cc, sc = -0.5 / (sigma_color * sigma_color), -0.5 / (sigma_space * sigma_space)
+    radius = max(int(np.rint(sigma_space * 1.5)), 1)
+    colour_w = np.exp((np.arange(256, dtype=np.float64) ** 2) * cc).astype(np.float32)
+    ii, jj = np.mgrid[-radius:radius + 1, -radius:radius + 1]
+    rr = np.sqrt((ii * ii + jj * jj).astype(np.float64))
+    space_w = np.where(rr > radius, 0.0, np.exp(rr * rr * sc)).astype(np.float32)
+    return radius, space_w, colour_w
+
+
+def bilateral8(plane: np.ndarray, sigma_color: float, sigma_space: float) -> np.ndarray:
+    """cv::bilateralFilter(src, dst, -1, sigmaColor, sigmaSpace, BORDER_DEFAULT) on one 8-bit channel, the call of
+    src/filter.cpp:371 and :535.  fp32 products and sums in row-major window order (no fused multiply-add),
+    round-half-even of sum / wsum.  `plane`: integers 0..255 (any dtype); returns uint8."""
+    src = np.asarray(plane).astype(np.int64)
+    H, W = src.shape
+    radius, space_w, colour_w = bilateral_tables(sigma_color, sigma_space)
+    rows = _reflect101(np.arange(-radius, H + radius), H)
+    cols = _reflect101(np.arange(-radius, W + radius), W)
+    pad = src[np.ix_(rows, cols)]
+    v0 = src
+    s = np.zeros((H, W), dtype=np.float32)
+    ws = np.zeros((H, W), dtype=np.float32)
+    d = 2 * radius + 1
+    for dy in range(d):
+        for dx in range(d):
+            sw = space_w[dy, dx]
+            if sw == 0.0:
+                continue
+            v = pad[dy:dy + H, dx:dx + W]
+            w = (sw * colour_w[np.abs(v - v0)]).astype(np.float32)          # fp32 product
+            s = (s + (v.astype(np.float32) * w).astype(np.float32)).astype(np.float32)
+            ws = (ws + w).astype(np.float32)
+    return np.rint((s / ws).astype(np.float32)).astype(np.uint8)
+
+
+def denoise_image(bgr: np.ndarray, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter, n_eigen_vectors,
+                  sigma_color: int, sigma_space: int, k: float) -> np.ndarray:
+    """`trainForDenoise` + `denoise`, src/filter.cpp:521-538, 349-410: the filter is trained on the bilateral-filtered
+    L channel; a and b go through `apply` with the eigenvalues shrunk to min(lambda, 1)^k; L becomes the
+    bilateral-filtered plane (the `apply` on channel 0 is commented out, :389)."""
+    if bgr.ndim != 3 or bgr.shape[2] != 3:
+        raise RuntimeError("Can only enchance RGB image.")  # :351-353 (sic)
+    lab = bgr_to_lab8(bgr)
+    Y = bilateral8(lab[..., 0], sigma_color, sigma_space)
+    V, S = train_filter(Y.astype(np.float64), n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter, n_eigen_vectors)
+    t = np.minimum(S, 1.0) ** k  # :381-387
+    out = lab.copy()
+    out[..., 0] = Y
+    for ch in (1, 2):
+        y = apply_filter(V, lab[..., ch].astype(np.float64), t).reshape(lab.shape[:2])
+        out[..., ch] = np.rint(np.clip(y, 0, 255)).astype(np.uint8)  # :394-399
+    return lab8_to_bgr(out)
