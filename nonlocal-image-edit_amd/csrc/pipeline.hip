@@ -53,9 +53,6 @@ struct nle_ctx {
     };
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> prof_pool;
-    // side stream for small device-to-host copies that must not wait for kernels queued after their data is ready
-    hipStream_t aux = nullptr;
-    hipEvent_t aux_ev = nullptr;
     long long prof_launches[NLE_KERNEL_COUNT] = {0};
     double prof_ms[NLE_KERNEL_COUNT] = {0};
 };
@@ -108,21 +105,6 @@ struct CurCtx {
     explicit CurCtx(nle_ctx* c) : prev(g_cur) { g_cur = c; }
     ~CurCtx() { g_cur = prev; }
 };
-
-hipStream_t aux_stream(nle_ctx* c) {
-    if (!c->aux) {
-        hipError_t e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
-        if (e != hipSuccess) throw Fail{NLE_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)};
-    }
-    return c->aux;
-}
-hipEvent_t aux_event(nle_ctx* c) {
-    if (!c->aux_ev) {
-        hipError_t e = hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming);
-        if (e != hipSuccess) throw Fail{NLE_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)};
-    }
-    return c->aux_ev;
-}
 
 void* arena_alloc(nle_ctx* c, size_t bytes) {
     if (c) {
@@ -1035,9 +1017,19 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         pass_pixels(nlek::ROWPASS_RECIP, n == 2 * T - 1 ? d_cbuf.p : nullptr);
         pass_update(n, nlek::ROWPASS_RECIP);
     }
-    HIP_OK(hipEventRecord(aux_event(c), c->stream));  // the scalings are final here
+    // sample row sums V_A u of the scaling that defines the final c (input of the last pass) and of the
+    // output of the last pass (the r scaling).  (Fetching them on a second stream, so that the Gram kernels
+    // could be queued first, saved ~50 us but made two processes sharing one GPU stall for tens of
+    // milliseconds per all-reduce: one stream per ctx it stays.)
+    std::vector<double> sA_c(p), sA_r(p);
+    HIP_OK(hipMemcpyAsync(sA_c.data(), d_sAh.p + (size_t)(2 * T - 2) * p, p * sizeof(double), hipMemcpyDeviceToHost,
+                          c->stream));
+    HIP_OK(hipMemcpyAsync(sA_r.data(), d_sAh.p + (size_t)(2 * T - 1) * p, p * sizeof(double), hipMemcpyDeviceToHost,
+                          c->stream));
     tm_s.stop();
     tr.mark("ss: passes enqueued");
+    HIP_OK(hipStreamSynchronize(c->stream));
+    tr.mark("ss: sinkhorn sync");
 
     // Gram in sample space, enqueued; the host half that does not need it runs meanwhile.
     // Quantised luminance: histogram + fp64 GEMM over the look-up tables (k_ghist_*); otherwise
@@ -1060,17 +1052,6 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         PROFILED(c, NLE_K_GRAM, nlek::gram64(c->stream, d_lum, ss.gs, d_samples.p, p, nsw, npw, pix0, M, d_cbuf.p,
                                              d_gpart.p, d_tiles.p));
     }
-    // sample row sums V_A u of the scaling that defines the final c (input of the last pass) and of the
-    // output of the last pass (the r scaling): fetched on the side stream as soon as the passes are done,
-    // with the Gram kernels already queued behind them on the main stream
-    std::vector<double> sA_c(p), sA_r(p);
-    HIP_OK(hipStreamWaitEvent(aux_stream(c), aux_event(c), 0));
-    HIP_OK(hipMemcpyAsync(sA_c.data(), d_sAh.p + (size_t)(2 * T - 2) * p, p * sizeof(double), hipMemcpyDeviceToHost,
-                          aux_stream(c)));
-    HIP_OK(hipMemcpyAsync(sA_r.data(), d_sAh.p + (size_t)(2 * T - 1) * p, p * sizeof(double), hipMemcpyDeviceToHost,
-                          aux_stream(c)));
-    HIP_OK(hipStreamSynchronize(aux_stream(c)));
-    tr.mark("ss: sinkhorn sync");
     double h0 = now_ms();
     OrthoSS o;
     ortho_ss_prepare(o, ny, p, sA_c, sA_r);  // host, while the Gram kernel runs
@@ -1411,8 +1392,6 @@ void nle_ctx_destroy(nle_ctx* ctx) {
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     for (auto& kv : ctx->arena_free) (void)hipFree(kv.second);
     ctx->arena_free.clear();
-    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
-    if (ctx->aux_ev) (void)hipEventDestroy(ctx->aux_ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
