@@ -225,14 +225,22 @@ class Context:
         comm = self._comm
         base = comm.data_ptr()
 
+        debug_path = os.environ.get("NLE_DEBUG_COMM")
+        views = {}   # (offset, count) -> tensor view: the Sinkhorn loop calls this 2T times with the same slice
+        stream_ctx = torch.cuda.stream
+
         def _cb(user, d_buf, count):
             try:
-                off = (int(d_buf) - base) // 8
-                if os.environ.get("NLE_DEBUG_COMM"):
-                    with open(os.environ["NLE_DEBUG_COMM"] + f".rank{rank}", "a") as fh:
-                        fh.write(f"{int(count)}\n")
-                with torch.cuda.stream(self._stream):   # same stream as the ctx's kernels
-                    allreduce(comm[off:off + int(count)])
+                key = (int(d_buf), int(count))
+                view = views.get(key)
+                if view is None:
+                    off = (key[0] - base) // 8
+                    view = views[key] = comm[off:off + key[1]]
+                if debug_path:
+                    with open(debug_path + f".rank{rank}", "a") as fh:
+                        fh.write(f"{key[1]}\n")
+                with stream_ctx(self._stream):   # same stream as the ctx's kernels
+                    allreduce(view)
                 return 0
             except Exception as e:  # noqa: BLE001 - must not propagate through C
                 print("nle allreduce callback failed:", repr(e), flush=True)
