@@ -1,4 +1,5 @@
-"""Full-size checks on the GPU (BASELINE.json configs[3] = cfg4, 4096x4096, p = 200, K = 50, T = 10): the CPU
+"""Full-size checks on the GPU (BASELINE.json configs[3] = cfg4, 4096x4096, p = 200, K = 50, T = 10; also configs[2]
+and configs[4] at the end): the CPU
 oracle needs ~4 minutes per megapixel, so at this size parity is established through size-independent
 properties and through agreement of the independent formulations of the N-sized passes (each of which
 is checked against the oracle at small sizes in test_gpu_parity.py)."""
@@ -73,7 +74,51 @@ def test_cfg4_properties_and_formulations_agree(nle, ctx, cfg4):
         e = float(torch.linalg.norm(Y_mat[j] - Y_tab[j]) / torch.linalg.norm(Y_tab[j]))
         assert e < 1e-4, (j, e)
     f_mat.close()
+    # (6) the eigen-decomposition form of K_A (NLE_FORCE_EIG=1) against the Cholesky form the default path took
+    os.environ["NLE_FORCE_EIG"] = "1"
+    try:
+        f_eig = _train(nle, ctx, cfg, lum, 2)
+    finally:
+        del os.environ["NLE_FORCE_EIG"]
+    assert rel_l2(f_eig.eigvals, ev) < 1e-8
+    Y_eig = f_eig.apply_layers(lum, L)
+    for j in range(L):
+        e = float(torch.linalg.norm(Y_eig[j] - Y_tab[j]) / torch.linalg.norm(Y_tab[j]))
+        assert e < 1e-6, (j, e)
+    f_eig.close()
     f_tab.close()
+    ctx.trim()
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg5"])
+def test_other_full_size_configs_keep_the_filter_properties(nle, ctx, name):
+    """BASELINE.json configs[2] (2048^2, 400 samples, T = 50) and configs[4] (8192^2, 900 samples, K = 100, 6 weights)
+    at full size on one GPU: telescoping layers, idempotent projector, linearity."""
+    import torch
+    import __graft_entry__ as entry
+    synth = entry._load("nle_amd_synthetic", os.path.join(entry.PKG_DIR, "synthetic.py"))
+    cfg = synth.CONFIGS[name]
+    H, W, L = cfg["H"], cfg["W"], cfg["L"]
+    lum = torch.as_tensor(synth.synthetic_luminance(H, W).astype(np.float32), device="cuda:0")
+    f = nle.NLEFilter(ctx).train_filter(lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"])
+    info = f.info()
+    assert info["p"] == cfg["n_row"] * cfg["n_col"] == info["r"] and info["K"] == cfg["K"] and info["n_local"] == H * W
+    ev = f.eigvals
+    assert np.all(np.diff(ev) <= 1e-12) and 0.99 < ev[0] < 1.01 and ev[-1] > 1e-10
+    Y = f.apply_layers(lum, L)
+    ones = np.ones(info["K"])
+    Px = f.apply(lum, ones)
+    assert float(torch.linalg.norm(Y.sum(0) - Px) / torch.linalg.norm(Px)) < 1e-5
+    del Y
+    PPx = f.apply(Px.view(H, W), ones)
+    assert float(torch.linalg.norm(PPx - Px) / torch.linalg.norm(Px)) < 1e-5
+    del PPx
+    z = torch.roll(lum, shifts=(29, 11), dims=(0, 1))
+    fs = np.linspace(2.0, 0.5, info["K"])
+    lhs = f.apply(2.0 * lum - 3.0 * z, fs)
+    rhs = 2.0 * f.apply(lum, fs) - 3.0 * f.apply(z, fs)
+    assert float(torch.linalg.norm(lhs - rhs) / torch.linalg.norm(rhs)) < 1e-5
+    f.close()
     ctx.trim()
 
 
