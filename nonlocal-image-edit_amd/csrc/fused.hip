@@ -196,13 +196,20 @@ hipError_t sink_pass(hipStream_t s, int mode, const float* d_lum, GridSpec gs, c
 // need w and s_A = V_A u (the samples' row sums), so u is eliminated:
 //     [w'; s_A'] = Mu [z; y_A],   Mu = [B; V_A] diag(lambda) [B; V_A]^T   (2p x 2p, built once per training)
 // -- one matrix-vector product whose outputs are independent, spread over ceil(2p / 8) workgroups.
+// Ka (optional): K_A itself when the factor is exact for it (Cholesky form, full rank): then the projector blocks are
+// the identity and the lower right block is K_A, written as such instead of as rounded products of the factor
+// (L^-T L^T differs from I by cond(L) eps, noise that near-singular K_A amplifies into the eigenvalues).
 __global__ __launch_bounds__(256) void k_update_matrix(int p, int r, const double* __restrict__ Bm,
                                                        const double* __restrict__ VA, const double* __restrict__ lam,
-                                                       double* __restrict__ Mu) {
+                                                       const double* __restrict__ Ka, double* __restrict__ Mu) {
     const int n2 = 2 * p;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)n2 * n2) return;
     const int i = (int)(idx / n2), j = (int)(idx % n2);
+    if (Ka != nullptr && (i >= p || j >= p)) {
+        Mu[idx] = (i >= p && j >= p) ? Ka[(size_t)(j - p) * p + (i - p)] : ((i % p) == (j % p) ? 1.0 : 0.0);
+        return;
+    }
     const double* xi = (i < p) ? Bm + i : VA + (i - p);
     const double* xj = (j < p) ? Bm + j : VA + (j - p);
     double s0 = 0.0, s1 = 0.0;
@@ -216,9 +223,10 @@ __global__ __launch_bounds__(256) void k_update_matrix(int p, int r, const doubl
 }
 
 hipError_t update_matrix(hipStream_t s, int p, int r, const double* d_B, const double* d_VA, const double* d_lam,
-                         double* d_Mu) {
+                         const double* d_Ka, double* d_Mu) {
     const long long n = 4ll * p * p;
-    hipLaunchKernelGGL(k_update_matrix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, r, d_B, d_VA, d_lam, d_Mu);
+    hipLaunchKernelGGL(k_update_matrix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, r, d_B, d_VA, d_lam, d_Ka,
+                       d_Mu);
     return hipGetLastError();
 }
 

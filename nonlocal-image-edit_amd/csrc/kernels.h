@@ -103,7 +103,7 @@ hipError_t sink_pass(hipStream_t s, int mode, const float* d_lum, GridSpec gs, c
 // p-sized update between passes: [w'; s_A'] = Mu [z; y_A], see fused.hip
 // d_z: zrows x zld partial column sums, added in row order
 hipError_t update_matrix(hipStream_t s, int p, int r, const double* d_B, const double* d_VA, const double* d_lam,
-                         double* d_Mu);
+                         const double* d_Ka /* or null */, double* d_Mu);
 hipError_t sink_update(hipStream_t s, int mode, int p, const double* d_Mu, const double* d_z, int zrows, int zld,
                        const double* d_sA_cur, double eps, double* d_sA_next, double* d_w_next);
 // Gk = sum over non-sample local pixels of c_i^2 k_i k_i^T on the fp64 MFMA; upper-triangular

@@ -1006,11 +1006,15 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     const int r = ny.r;
     f->r = r;
     {
-        DevBuf<double> d_B(ny.B.size()), d_VA(ny.VA.size()), d_lam(r);
+        DevBuf<double> d_B(ny.B.size()), d_VA(ny.VA.size()), d_lam(r), d_Ka;
         HIP_OK(hipMemcpyAsync(d_B.p, ny.B.data(), ny.B.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipMemcpyAsync(d_VA.p, ny.VA.data(), ny.VA.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        PROFILED(c, NLE_K_SMALL, nlek::update_matrix(c->stream, p, r, d_B.p, d_VA.p, d_lam.p, d_Mu.p));
+        if (ny.chol) {  // full rank: the projector is I and V_A diag(lambda) V_A^T is Ka, exactly
+            d_Ka.alloc(ny.Ka.size());
+            HIP_OK(hipMemcpyAsync(d_Ka.p, ny.Ka.data(), ny.Ka.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        PROFILED(c, NLE_K_SMALL, nlek::update_matrix(c->stream, p, r, d_B.p, d_VA.p, d_lam.p, d_Ka.p, d_Mu.p));
     }  // (the arena keeps the three buffers alive until the stream has used them: frees are stream-ordered)
     pass_update(0, nlek::ROWPASS_COLSUM);
     for (int n = 1; n < 2 * T; ++n) {
@@ -1222,9 +1226,10 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         throw Fail{NLE_ERR_INVALID, "Phi-free path without tables supports at most 256 samples and 128 eigenvectors"};
     if (c->mode == 2 && !generic_ok && !tables_ok)
         throw Fail{NLE_ERR_INVALID, "Phi-free path supports at most 128 eigenvectors and a 32 x 36 sample grid"};
-    // auto: Phi-free needs enough non-sample pixels per sample (DESIGN.md "Numerics"); tiny images cost
-    // nothing either way
-    const bool want_fuse = c->mode >= 2 || (c->mode == 0 && (long long)H * W >= 64ll * gs.p());
+    // auto: the table form (all fp64) whenever it applies; the generic Phi-free form (fp32 affinities) needs
+    // enough non-sample pixels per sample for its rounding to average out (DESIGN.md "Numerics")
+    const bool enough_pixels = (long long)H * W >= 64ll * gs.p();
+    const bool want_fuse = c->mode >= 2 || (c->mode == 0 && (enough_pixels || tables_ok));
     HIP_OK(hipSetDevice(c->device));
 
     auto f = new nle_filter();
@@ -1243,7 +1248,8 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         Timer tm_a(c->stream);
         tm_a.start();
         SampleSet ss = fetch_samples(c, d_lum, gs, want_fuse && tables_ok);
-        const bool fuse = want_fuse && (generic_ok || (tables_ok && ss.quantised));
+        const bool fuse = c->mode == 0 ? ((tables_ok && ss.quantised) || (enough_pixels && generic_ok))
+                                       : (want_fuse && (generic_ok || (tables_ok && ss.quantised)));
         if (c->mode == 2 && !fuse)
             throw Fail{NLE_ERR_INVALID, "Phi-free path: more than 256 samples needs an integer-valued luminance plane"};
         tr.mark("fetch_samples");
