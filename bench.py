@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--simulate-world", type=int, default=0,
+                    help="timing only, one GPU: run rank 0 of a W-way row shard with a no-op all-reduce (results are "
+                         "meaningless, the per-rank compute time at 1/W of the rows is not)")
     ap.add_argument("--inflight", type=int, default=1, help="images in flight on one GPU (throughput mode, opt-in)")
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 materialised Phi, 2 Phi-free (NLE_MODE_*)")
     ap.add_argument("--cpu-sample", type=int, default=768, help="side of the CPU-baseline sample image")
@@ -168,6 +171,8 @@ def main():
     p = g["n_sel_rows"] * g["n_sel_cols"]
     if world > 1:
         ctx.set_shard(rank, world, p, lambda t: dist.all_reduce(t))
+    elif args.simulate_world > 1:
+        ctx.set_shard(0, args.simulate_world, p, lambda t: None)
 
     lum = torch.as_tensor(synth.synthetic_luminance(H, W).astype(np.float32), device=f"cuda:{local_rank}")
     n_local = ctx.local_pixels(H, W)
@@ -321,7 +326,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {H}x{W} synthetic luminance, {cfg['n_row']}x{cfg['n_col']} samples "
                                    f"(p={p}), K={cfg['K']}, T={cfg['T']}, L={L} layers; input resident in HBM",
-                       "parallelism": (f"row-slab x{world}" if world > 1 else "single GPU")
+                       "parallelism": (f"row-slab x{world}" if world > 1 else
+                                       f"TIMING ONLY: rank 0 of a simulated {args.simulate_world}-way row shard, no-op all-reduce"
+                                       if args.simulate_world > 1 else "single GPU")
                        + (f", {args.inflight} images in flight" if args.inflight > 1 else ""),
                        "formulation": form + (" (V implicit, apply in sample space)" if lazy else ""),
                        "storage": ("fp64 tables, histograms, reductions and MFMA; fp32 output planes; V implicit" if lazy else
