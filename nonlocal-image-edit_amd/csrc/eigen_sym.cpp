@@ -12,12 +12,17 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 #include <thread>
 #include <vector>
 #if defined(__x86_64__)
 #include <immintrin.h>
+#endif
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
 #endif
 
 namespace nleh {
@@ -410,6 +415,53 @@ NLE_SIMD_CLONES void back_transform_cols(int n, const double* V, const double* h
     }
 }
 
+// CPUs that share the calling thread's last-level cache (Linux sysfs), empty if unknown.  Short-lived helper
+// threads are pinned there: left to the scheduler on a 256-CPU host they start on other core complexes, with cold
+// caches and a remote copy of the matrix, and cost more than they save.
+std::vector<int> llc_siblings() {
+    std::vector<int> cpus;
+#if defined(__linux__)
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return cpus;
+    char path[128];
+    std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+    FILE* fh = std::fopen(path, "r");
+    if (!fh) return cpus;
+    char buf[512] = {0};
+    if (std::fgets(buf, sizeof buf, fh)) {
+        const char* q = buf;
+        while (*q) {  // "a-b,c,d-e"
+            char* end = nullptr;
+            long a = std::strtol(q, &end, 10);
+            if (end == q) break;
+            long b = a;
+            if (*end == '-') {
+                q = end + 1;
+                b = std::strtol(q, &end, 10);
+            }
+            for (long c = a; c <= b && cpus.size() < 256; ++c) cpus.push_back((int)c);
+            q = (*end == ',') ? end + 1 : end;
+            if (*end != ',') break;
+        }
+    }
+    std::fclose(fh);
+#endif
+    return cpus;
+}
+
+void pin_to(std::thread& t, const std::vector<int>& cpus) {
+#if defined(__linux__)
+    if (cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) CPU_SET(c, &set);
+    (void)pthread_setaffinity_np(t.native_handle(), sizeof set, &set);
+#else
+    (void)t;
+    (void)cpus;
+#endif
+}
+
 template <typename F>
 void run_split(int nparts, int nthreads, F&& body) {  // body(part) for part in [0, nparts), split over threads
     nthreads = std::max(1, std::min(nthreads, nparts));
@@ -417,11 +469,16 @@ void run_split(int nparts, int nthreads, F&& body) {  // body(part) for part in 
         for (int q = 0; q < nparts; ++q) body(q);
         return;
     }
+    static const bool pin = std::getenv("NLE_NO_PIN") == nullptr;
+    const std::vector<int> near = pin ? llc_siblings() : std::vector<int>();
     std::vector<std::thread> th;
     auto work = [&](int t) {
         for (int q = t; q < nparts; q += nthreads) body(q);
     };
-    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+    for (int t = 1; t < nthreads; ++t) {
+        th.emplace_back(work, t);
+        pin_to(th.back(), near);
+    }
     work(0);
     for (auto& x : th) x.join();
 }
@@ -589,12 +646,16 @@ bool sym_eigen(const double* M, int n, double* U, double* D) {
     return true;
 }
 
-// Threads for the two parallel phases.  Measured on the GPU box's host (EPYC 9575F, 16-CPU quota spread over
-// 256 logical CPUs): short-lived threads land on other core complexes and make n = 200 slower (1.3 -> 2.8 ms),
-// while n = 900 gains (124 -> 74 ms with 4 threads, 62 ms with 16).  NLE_EIG_THREADS overrides.
-int default_threads(int n) {
+// Threads for the two parallel phases (helpers are pinned to the caller's L3 domain, see run_split).  Measured on
+// the GPU box's host (EPYC 9575F, 16-CPU quota over 256 logical CPUs), n = 200: all eigenvectors 1.90 ms on one
+// thread, 1.35 ms on four (classic one-loop form: 1.65 ms); top 50: 1.27 ms on one, 1.14 ms on two, 1.30 ms on
+// four (thread start-up is ~50 us each).  Unpinned helpers land on other core complexes: 1.8 - 2.8 ms.
+// n = 900, all eigenvectors: 124 ms on one thread, 74 ms on four, 62 ms on sixteen.  NLE_EIG_THREADS overrides.
+int default_threads(int n, int ncols) {
     if (const char* e = std::getenv("NLE_EIG_THREADS")) return std::max(1, std::atoi(e));
-    return n >= 512 ? 8 : 1;
+    if (n < 96) return 1;
+    if (n >= 512) return 8;
+    return 2 * ncols > n ? 4 : 2;
 }
 
 bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, double* D) {
@@ -605,7 +666,7 @@ bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, d
         if (ncols) U[0] = 1.0;
         return true;
     }
-    if (nthreads <= 0) nthreads = default_threads(n);
+    if (nthreads <= 0) nthreads = default_threads(n, ncols);
     std::vector<double> V((size_t)n * n), d(n), e(n), hs(n);
     for (int c = 0; c < n; ++c)  // mirror the lower triangle (SelfAdjointEigenSolver reads only the lower one)
         for (int r = 0; r < n; ++r) V[(size_t)c * n + r] = (r >= c) ? M[(size_t)c * n + r] : M[(size_t)r * n + c];
@@ -643,10 +704,9 @@ bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, d
 
 bool eigen_decomposition_top(const double* M, int n, double eps, int kmax, double* U, double* D, int* r_out) {
     kmax = std::max(0, std::min(kmax, n));
-    if (2 * kmax > n && default_threads(n) == 1) {
+    if (2 * kmax > n && default_threads(n, kmax) == 1) {
         // most eigenvectors wanted, one thread: accumulating the orthogonal factor (classic form) is cheaper
-        // than back-transforming them one by one (n = 200: 1.65 ms against 1.9 ms; n = 900: 116 against 124 ms,
-        // but 62-74 ms once the two phases are threaded)
+        // than back-transforming them one by one (n = 200: 1.65 ms against 1.9 ms)
         std::vector<double> Ua((size_t)n * n), Da(n);
         if (!sym_eigen(M, n, Ua.data(), Da.data())) return false;
         for (int j = 0; j < n; ++j) {  // ascending -> descending
