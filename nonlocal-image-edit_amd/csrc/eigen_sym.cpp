@@ -415,9 +415,9 @@ NLE_SIMD_CLONES void back_transform_cols(int n, const double* V, const double* h
     }
 }
 
-// CPUs that share the calling thread's last-level cache (Linux sysfs), empty if unknown.  Short-lived helper
-// threads are pinned there: left to the scheduler on a 256-CPU host they start on other core complexes, with cold
-// caches and a remote copy of the matrix, and cost more than they save.
+// CPUs that share the calling thread's last-level cache (Linux sysfs), empty if unknown: where helper threads are
+// pinned when NLE_PIN_THREADS is set (left to the scheduler on a 256-CPU host they start on other core complexes,
+// with cold caches and a remote copy of the matrix).
 std::vector<int> llc_siblings() {
     std::vector<int> cpus;
 #if defined(__linux__)
@@ -469,7 +469,7 @@ void run_split(int nparts, int nthreads, F&& body) {  // body(part) for part in 
         for (int q = 0; q < nparts; ++q) body(q);
         return;
     }
-    static const bool pin = std::getenv("NLE_NO_PIN") == nullptr;
+    static const bool pin = std::getenv("NLE_PIN_THREADS") != nullptr;  // opt-in, see default_threads
     const std::vector<int> near = pin ? llc_siblings() : std::vector<int>();
     std::vector<std::thread> th;
     auto work = [&](int t) {
@@ -646,16 +646,17 @@ bool sym_eigen(const double* M, int n, double* U, double* D) {
     return true;
 }
 
-// Threads for the two parallel phases (helpers are pinned to the caller's L3 domain, see run_split).  Measured on
-// the GPU box's host (EPYC 9575F, 16-CPU quota over 256 logical CPUs), n = 200: all eigenvectors 1.90 ms on one
-// thread, 1.35 ms on four (classic one-loop form: 1.65 ms); top 50: 1.27 ms on one, 1.14 ms on two, 1.30 ms on
-// four (thread start-up is ~50 us each).  Unpinned helpers land on other core complexes: 1.8 - 2.8 ms.
-// n = 900, all eigenvectors: 124 ms on one thread, 74 ms on four, 62 ms on sixteen.  NLE_EIG_THREADS overrides.
-int default_threads(int n, int ncols) {
+// Threads for the two parallel phases.  Measured on the GPU box's host (EPYC 9575F, a 16-CPU quota over 256 logical
+// CPUs shared with other tenants), n = 200: helpers left to the scheduler start on other core complexes and make the
+// solve slower (1.3 -> 1.8-2.8 ms); pinned to the caller's L3 domain (NLE_PIN_THREADS=1) they gain a little (all
+// eigenvectors 1.90 -> 1.35 ms on four threads, top 50 1.27 -> 1.14 ms on two) but stall for milliseconds whenever
+// that domain is busy with somebody else's work, which a shared host cannot rule out.  So: one thread below
+// n = 512; from there eight unpinned helpers pay (n = 900, all eigenvectors: 124 -> ~70 ms).  NLE_EIG_THREADS overrides.
+void run_parts(int nparts, int nthreads, const std::function<void(int)>& body) { run_split(nparts, nthreads, body); }
+
+int default_threads(int n, int) {
     if (const char* e = std::getenv("NLE_EIG_THREADS")) return std::max(1, std::atoi(e));
-    if (n < 96) return 1;
-    if (n >= 512) return 8;
-    return 2 * ncols > n ? 4 : 2;
+    return n >= 512 ? 8 : 1;
 }
 
 bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, double* D) {
@@ -706,7 +707,8 @@ bool eigen_decomposition_top(const double* M, int n, double eps, int kmax, doubl
     kmax = std::max(0, std::min(kmax, n));
     if (2 * kmax > n && default_threads(n, kmax) == 1) {
         // most eigenvectors wanted, one thread: accumulating the orthogonal factor (classic form) is cheaper
-        // than back-transforming them one by one (n = 200: 1.65 ms against 1.9 ms)
+        // than back-transforming them one by one (n = 200: 1.65 ms against 1.9 ms; n = 900: 116 against 124 ms,
+        // but ~70 ms once the two phases are threaded)
         std::vector<double> Ua((size_t)n * n), Da(n);
         if (!sym_eigen(M, n, Ua.data(), Da.data())) return false;
         for (int j = 0; j < n; ++j) {  // ascending -> descending

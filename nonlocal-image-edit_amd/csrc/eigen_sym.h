@@ -1,6 +1,8 @@
 // Host fp64 symmetric eigensolver (see eigen_sym.cpp).  Internal to libnle_hip.so.
 #pragma once
 
+#include <functional>
+
 namespace nleh {
 
 // M: n x n column-major symmetric (lower triangle read).  U: n x n column-major
@@ -32,5 +34,9 @@ bool cholesky_with_inverse(const double* M, int n, double* L, double* Linv, doub
 void gemm_nn_cols(const double* A, const double* B, double* C, int m, int k, int n, int j0, int j1);
 void gemm_nt_cols(const double* A, const double* B, double* C, int m, int k, int n, int j0, int j1);
 void gemm_tn_cols(const double* A, const double* B, double* C, int m, int k, int n, int j0, int j1);
+
+// body(part) for part in [0, nparts) on up to nthreads threads (the caller's plus short-lived helpers pinned to its
+// L3 domain); parts are dealt round-robin
+void run_parts(int nparts, int nthreads, const std::function<void(int)>& body);
 
 }  // namespace nleh

@@ -556,21 +556,19 @@ std::vector<double> gram_all(nle_ctx* c, const float* d_phi, long long M, int ld
 
 // ---- small host algebra, column-major ----
 // The p x p products of the orthogonalisation run on the register-blocked kernels of eigen_sym.cpp (a 200^3
-// product is ~0.2 ms on one core); only products of more than ~80 MFLOP per thread are split by output
-// columns over short-lived threads (thread start-up and remote caches cost more than that on the GPU box).
+// product is ~0.2 ms on one core); only products of more than ~80 MFLOP per thread are split by output columns
+// over short-lived threads (nleh::run_parts; thread start-up and remote caches cost more than that on the GPU box).
 template <typename F>
 void par_cols(int n, long long work_per_col, F&& body) {
-    int nt = (int)std::min<long long>(16, (work_per_col * n) / 40000000 + 1);
+    const long long work = work_per_col * n;  // multiply-adds
+    int nt = (int)std::min<long long>(16, work / 40000000 + 1);
     if (const char* e = std::getenv("NLE_HOST_THREADS")) nt = std::max(1, std::atoi(e));
     nt = std::min(nt, n);
     if (nt <= 1) {
         body(0, n);
         return;
     }
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back([&, t] { body((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); });
-    body(0, n / nt);
-    for (auto& x : th) x.join();
+    nleh::run_parts(nt, nt, [&](int t) { body((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); });
 }
 // C (m x n) = A (m x k) * B (k x n)
 void mm(const double* A, const double* B, double* C, int m, int k, int n) {
