@@ -1494,6 +1494,7 @@ template <int MT>
 __global__ __launch_bounds__(256) void k_ghist_gemm(const double* __restrict__ EE, int ldm, const double* __restrict__ A,
                                                     long long N, int Ktot, int ksplit, double* __restrict__ Cz) {
     constexpr int KB = 16;
+    constexpr int EPT = (KB * MT * 16 + 255) / 256;  // EE values staged per thread and k block
     __shared__ __attribute__((aligned(16))) double sE[KB][MT * 16 + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const long long n0 = ((long long)blockIdx.x * 4 + wave) * 16;
@@ -1504,20 +1505,39 @@ __global__ __launch_bounds__(256) void k_ghist_gemm(const double* __restrict__ E
     f64x4 acc[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[j] = f64x4{0.0, 0.0, 0.0, 0.0};
-    for (int k0 = kbeg; k0 < K; k0 += KB) {
-        __syncthreads();
-        for (int idx = tid; idx < KB * MT * 16; idx += 256) {
-            const int kk = idx / (MT * 16), mm = idx % (MT * 16);
-            sE[kk][mm] = (k0 + kk < K && m0 + mm < ldm) ? EE[(size_t)(k0 + kk) * ldm + m0 + mm] : 0.0;
-        }
-        __syncthreads();
+    // software pipeline over the 16-row k blocks: the next block's EE slice and A operands are fetched into
+    // registers while the MFMAs of the current one run; LDS is rewritten between two barriers
+    double e_next[EPT], b_next[KB / 4];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int kk = 0; kk < KB; kk += 4) {
-            const int kr = k0 + kk + kq;
-            const double bv = (ncol_ok && kr < K) ? A[(size_t)kr * N + n0 + l15] : 0.0;
+        for (int q = 0; q < EPT; ++q) {
+            const int idx = tid + q * 256, kk = idx / (MT * 16), mm = idx % (MT * 16);
+            e_next[q] = (idx < KB * MT * 16 && k0 + kk < K && m0 + mm < ldm) ? EE[(size_t)(k0 + kk) * ldm + m0 + mm] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < KB / 4; ++q) {
+            const int kr = k0 + 4 * q + kq;
+            b_next[q] = (ncol_ok && kr < K) ? A[(size_t)kr * N + n0 + l15] : 0.0;
+        }
+    };
+    if (kbeg < K) fetch(kbeg);
+    for (int k0 = kbeg; k0 < K; k0 += KB) {
+        __syncthreads();  // everybody is done reading the previous block's sE
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int idx = tid + q * 256;
+            if (idx < KB * MT * 16) sE[idx / (MT * 16)][idx % (MT * 16)] = e_next[q];
+        }
+        double bcur[KB / 4];
+#pragma unroll
+        for (int q = 0; q < KB / 4; ++q) bcur[q] = b_next[q];
+        __syncthreads();
+        if (k0 + KB < K) fetch(k0 + KB);
+#pragma unroll
+        for (int q = 0; q < KB / 4; ++q) {
 #pragma unroll
             for (int j = 0; j < MT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(sE[kk + kq][j * 16 + l15], bv, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(sE[4 * q + kq][j * 16 + l15], bcur[q], acc[j], 0, 0, 0);
         }
     }
     if (ncol_ok) {
