@@ -9,6 +9,10 @@ namespace nleh {
 // eigenvectors (columns), D: eigenvalues ASCENDING.  false = QL did not converge.
 bool sym_eigen(const double* M, int n, double* U, double* D);
 
+// Same results as sym_eigen (ASCENDING); the QL rotations are recorded and applied to the accumulated orthogonal
+// factor by cache-resident row blocks (n = 200: 1.65 -> ~1.45 ms).
+bool sym_eigen_blocked(const double* M, int n, double* U, double* D);
+
 // The reference's eigenDecomposition (src/filter.cpp:204-228): eigenvalues DESCENDING,
 // *r = length of the leading run with D >= eps (columns/values beyond *r are still
 // filled but not part of the result).

@@ -20,6 +20,9 @@ int main(int argc,char**argv){
       auto t1=std::chrono::steady_clock::now();
       sym_eigen_top(A.data(),n,ncols,nthreads,U.data(),D.data());
       auto t2=std::chrono::steady_clock::now();
+      sym_eigen_blocked(A.data(),n,U.data(),D.data());
+      auto t3=std::chrono::steady_clock::now();
+      printf("n=%d classic+blocked rotations %.3f ms\n",n,ms(t2,t3));
       printf("n=%d classic %.3f ms   three-phase (ncols=%d, threads=%d) %.3f ms\n",n,ms(t0,t1),ncols,nthreads,ms(t1,t2));
     }
   }
