@@ -71,7 +71,7 @@ def build_host(force: bool = False):
     out = []
     common = [os.path.join(HOST, "filter.cpp"), os.path.join(HOST, "image_io.cpp")]
     hdrs = [os.path.join(ROOT, "include", "nle", "filter.hpp"), os.path.join(ROOT, "include", "nle", "image_io.hpp"),
-            os.path.join(ROOT, "include", "nle.h")]
+            os.path.join(ROOT, "include", "nle.h"), os.path.join(HOST, "cli_common.hpp")]
     for name, main in (("enhance", "enhance.cpp"), ("denoise", "denoise.cpp"), ("test_filter", "test_filter.cpp")):
         target = os.path.join(BINDIR, name)
         srcs = common + [os.path.join(HOST, main)]
