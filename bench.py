@@ -246,7 +246,9 @@ def main():
     form = "materialised" if "nystrom_extend" in ran else ("phi_free_tables" if "gram_gemm" in ran else "phi_free_exp")
     lazy = form == "phi_free_tables" and "project" not in ran
     models = roofline_models(info, L, form, g, lazy)
-    traffic = load_traffic()
+    # (the committed PMC summary was collected at N = 1 on the default config: per-launch bytes of a row slab or of
+    # another config differ, so `traffic` is only attached to that case)
+    traffic = load_traffic() if (world == 1 and args.config == "cfg4" and args.simulate_world <= 1) else {}
     per_kernel = {}
     for name, (launches, total_ms) in stats.items():
         if launches == 0:
