@@ -165,7 +165,8 @@ int nle_filter_info(const nle_filter* f, long long* n_local, int* K, int* r, int
                     int* row0, int* row1);
 int nle_filter_eigvals(const nle_filter* f, double* h_eigvals /* K */);
 /* min / max coefficient of the first `ncols` eigenvectors over this rank's slab (what the reference
- * prints at src/filter.cpp:506): h_min[ncols], h_max[ncols] */
+ * prints at src/filter.cpp:506): h_min[ncols], h_max[ncols].  A filter whose V is implicit projects just
+ * these columns into a temporary; it does not materialise the N x K matrix. */
 int nle_filter_eigvec_range(const nle_filter* f, int ncols, double* h_min, double* h_max);
 /* device pointer + leading dimension of V (n_local x ld), for inspection.  In the table formulation
  * the filter keeps V implicit (V = diag(c) K D) and applies it on its p-sized side; the first call of

@@ -500,6 +500,14 @@ class NLEFilter:
         _check(lib().nle_filter_copy_eigvecs(self._f, C.c_void_p(out.data_ptr())), self.ctx._h)
         return out
 
+    def eigvec_range(self, ncols):
+        """(min, max) of the first `ncols` eigenvector columns over this rank's pixels (the banner of
+        src/filter.cpp:506); does not materialise an implicit V"""
+        mn = np.zeros(ncols, dtype=np.float64)
+        mx = np.zeros(ncols, dtype=np.float64)
+        _check(lib().nle_filter_eigvec_range(self._f, int(ncols), _np_ptr(mn), _np_ptr(mx)), self.ctx._h)
+        return mn, mx
+
     def timings(self):
         ms = np.zeros(6)
         _check(lib().nle_filter_timings(self._f, _np_ptr(ms)))

@@ -1760,10 +1760,35 @@ int nle_filter_eigvec_range(const nle_filter* f, int ncols, double* h_min, doubl
     return guard(f->ctx, [&] {
         nle_ctx* c = f->ctx;
         HIP_OK(hipSetDevice(c->device));
-        ensure_V(const_cast<nle_filter*>(f));
+        // an implicit V is not materialised for this: only the requested leading columns are projected, into a
+        // temporary (the CLI prints the range of 5 of K columns, src/filter.cpp:506)
+        const float* d_cols = f->d_V;
+        int ldc = f->ldv;
+        DevBuf<float> d_tmp;
+        if (!f->d_V && f->lazy) {
+            const long long M = f->n_local, pix0 = (long long)f->row0 * f->W;
+            const int ldd_full = f->ldd, ldd = nlek::project64_ld(ncols);
+            std::vector<double> Dfull((size_t)f->p * ldd_full), Dk((size_t)f->p * ldd, 0.0);
+            HIP_OK(hipMemcpyAsync(Dfull.data(), f->d_D, Dfull.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(hipStreamSynchronize(c->stream));
+            for (int a = 0; a < f->p; ++a)
+                for (int k = 0; k < ncols; ++k) Dk[(size_t)a * ldd + k] = Dfull[(size_t)a * ldd_full + k];
+            DevBuf<double> d_Dk(Dk.size());
+            HIP_OK(hipMemcpyAsync(d_Dk.p, Dk.data(), Dk.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            ldc = ld4(ncols);
+            d_tmp.alloc((size_t)std::max<long long>(M, 1) * ldc);
+            PROFILED(c, NLE_K_PROJECT, nlek::project64(c->stream, f->d_lum - pix0, f->gs, f->d_samples, f->p, f->nsw, f->npw,
+                                                       pix0, M, d_Dk.p, ncols, f->d_c, d_tmp.p, ldc));
+            scatter_sample_rows(c, f->h_sample_pix, f->p, f->h_Vrows, f->p, ncols, ldc, pix0, M, d_tmp.p);
+            HIP_OK(hipStreamSynchronize(c->stream));  // Dk (host) is consumed
+            d_cols = d_tmp.p;
+        } else {
+            ensure_V(const_cast<nle_filter*>(f));
+            d_cols = f->d_V;
+        }
         const int nb = 256;
         DevBuf<float> d_out((size_t)nb * 2 * ncols);
-        HIP_OK(nlek::col_range(c->stream, f->d_V, f->n_local, f->ldv, ncols, d_out.p, nb));
+        HIP_OK(nlek::col_range(c->stream, d_cols, f->n_local, ldc, ncols, d_out.p, nb));
         std::vector<float> out((size_t)nb * 2 * ncols);
         HIP_OK(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));

@@ -226,6 +226,21 @@ def test_cholesky_and_eigen_forms_of_Ka_agree(nle, oracle, ctx, case, monkeypatc
         assert rel_l2(Y_c[j], Y_e[j]) < 1e-5, f"layer {j}"
 
 
+def test_eigvec_range_without_materialising_V(nle, oracle, ctx):
+    """the `Eigvec i ... minCoeff ... maxCoeff` banner (src/filter.cpp:506) needs the range of a few columns: on the
+    default path they are projected into a temporary, and agree with the materialised matrix"""
+    H, W = 96, 128
+    x = oracle.synthetic_luminance(H, W).astype(np.float32)
+    f = nle.NLEFilter(ctx).train_filter(x, 6, 8, 32.0, 30.0, 10, 10)
+    mn, mx = f.eigvec_range(4)
+    V = f.eigvecs().cpu().numpy()[:, :4].astype(np.float64)      # materialises
+    assert np.allclose(mn, V.min(0), rtol=0, atol=1e-6) and np.allclose(mx, V.max(0), rtol=0, atol=1e-6)
+    mn2, mx2 = f.eigvec_range(4)                                  # now from the stored matrix
+    assert np.allclose(mn2, V.min(0), rtol=0, atol=1e-7) and np.allclose(mx2, V.max(0), rtol=0, atol=1e-7)
+    with pytest.raises(nle.NLEError):
+        f.eigvec_range(f.info()["K"] + 1)
+
+
 def test_errors_mirror_reference(nle, oracle, ctx):
     x = oracle.synthetic_luminance(20, 30).astype(np.float32)
     with pytest.raises(nle.NLEError, match="Number of samples per row and col must be <= that of image"):
