@@ -163,6 +163,14 @@ void nle_filter_destroy(nle_filter* f);
  * (K' of src/filter.cpp:314), r = retained rank of Ka, p = realised sample count. */
 int nle_filter_info(const nle_filter* f, long long* n_local, int* K, int* r, int* p,
                     int* row0, int* row1);
+/* What the last train decided, h_info[8]:
+ *   [0] formulation of the N-sized passes that was taken (NLE_MODE_MATERIALISED, NLE_MODE_PHI_FREE = look-up
+ *       tables, NLE_MODE_PHI_FREE_EXP) -- auto mode resolves to one of these per image;
+ *   [1] p realised sample count;  [2] eigenvalues of Ka kept by the cut at 1e-10 (src/filter.cpp:214,262-271);
+ *   [3] eigenvalues of Wa kept (:287);  [4] eigenvalues of Q kept (:313);  [5] K' = min(nEigenVectors, [4]) (:314);
+ *   [6] 1 if Ka was factored by Cholesky (certified full rank at the cut), 0 if by the eigensolver;
+ *   [7] the same for Wa's inverse root. */
+int nle_filter_diag(const nle_filter* f, int* h_info);
 int nle_filter_eigvals(const nle_filter* f, double* h_eigvals /* K */);
 /* min / max coefficient of the first `ncols` eigenvectors over this rank's slab (what the reference
  * prints at src/filter.cpp:506): h_min[ncols], h_max[ncols].  A filter whose V is implicit projects just

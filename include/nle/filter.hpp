@@ -13,6 +13,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <tuple>
 #include <utility>
@@ -170,11 +171,10 @@ Image bilateralFilter8_device(const Image& plane, double sigmaColor, double sigm
 // include/filter.hpp:35-54.  The trained state (m_eigvecs N x K', m_eigvals) lives on the GPU.
 class NLEFilter {
 public:
+    // copyable like the reference's class (its state is two Eigen members, include/filter.hpp:52-53): copies
+    // share the trained, immutable device-side filter
     NLEFilter();
     ~NLEFilter();
-    NLEFilter(const NLEFilter&) = delete;
-    NLEFilter& operator=(const NLEFilter&) = delete;
-    NLEFilter(NLEFilter&& o) noexcept;
 
     void trainForEnhancement(const Image& image, int nRowSamples, int nColSamples, DType hx, DType hy,
                              int nSinkhornIter = 10, int nEigenVectors = 5);
@@ -199,11 +199,14 @@ public:
     Vec eigvals() const;                 // m_eigvals
     Mat eigvecs() const;                 // m_eigvecs, downloaded (N x K')
     void timings(double ms[6]) const;    // nle_filter_timings
+    // nle_filter_diag: {formulation, p, rank Ka, rank Wa, rank Q, K', chol(Ka), chol(Wa)}
+    void diag(int info[8]) const;
     bool verbose = true;                 // the reference's stdout stage banners (:483-498,506)
 
 private:
     nle_ctx* ctx_ = nullptr;
-    nle_filter* f_ = nullptr;
+    std::shared_ptr<nle_filter> fh_;  // nle_filter_destroy when the last copy goes
+    nle_filter* f_ = nullptr;         // == fh_.get()
     int rows_ = 0, cols_ = 0;
 };
 

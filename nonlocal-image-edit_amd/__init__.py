@@ -59,6 +59,7 @@ _SIGNATURES = {
                                  C.c_int, C.POINTER(_P)]),
     "nle_filter_destroy": (None, [_P]),
     "nle_filter_info": (C.c_int, [_P, C.POINTER(C.c_longlong)] + [C.POINTER(C.c_int)] * 5),
+    "nle_filter_diag": (C.c_int, [_P, _P]),
     "nle_filter_eigvals": (C.c_int, [_P, _P]),
     "nle_filter_eigvec_range": (C.c_int, [_P, C.c_int, _P, _P]),
     "nle_filter_eigvecs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int)]),
@@ -83,6 +84,7 @@ _SIGNATURES = {
     "nle_bench_sinkhorn_pass": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+MODE_AUTO, MODE_MATERIALISED, MODE_PHI_FREE, MODE_PHI_FREE_EXP = 0, 1, 2, 3   # NLE_MODE_* of include/nle.h
 
 _lib = None
 
@@ -482,6 +484,13 @@ class NLEFilter:
         v = [C.c_int() for _ in range(5)]
         _check(lib().nle_filter_info(self._f, C.byref(n), *[C.byref(x) for x in v]))
         return dict(n_local=n.value, K=v[0].value, r=v[1].value, p=v[2].value, row0=v[3].value, row1=v[4].value)
+
+    def diag(self):
+        """what the last train decided (nle_filter_diag): formulation taken, ranks kept by the three 1e-10 cuts"""
+        v = np.zeros(8, dtype=np.int32)
+        _check(lib().nle_filter_diag(self._f, _np_ptr(v)))
+        keys = ("formulation", "p", "r_Ka", "r_Wa", "r_Q", "K", "chol_Ka", "chol_Wa")
+        return {k: int(x) for k, x in zip(keys, v)}
 
     @property
     def eigvals(self):

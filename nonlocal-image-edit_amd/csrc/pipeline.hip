@@ -66,6 +66,8 @@ struct nle_filter {
     size_t v_bytes = 0;
     std::vector<double> eigvals;
     double ms[6] = {0, 0, 0, 0, 0, 0};
+    // nle_filter_diag: formulation taken, eigenvalues kept by the three cuts (:214 on Ka, Wa, Q), Cholesky shortcuts
+    int formulation = 0, r_wa = 0, r_q = 0, chol_ka = 0, chol_wa = 0;
     // Lazy / sample-space form (tables formulation): m_eigvecs is the implicit V = diag(c) K D.  apply()
     // works on the p-sized side of it (t = D^T sum_i k_i c_i x_i, y = c_i k_i . D(f o t)) and never needs
     // the N x K' matrix; nle_filter_eigvecs & co. build it on demand with the projection kernel.
@@ -608,7 +610,7 @@ double now_ms() {
 // reference src/filter.cpp:247-250 (W blocks, q = phi.cols()), :282-331 (orthogonalize).
 namespace {
 struct Ortho {
-    int q = 0, K = 0;
+    int q = 0, K = 0, r_wa = 0, r_q = 0;
     std::vector<double> Sq, Cproj, VArows, Wa;
 };
 
@@ -665,6 +667,7 @@ Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_
         for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * s;
     }
     mm_nt(Us.data(), U2.data(), S.data(), q, r2, q);
+    o.r_wa = r2;
     // Q = Wa + S * WW * S  (:296)
     std::vector<double> T1((size_t)q * q), Qm((size_t)q * q);
     mm(S.data(), WW.data(), T1.data(), q, q, q);
@@ -677,6 +680,7 @@ Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_
     const int K = std::min(n_eig, rq);  // :314
     if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
     o.K = K;
+    o.r_q = rq;
     o.Sq.assign(Sq.begin(), Sq.begin() + K);
     // T2 = S * Vq * diag(Sq^-1/2)  (q x K)
     std::vector<double> T2((size_t)q * K);
@@ -703,7 +707,8 @@ Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_
 // No 1/lambda factor appears anywhere: the ill-conditioned B = V_A / lambda is only used for
 // the r-vectors of the Sinkhorn update.
 struct OrthoSS {
-    int q = 0, K = 0;
+    int q = 0, K = 0, r_wa = 0, r_q = 0;
+    bool chol_wa = false;
     std::vector<double> Sq, D, Vrows;  // D: p x K, Vrows: p x K (col-major)
     // state between the two halves
     int p = 0, r = 0;
@@ -761,6 +766,8 @@ void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<do
             o.St = std::move(Li);
             o.A2.resize((size_t)q * q);
             mm(Lt.data(), L.data(), o.A2.data(), q, q, q);  // F^T A^2 F = L^T L
+            o.r_wa = q;
+            o.chol_wa = true;
             return;
         }
     }
@@ -774,6 +781,7 @@ void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<do
         for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * sv;
     }
     mm_nt(Us.data(), U2.data(), o.S.data(), q, r2, q);  // :287-292
+    o.r_wa = r2;
     if (std::getenv("NLE_TRACE"))
         fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e)\n", r2, q, l2[0],
                 r2 > 0 ? l2[r2 - 1] : 0.0);
@@ -812,6 +820,7 @@ void ortho_ss_finish(OrthoSS& o, std::vector<double> Gk, int n_eig) {
     const int K = std::min(n_eig, rq);  // :314
     if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
     o.K = K;
+    o.r_q = rq;
     o.Sq.assign(Sq.begin(), Sq.begin() + K);
     std::vector<double> T2((size_t)q * K), RT2((size_t)q * K);
     mm(S.data(), Vq.data(), T2.data(), q, q, K);
@@ -908,6 +917,9 @@ void train_materialised(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     f->K = o.K;
     f->ldv = ld4(o.K);
     f->eigvals = o.Sq;
+    f->formulation = NLE_MODE_MATERIALISED;
+    f->r_wa = o.r_wa;
+    f->r_q = o.r_q;
     tm_p.start();
     std::vector<float> Cp((size_t)ny.r * f->ldv, 0.f);
     for (int k = 0; k < o.K; ++k)
@@ -1003,6 +1015,8 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     const Nystrom ny = solve();
     const int r = ny.r;
     f->r = r;
+    f->chol_ka = ny.chol ? 1 : 0;
+    f->formulation = hist ? NLE_MODE_PHI_FREE : NLE_MODE_PHI_FREE_EXP;
     {
         DevBuf<double> d_B(ny.B.size()), d_VA(ny.VA.size()), d_lam(r), d_Ka;
         HIP_OK(hipMemcpyAsync(d_B.p, ny.B.data(), ny.B.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1075,6 +1089,9 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     f->K = o.K;
     f->ldv = ld4(o.K);
     f->eigvals = o.Sq;
+    f->r_wa = o.r_wa;
+    f->r_q = o.r_q;
+    f->chol_wa = o.chol_wa ? 1 : 0;
 
     // V = diag(c) K_AB^T D: the Nystrom extension of the K' retained eigenvectors, affinity fused
     tm_p.start();
@@ -1746,6 +1763,13 @@ int nle_filter_info(const nle_filter* f, long long* n_local, int* K, int* r, int
     if (p) *p = f->p;
     if (row0) *row0 = f->row0;
     if (row1) *row1 = f->row1;
+    return NLE_OK;
+}
+
+int nle_filter_diag(const nle_filter* f, int* h_info) {
+    if (!f || !h_info) return NLE_ERR_INVALID;
+    const int v[8] = {f->formulation, f->p, f->r, f->r_wa, f->r_q, f->K, f->chol_ka, f->chol_wa};
+    std::copy(v, v + 8, h_info);
     return NLE_OK;
 }
 

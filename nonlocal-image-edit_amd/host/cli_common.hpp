@@ -5,6 +5,8 @@
 // (usage, unreadable image) for drop-in compatibility.
 #pragma once
 
+#include <cstdlib>
+#include <fstream>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -49,8 +51,30 @@ inline nle::Image load(const FilterArgs& a) {
     return image;
 }
 
-inline int finish(const FilterArgs& a, const nle::Image& result) {
-    std::cout << "Done." << std::endl;
+// NLE_REPORT=<path> (an environment variable, so that reference-style command lines stay valid): one JSON object
+// with what the train decided (nle_filter_diag), the kept eigenvalues and the per-stage milliseconds
+inline void report(const nle::NLEFilter& filter) {
+    const char* path = std::getenv("NLE_REPORT");
+    if (!path || !*path) return;
+    int d[8];
+    double ms[6] = {0, 0, 0, 0, 0, 0};
+    filter.diag(d);
+    filter.timings(ms);
+    const nle::Vec ev = filter.eigvals();
+    std::ofstream os(path);
+    os.precision(17);
+    os << "{\"formulation\": " << d[0] << ", \"p\": " << d[1] << ", \"r_Ka\": " << d[2] << ", \"r_Wa\": " << d[3]
+       << ", \"r_Q\": " << d[4] << ", \"K\": " << d[5] << ", \"chol_Ka\": " << d[6] << ", \"chol_Wa\": " << d[7]
+       << ", \"eigvals\": [";
+    for (int i = 0; i < ev.size(); ++i) os << (i ? ", " : "") << ev(i);
+    os << "], \"ms\": {\"samples\": " << ms[0] << ", \"sinkhorn\": " << ms[1] << ", \"gram\": " << ms[2]
+       << ", \"project\": " << ms[3] << ", \"host\": " << ms[4] << ", \"train_total\": " << ms[5] << "}}" << std::endl;
+}
+
+// `banner`: the line the reference prints before it writes the file (src/enhance.cpp:45, src/denoise.cpp:45); the
+// window and the key press it announces do not exist here (headless)
+inline int finish(const FilterArgs& a, const nle::Image& result, const char* banner) {
+    std::cout << banner << std::endl;
     if (nle::imwrite(a.output, result)) return 0;
     std::cerr << "Failed to write " << a.output << std::endl;
     return 1;

@@ -16,5 +16,7 @@ int main(int argc, char* argv[]) {
     nle::NLEFilter filter;
     filter.trainForDenoise(image, a.rowSamples, a.colSamples, a.hx, a.hy, a.sinkhornIters, a.eigenVectors, sigmaColor,
                            sigmaSpace);
-    return nlecli::finish(a, filter.denoise(image, shrinkFactor, sigmaColor, sigmaSpace));
+    const nle::Image result = filter.denoise(image, shrinkFactor, sigmaColor, sigmaSpace);
+    nlecli::report(filter);
+    return nlecli::finish(a, result, "Done. Press any key in result window to exit.");  // src/denoise.cpp:45
 }

@@ -13,5 +13,7 @@ int main(int argc, char* argv[]) {
     if (image.empty()) return 0;                        // src/enhance.cpp:34-37
     nle::NLEFilter filter;
     filter.trainForEnhancement(image, a.rowSamples, a.colSamples, a.hx, a.hy, a.sinkhornIters, a.eigenVectors);
-    return nlecli::finish(a, filter.enhance(image, a.extra));  // the weights are argv[9..]
+    const nle::Image result = filter.enhance(image, a.extra);  // the weights are argv[9..]
+    nlecli::report(filter);
+    return nlecli::finish(a, result, "Done. Press any key in result window to exit.");  // src/enhance.cpp:45
 }

@@ -383,12 +383,7 @@ Image luminance_plane(const Image& lab) {  // split + convertTo(CV_64F), :460-46
 
 // ------------------------------------------------------------------ NLEFilter
 NLEFilter::NLEFilter() = default;
-NLEFilter::~NLEFilter() {
-    if (f_) nle_filter_destroy(f_);
-}
-NLEFilter::NLEFilter(NLEFilter&& o) noexcept : verbose(o.verbose), ctx_(o.ctx_), f_(o.f_), rows_(o.rows_), cols_(o.cols_) {
-    o.f_ = nullptr;
-}
+NLEFilter::~NLEFilter() = default;
 
 void NLEFilter::trainFilter(const Image& channel, int nRowSamples, int nColSamples, DType hx, DType hy,
                             int nSinkhornIter, int nEigenVectors) {  // :480-512
@@ -404,10 +399,8 @@ void NLEFilter::trainFilter(const Image& channel, int nRowSamples, int nColSampl
 void NLEFilter::trainOnDevice(const float* d_lum, int rows, int cols, int nRowSamples, int nColSamples, DType hx,
                               DType hy, int nSinkhornIter, int nEigenVectors) {
     ctx_ = shared_ctx();
-    if (f_) {
-        nle_filter_destroy(f_);
-        f_ = nullptr;
-    }
+    fh_.reset();
+    f_ = nullptr;
     if (verbose) {
         // the four stages run as one fused GPU pipeline; the banners keep the reference's stdout (:483-498)
         std::cout << "Computing kernel" << std::endl;
@@ -416,6 +409,7 @@ void NLEFilter::trainOnDevice(const float* d_lum, int rows, int cols, int nRowSa
         std::cout << "Orthogonalize" << std::endl;
     }
     check(nle_train(ctx_, d_lum, rows, cols, nRowSamples, nColSamples, hx, hy, nSinkhornIter, nEigenVectors, &f_), ctx_);
+    fh_.reset(f_, [](nle_filter* f) { nle_filter_destroy(f); });
     rows_ = rows;
     cols_ = cols;
     if (verbose) {
@@ -634,6 +628,11 @@ Mat NLEFilter::eigvecs() const {
 
 void NLEFilter::timings(double ms[6]) const {
     if (f_) nle_filter_timings(f_, ms);
+}
+
+void NLEFilter::diag(int info[8]) const {
+    std::fill(info, info + 8, 0);
+    if (f_) nle_filter_diag(f_, info);
 }
 
 }  // namespace nle

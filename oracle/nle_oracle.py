@@ -112,9 +112,13 @@ def compute_kernel(mat: np.ndarray, n_row_samples: int, n_col_samples: int,
     return perm, Ka, Kab
 
 
-def eigen_decomposition(M: np.ndarray, eps: float = EPS):
+def eigen_decomposition(M: np.ndarray, eps: float = EPS, info: list | None = None, force_rank: int | None = None):
     """`eigenDecomposition`, src/filter.cpp:204-228: lower-triangle symmetric eigensolve,
-    descending order, keep the leading run with D >= eps.  Returns (U, D)."""
+    descending order, keep the leading run with D >= eps.  Returns (U, D).
+
+    Diagnostics only (never used by the parity path): `info`, when given, receives a dict with the size, the
+    number kept and the eigenvalues either side of the cut; `force_rank` overrides the cut (used by the README-pair
+    study to ask which rank the author's Eigen build must have kept)."""
     M = np.asarray(M, dtype=np.float64)
     w, v = np.linalg.eigh(M, UPLO="L")
     D = w[::-1]
@@ -122,13 +126,18 @@ def eigen_decomposition(M: np.ndarray, eps: float = EPS):
     r = 0
     while r < D.size and D[r] >= eps:  # :214
         r += 1
+    if info is not None:
+        info.append(dict(n=int(D.size), kept=r, last_kept=float(D[r - 1]) if r else None,
+                         first_dropped=float(D[r]) if r < D.size else None))
+    if force_rank is not None:
+        r = int(force_rank)
     return np.ascontiguousarray(U[:, :r]), D[:r].copy()
 
 
-def nystrom_approximation(Ka: np.ndarray, Kab: np.ndarray):
+def nystrom_approximation(Ka: np.ndarray, Kab: np.ndarray, info: list | None = None, force_rank: int | None = None):
     """`nystromApproximation`, src/filter.cpp:257-280.  Returns (eigvals (r), phi (N x r)),
     phi = [V ; Kab^T V diag(1/lambda)] in [selected; rest] order."""
-    eigvecs, eigvals = eigen_decomposition(Ka)
+    eigvecs, eigvals = eigen_decomposition(Ka, info=info, force_rank=force_rank)
     inv, nnz = inplace_reciprocal(eigvals)  # :265-266
     eigvecs = eigvecs[:, :nnz]  # :269
     eigvals = eigvals[:nnz]  # :271
@@ -158,15 +167,15 @@ def sinkhorn_with_scalings(phi, eigvals, max_iter=10):
     return Wa, Wab, r, c
 
 
-def orthogonalize(Wa: np.ndarray, Wab: np.ndarray, n_eig_vectors: int = 5, eps: float = EPS):
+def orthogonalize(Wa: np.ndarray, Wab: np.ndarray, n_eig_vectors: int = 5, eps: float = EPS, info: list | None = None):
     """`orthogonalize`, src/filter.cpp:282-331, default (non-Spectra) branch :313-316.
     Returns (V (N x K'), Sq (K'))."""
-    eigvecs, eigvals = eigen_decomposition(Wa)  # :287
+    eigvecs, eigvals = eigen_decomposition(Wa, info=info)  # :287
     inv_root, _ = inplace_reciprocal(eigvals)  # :289-291
     inv_root = np.sqrt(inv_root)
     inv_root_wa = (eigvecs * inv_root[None, :]) @ eigvecs.T  # :292
     Q = Wa + inv_root_wa @ (Wab @ Wab.T) @ inv_root_wa  # :296
-    Vq, Sq = eigen_decomposition(Q)  # :313
+    Vq, Sq = eigen_decomposition(Q, info=info)  # :313
     k = min(n_eig_vectors, Vq.shape[1])  # :314
     Vq, Sq = Vq[:, :k], Sq[:k]
     inv_root_sq, _ = inplace_reciprocal(Sq)  # :319-321
@@ -199,14 +208,15 @@ def layer_responses(eigvals: np.ndarray, n_layers: int) -> np.ndarray:
 
 def train_filter(channel: np.ndarray, n_row_samples: int, n_col_samples: int,
                  hx: float, hy: float, n_sinkhorn_iter: int, n_eigen_vectors: int,
-                 return_intermediates: bool = False):
+                 return_intermediates: bool = False, info: list | None = None, force_rank: int | None = None):
     """`NLEFilter::trainFilter`, src/filter.cpp:480-502 (GUI loop :504-511 omitted).
-    Returns (eigvecs N x K' in PIXEL order, eigvals K')."""
+    Returns (eigvecs N x K' in PIXEL order, eigvals K').  `info` collects the three eigensolves' cut
+    diagnostics (K_A, W_A, Q, in that order); `force_rank` overrides K_A's cut (diagnostics only)."""
     perm, Ka, Kab = compute_kernel(channel, n_row_samples, n_col_samples, hx, hy)
-    eigvals, phi = nystrom_approximation(Ka, Kab)
+    eigvals, phi = nystrom_approximation(Ka, Kab, info=info, force_rank=force_rank)
     del Kab
     Wa, Wab, r_vec, c_vec = sinkhorn_with_scalings(phi, eigvals, n_sinkhorn_iter)
-    V, S = orthogonalize(Wa, Wab, n_eigen_vectors)
+    V, S = orthogonalize(Wa, Wab, n_eigen_vectors, info=info)
     out = np.empty_like(V)
     out[perm] = V  # :502  (P*V).row(P.indices[i]) = V.row(i)
     if return_intermediates:
@@ -442,18 +452,24 @@ def lab8_to_bgr(lab: np.ndarray) -> np.ndarray:
 
 
 def enhance_image(bgr: np.ndarray, n_row_samples, n_col_samples, hx, hy,
-                  n_sinkhorn_iter, n_eigen_vectors, weights) -> np.ndarray:
-    """`trainForEnhancement` + `enhance`, src/filter.cpp:514-519, 412-443."""
+                  n_sinkhorn_iter, n_eigen_vectors, weights, info: list | None = None,
+                  force_rank: int | None = None, return_L: bool = False):
+    """`trainForEnhancement` + `enhance`, src/filter.cpp:514-519, 412-443.  With `return_L` also returns the
+    8-bit filtered L plane (before Lab -> BGR) and the eigenvalues."""
     if bgr.ndim != 3 or bgr.shape[2] != 3:
         raise RuntimeError("Can only enhance RGB image.")  # :414-416
     lab = bgr_to_lab8(bgr)
     L = lab[..., 0].astype(np.float64)
-    V, S = train_filter(L, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter, n_eigen_vectors)
+    V, S = train_filter(L, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter, n_eigen_vectors,
+                        info=info, force_rank=force_rank)
     y = apply_filter(V, L, transform_eigenvalues(S, weights))
     y = np.clip(y, 0, 255)  # :434-435
     lab2 = lab.copy()
     lab2[..., 0] = np.rint(y).astype(np.uint8)  # convertTo(CV_8U): round-half-even, :436
-    return lab8_to_bgr(lab2)
+    out = lab8_to_bgr(lab2)
+    if return_L:
+        return out, lab2[..., 0].copy(), S
+    return out
 
 
 # --------------------------------------------------------------------------- denoise wrapper (SURVEY.md section 8f #3)

@@ -68,7 +68,7 @@ def test_enhance_cli_flower_matches_readme_pair(oracle, tmp_path, ext):
     lines = r.stdout.splitlines()
     assert lines[:4] == ["Computing kernel", "Nystrom approximation", "Sinkhorn", "Orthogonalize"]  # :483-498
     assert sum(l.startswith("Eigvec ") and "minCoeff" in l for l in lines) == 5                      # :506
-    assert lines[-1].startswith("Done.")
+    assert lines[-1] == "Done. Press any key in result window to exit."
     got = np.asarray(Image.open(out).convert("RGB"))[..., ::-1]
     want = np.asarray(Image.open(os.path.join(GOLDEN, "flower-filtered.png")).convert("RGB"))[..., ::-1]
     assert got.shape == want.shape == (267, 400, 3)

@@ -113,7 +113,7 @@ def test_denoise_cli_matches_the_oracle_pipeline(oracle, tmp_path):
     lines = r.stdout.splitlines()
     assert lines[:4] == ["Computing kernel", "Nystrom approximation", "Sinkhorn", "Orthogonalize"]   # :483-498
     assert sum(l.startswith("eig ") and " val: " in l for l in lines) == 20                            # :383
-    assert lines[-1].startswith("Done.")
+    assert lines[-1] == "Done. Press any key in result window to exit."
     got = np.asarray(Image.open(out).convert("RGB"))[..., ::-1]
     src = np.asarray(Image.open(src_path).convert("RGB"))[..., ::-1]
     want = oracle.denoise_image(src, 10, 20, 100.0, 30.0, 10, 20, 10, 10, 2.0)

@@ -1,0 +1,93 @@
+"""The HIP path on the reference's README sample pairs (README.md:72-83; tests/readme_pairs.py), i.e. in the
+rank-truncated regime most real invocations live in: eigenvalues of Ka, Wa and Q right at the 1e-10 cut
+(src/filter.cpp:204-216 via :262-271, :287, :313-316).
+
+Two legs per pair, both through the C ABI:
+  * the luminance plane through nle_train / nle_apply_layers (ctypes mirror) against the oracle: the SAME number of
+    eigenvalues kept by each of the three cuts, the same K', eigenvalues, every layer within 1e-4 relative L2, and the
+    8-bit output plane equal up to rounding ties;
+  * `bin/enhance <input> <out> <README args>` against the author's output image at the tolerance the oracle itself
+    meets (tests/test_oracle_readme_pairs.py), with the ranks taken from the NLE_REPORT file.
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import readme_pairs as rp
+from conftest import ROOT, rel_l2
+from test_oracle_readme_pairs import TOL, oracle_run
+
+pytestmark = pytest.mark.gpu
+
+ENHANCE = os.path.join(ROOT, "nonlocal-image-edit_amd", "bin", "enhance")
+NAMES = [p[0] for p in rp.PAIRS]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_hot_path_matches_oracle_on_readme_pair(nle, oracle, ctx, name):
+    pair = [p for p in rp.PAIRS if p[0] == name][0]
+    _, _, _, nr, nc, hx, hy, T, K, w = pair
+    o = oracle_run(oracle, name)
+    L = o["L"]
+    x = L.astype(np.float32)
+    f = nle.NLEFilter(ctx).train_filter(x, nr, nc, hx, hy, T, K)
+    d = f.diag()
+    want_cuts = [c["kept"] for c in o["info"]]
+    print(f"{name}: HIP formulation {d['formulation']} chol(Ka) {d['chol_Ka']} chol(Wa) {d['chol_Wa']}; kept Ka/Wa/Q = "
+          f"{[d['r_Ka'], d['r_Wa'], d['r_Q']]} (oracle {want_cuts}), K' = {d['K']} (oracle {o['S'].size})")
+    assert d["formulation"] == nle.MODE_PHI_FREE          # integer-valued plane: the all-fp64 table form
+    assert d["p"] == o["info"][0]["n"]
+    assert [d["r_Ka"], d["r_Wa"], d["r_Q"]] == want_cuts
+    assert d["K"] == o["S"].size
+    ev = f.eigvals
+    assert rel_l2(ev, o["S"]) < 1e-6
+    wts = [float(v) for v in w]
+    Y = f.apply_layers(x, len(wts)).cpu().numpy().astype(np.float64)
+    Y_o = o["layers"]
+    errs = [rel_l2(Y[j], Y_o[j]) for j in range(len(wts))]
+    print(f"{name}: per-layer relative L2 vs oracle {['%.2e' % e for e in errs]}, eigenvalues {rel_l2(ev, o['S']):.2e}")
+    assert max(errs) < 1e-4, errs
+    y = f.apply(x, nle.transform_eigenvalues(ev, wts)).cpu().numpy().astype(np.float64).reshape(L.shape)
+    L_out = np.rint(np.clip(y, 0, 255)).astype(np.int64)
+    diff = np.abs(L_out - o["L_out"].astype(np.int64))
+    print(f"{name}: 8-bit plane vs oracle: {int((diff > 0).sum())} of {diff.size} pixels differ, max {int(diff.max())}")
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3        # rounding ties of .5 values only
+    f.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_enhance_cli_reproduces_readme_pair(oracle, tmp_path, name):
+    from PIL import Image
+    pair = [p for p in rp.PAIRS if p[0] == name][0]
+    src_p, want_p = rp.paths(pair)
+    out = tmp_path / (name + "-out.png")
+    rep = tmp_path / "report.json"
+    env = dict(os.environ, NLE_REPORT=str(rep))
+    r = subprocess.run([ENHANCE, src_p, str(out)] + rp.cli_args(pair), capture_output=True, text=True, timeout=600,
+                       env=env)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[:4] == ["Computing kernel", "Nystrom approximation", "Sinkhorn", "Orthogonalize"]  # src/filter.cpp:483-498
+    assert lines[-1] == "Done. Press any key in result window to exit."                              # src/enhance.cpp:45
+    got = np.asarray(Image.open(out).convert("RGB"))[..., ::-1]
+    want = np.asarray(Image.open(want_p).convert("RGB"))[..., ::-1]
+    assert got.shape == want.shape
+    L_got = oracle.bgr_to_lab8(got)[..., 0].astype(np.float64)
+    L_want = oracle.bgr_to_lab8(want)[..., 0].astype(np.float64)
+    err = np.abs(L_got - L_want)
+    o = oracle_run(oracle, name)
+    info = json.load(open(rep))
+    print(f"{name}: CLI vs author's output: mean |dL| = {err.mean():.3f} (oracle {o['mean']:.3f}), p99 = "
+          f"{np.percentile(err, 99):.1f} (oracle {o['p99']:.1f}); kept {[info['r_Ka'], info['r_Wa'], info['r_Q']]}, "
+          f"K' = {info['K']}")
+    mean_tol, p99_tol = TOL[name]
+    assert err.mean() < mean_tol and np.percentile(err, 99) <= p99_tol
+    assert abs(err.mean() - o["mean"]) < 0.05                   # and it is the oracle's answer, not merely a close one
+    assert [info["r_Ka"], info["r_Wa"], info["r_Q"]] == [c["kept"] for c in o["info"]]
+    assert info["K"] == o["S"].size
+    # the colour planes pass through unchanged (src/filter.cpp:431-440)
+    d_ab = np.abs(oracle.bgr_to_lab8(got)[..., 1:].astype(int) - oracle.bgr_to_lab8(want)[..., 1:].astype(int))
+    assert d_ab.mean() < 0.5
