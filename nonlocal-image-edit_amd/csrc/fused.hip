@@ -192,87 +192,94 @@ hipError_t sink_pass(hipStream_t s, int mode, const float* d_lum, GridSpec gs, c
 // ------------------------------------------------------------------ Sinkhorn update (p-, r-sized)
 // ---- the p-sized update between two passes
 // After the pass with scaling vector u (w = B u):  y_a = 1 or recip(V_A[a] . u) for the p sample pixels
-// (exact fp64 rows, :275 top block), t = B^T z + V_A^T y_A, u' = lambda o t, w' = B u'.  The passes only
-// need w and s_A = V_A u (the samples' row sums), so u is eliminated:
-//     [w'; s_A'] = Mu [z; y_A],   Mu = [B; V_A] diag(lambda) [B; V_A]^T   (2p x 2p, built once per training)
-// -- one matrix-vector product whose outputs are independent, spread over ceil(2p / 8) workgroups.
-// Ka (optional): K_A itself when the factor is exact for it (Cholesky form, full rank): then the projector blocks are
-// the identity and the lower right block is K_A, written as such instead of as rounded products of the factor
-// (L^-T L^T differs from I by cond(L) eps, noise that near-singular K_A amplifies into the eigenvalues).
-__global__ __launch_bounds__(256) void k_update_matrix(int p, int r, const double* __restrict__ Bm,
-                                                       const double* __restrict__ VA, const double* __restrict__ lam,
-                                                       const double* __restrict__ Ka, double* __restrict__ Mu) {
-    const int n2 = 2 * p;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)n2 * n2) return;
-    const int i = (int)(idx / n2), j = (int)(idx % n2);
-    if (Ka != nullptr && (i >= p || j >= p)) {
-        Mu[idx] = (i >= p && j >= p) ? Ka[(size_t)(j - p) * p + (i - p)] : ((i % p) == (j % p) ? 1.0 : 0.0);
-        return;
-    }
-    const double* xi = (i < p) ? Bm + i : VA + (i - p);
-    const double* xj = (j < p) ? Bm + j : VA + (j - p);
-    double s0 = 0.0, s1 = 0.0;
-    int k = 0;
-    for (; k + 1 < r; k += 2) {
-        s0 += xi[(size_t)k * p] * lam[k] * xj[(size_t)k * p];
-        s1 += xi[(size_t)(k + 1) * p] * lam[k + 1] * xj[(size_t)(k + 1) * p];
-    }
-    if (k < r) s0 += xi[(size_t)k * p] * lam[k] * xj[(size_t)k * p];
-    Mu[idx] = s0 + s1;
-}
-
-hipError_t update_matrix(hipStream_t s, int p, int r, const double* d_B, const double* d_VA, const double* d_lam,
-                         const double* d_Ka, double* d_Mu) {
-    const long long n = 4ll * p * p;
-    hipLaunchKernelGGL(k_update_matrix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, r, d_B, d_VA, d_lam, d_Ka,
-                       d_Mu);
-    return hipGetLastError();
-}
-
+// (exact fp64 rows, :275 top block), then, in the reference's own order of operations (:239,243),
+//     t = B^T z + V_A^T y_A,   u' = lambda o t,   w' = B u',   s_A' = V_A u'
+// (the passes only need w and the samples' row sums s_A).  The products stay FACTORED: two dependent
+// matrix-vector launches, stage A (r outputs) and stage B (2p outputs).  Round 1 folded them into one matrix
+// Mu = [B; V_A] diag(lambda) [B; V_A]^T; its upper left block is pinv(K_A) written out, entries ~1/lambda_min, and the
+// rounding of those entries (eps / lambda_min, unstructured) is not damped by the k_i . v_small <= sqrt(lambda)
+// factor that damps the rounding of the factored form.  On the README images, where lambda_min sits at the 1e-10
+// cut, that cost 1e-4 ... 1e-3 per layer and flipped a rank decision; the factored form agrees with the oracle to
+// 1e-7 there (tests/test_readme_pairs_gpu.py).
+//   X1: 2p x r column-major (column k contiguous): [B; V_A]
+//   X2: 2p x r row-major    (row o contiguous):    [B; V_A]
+// Cholesky form (K_A full rank, V_A := L, B := L^-T, lambda := 1, r == p): the projector blocks are the identity and
+// V_A diag(lambda) V_A^T is K_A exactly, used as such: X1 = [L^-T; 0], u' = L^-1 z, w' = L^-T u' + y_A,
+// s_A' = z + K_A y_A -- the lower half of X2 then holds the rows of K_A and is contracted with y_A.
+//
+// stage A: v = [z; y_A] (every workgroup builds it in LDS; workgroup 0 also stores it), u'_k = lambda_k X1[:,k] . v
 // z: zrows slices of stride zld (summed here in a fixed order); sA_cur: s_A of the scaling the pass used
 // (ignored by the column-sum pass, where y_A = 1)
-__global__ __launch_bounds__(256) void k_sink_update(int mode, int p, const double* __restrict__ Mu,
-                                                     const double* __restrict__ z, int zrows, int zld,
-                                                     const double* __restrict__ sA_cur, double eps,
-                                                     double* __restrict__ sA_next, double* __restrict__ w_next) {
+__global__ __launch_bounds__(256) void k_sink_update_a(int mode, int p, int r, const double* __restrict__ X1,
+                                                       const double* __restrict__ lam, const double* __restrict__ z,
+                                                       int zrows, int zld, const double* __restrict__ sA_cur, double eps,
+                                                       double* __restrict__ v_out, double* __restrict__ u_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* v = reinterpret_cast<double*>(smem_raw);  // [2p] = [z; y_A]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n2 = 2 * p;
     for (int a = tid; a < p; a += 256) {
         double t = 0.0;
         for (int q = 0; q < zrows; ++q) t += z[(size_t)q * zld + a];
+        const double ya = (mode == ROWPASS_COLSUM) ? 1.0 : recip_or_zero_d(sA_cur[a], eps);
         v[a] = t;
-        v[p + a] = (mode == ROWPASS_COLSUM) ? 1.0 : recip_or_zero_d(sA_cur[a], eps);
+        v[p + a] = ya;
+        if (blockIdx.x == 0) {
+            v_out[a] = t;
+            v_out[p + a] = ya;
+        }
     }
     __syncthreads();
+    const int k = blockIdx.x * 4 + wave;
+    if (k >= r) return;  // wave-uniform
+    const double* col = X1 + (size_t)k * n2;
+    double s0 = 0.0, s1 = 0.0;
+    int i = lane;
+    for (; i + 64 < n2; i += 128) {
+        s0 += col[i] * v[i];
+        s1 += col[i + 64] * v[i + 64];
+    }
+    if (i < n2) s0 += col[i] * v[i];
+    double sum = s0 + s1;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int o = (blockIdx.x * 4 + wave) * 2 + j;
-        if (o >= n2) break;  // wave-uniform
-        const double* row = Mu + (size_t)o * n2;
-        double s0 = 0.0, s1 = 0.0;
-        int i = lane;
-        for (; i + 64 < n2; i += 128) {
-            s0 += row[i] * v[i];
-            s1 += row[i + 64] * v[i + 64];
-        }
-        if (i < n2) s0 += row[i] * v[i];
-        double sum = s0 + s1;
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) u_out[k] = lam[k] * sum;
+}
+
+// stage B: w'_o = X2[o,:] . u' (+ y_A[o] in the Cholesky form);  s_A'_a = X2[p+a,:] . u'  or  z_a + K_A[a,:] . y_A
+__global__ __launch_bounds__(256) void k_sink_update_b(int p, int r, int chol, const double* __restrict__ X2,
+                                                       const double* __restrict__ u, const double* __restrict__ v,
+                                                       double* __restrict__ sA_next, double* __restrict__ w_next) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int o = blockIdx.x * 4 + wave;
+    if (o >= 2 * p) return;  // wave-uniform
+    const bool exact = chol != 0 && o >= p;  // contract the row of K_A with y_A
+    const double* row = X2 + (size_t)o * r;
+    const double* x = exact ? v + p : u;
+    double s0 = 0.0, s1 = 0.0;
+    int i = lane;
+    for (; i + 64 < r; i += 128) {
+        s0 += row[i] * x[i];
+        s1 += row[i + 64] * x[i + 64];
+    }
+    if (i < r) s0 += row[i] * x[i];
+    double sum = s0 + s1;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-        if (lane == 0) {
-            if (o < p) w_next[o] = sum;
-            else sA_next[o - p] = sum;
-        }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) {
+        if (o < p) w_next[o] = chol ? sum + v[p + o] : sum;
+        else sA_next[o - p] = chol ? v[o - p] + sum : sum;
     }
 }
 
-hipError_t sink_update(hipStream_t s, int mode, int p, const double* d_Mu, const double* d_z, int zrows, int zld,
-                       const double* d_sA_cur, double eps, double* d_sA_next, double* d_w_next) {
+// d_v: 2p doubles, d_u: r doubles of scratch
+hipError_t sink_update(hipStream_t s, int mode, int p, int r, bool chol, const double* d_X1, const double* d_X2,
+                       const double* d_lam, const double* d_z, int zrows, int zld, const double* d_sA_cur, double eps,
+                       double* d_v, double* d_u, double* d_sA_next, double* d_w_next) {
     const size_t shm = (size_t)2 * p * sizeof(double);
-    hipLaunchKernelGGL(k_sink_update, dim3((unsigned)((2 * p + 7) / 8)), dim3(256), shm, s, mode, p, d_Mu, d_z, zrows,
-                       zld, d_sA_cur, eps, d_sA_next, d_w_next);
+    hipLaunchKernelGGL(k_sink_update_a, dim3((unsigned)((r + 3) / 4)), dim3(256), shm, s, mode, p, r, d_X1, d_lam, d_z,
+                       zrows, zld, d_sA_cur, eps, d_v, d_u);
+    hipLaunchKernelGGL(k_sink_update_b, dim3((unsigned)((2 * p + 3) / 4)), dim3(256), 0, s, p, r, chol ? 1 : 0, d_X2, d_u,
+                       d_v, d_sA_next, d_w_next);
     return hipGetLastError();
 }
 

@@ -100,12 +100,12 @@ int sink_pass_max_p();
 hipError_t sink_pass(hipStream_t s, int mode, const float* d_lum, GridSpec gs, const Sample4* d_samples,
                      int p, const double* d_w, float nsw, float npw, long long pix0, long long M, double eps,
                      double* d_ybuf, double* d_partial);
-// p-sized update between passes: [w'; s_A'] = Mu [z; y_A], see fused.hip
-// d_z: zrows x zld partial column sums, added in row order
-hipError_t update_matrix(hipStream_t s, int p, int r, const double* d_B, const double* d_VA, const double* d_lam,
-                         const double* d_Ka /* or null */, double* d_Mu);
-hipError_t sink_update(hipStream_t s, int mode, int p, const double* d_Mu, const double* d_z, int zrows, int zld,
-                       const double* d_sA_cur, double eps, double* d_sA_next, double* d_w_next);
+// p-sized update between passes in factored form: u' = lambda o (X1^T [z; y_A]), [w'; s_A'] = X2 u' (see fused.hip)
+// d_z: zrows x zld partial column sums, added in row order; d_X1: 2p x r column-major, d_X2: 2p x r row-major;
+// d_v (2p) and d_u (r): scratch
+hipError_t sink_update(hipStream_t s, int mode, int p, int r, bool chol, const double* d_X1, const double* d_X2,
+                       const double* d_lam, const double* d_z, int zrows, int zld, const double* d_sA_cur, double eps,
+                       double* d_v, double* d_u, double* d_sA_next, double* d_w_next);
 // Gk = sum over non-sample local pixels of c_i^2 k_i k_i^T on the fp64 MFMA; upper-triangular
 // 16x16 tiles (row-major 256 doubles each), p <= 256.
 constexpr int kG64TilesPerWave = 23;

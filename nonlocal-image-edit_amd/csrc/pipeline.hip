@@ -957,7 +957,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     HIP_OK(hipMemsetAsync(d_samples.p, 0, P64 * sizeof(float4), c->stream));
     HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), p * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     constexpr int kZS = 8;  // slices of the block partials, summed by k_sink_update
-    DevBuf<double> d_z((size_t)kZS * P64), d_w(P64), d_sAh((size_t)2 * T * p), d_Mu((size_t)4 * p * p),
+    DevBuf<double> d_z((size_t)kZS * P64), d_w(P64), d_sAh((size_t)2 * T * p), d_X1, d_X2, d_lam, d_uv((size_t)3 * p),
         d_partial((size_t)nlek::sink_pass_rows(std::max<long long>(M, 1)) * P64);
     DevBuf<double> d_cbuf((size_t)std::max<long long>(M, 1));
     // quantised luminance + Cartesian sample grid: table look-ups replace the exponentials (fused.hip)
@@ -1003,31 +1003,45 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         }
     };
     const int zrows = hist_tiled ? 1 : kZS;
-    auto pass_update = [&](int n, int mode) {  // the p-sized half: all-reduce, then [w; s_A] = Mu [z; y_A]
+    int r = 0;
+    bool chol = false;
+    auto pass_update = [&](int n, int mode) {  // the p-sized half: all-reduce, then the factored update (fused.hip)
         all_reduce(c, d_z.p, (size_t)zrows * P64);
         PROFILED(c, NLE_K_SMALL,
-                 nlek::sink_update(c->stream, mode, p, d_Mu.p, d_z.p, zrows, P64,
-                                   n > 0 ? d_sAh.p + (size_t)(n - 1) * p : nullptr, NLE_EPS, d_sAh.p + (size_t)n * p,
-                                   d_w.p));
+                 nlek::sink_update(c->stream, mode, p, r, chol, d_X1.p, d_X2.p, d_lam.p, d_z.p, zrows, P64,
+                                   n > 0 ? d_sAh.p + (size_t)(n - 1) * p : nullptr, NLE_EPS, d_uv.p, d_uv.p + 2 * p,
+                                   d_sAh.p + (size_t)n * p, d_w.p));
     };
     pass_pixels(nlek::ROWPASS_COLSUM, nullptr);
-    // factor Ka on the host while the column-sum pass runs, then build the update matrix
+    // factor Ka on the host while the column-sum pass runs, then upload the factors of the update
     const Nystrom ny = solve();
-    const int r = ny.r;
+    r = ny.r;
+    chol = ny.chol;
     f->r = r;
     f->chol_ka = ny.chol ? 1 : 0;
     f->formulation = hist ? NLE_MODE_PHI_FREE : NLE_MODE_PHI_FREE_EXP;
     {
-        DevBuf<double> d_B(ny.B.size()), d_VA(ny.VA.size()), d_lam(r), d_Ka;
-        HIP_OK(hipMemcpyAsync(d_B.p, ny.B.data(), ny.B.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(d_VA.p, ny.VA.data(), ny.VA.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        // X1 (2p x r column-major) and X2 (2p x r row-major) = [B; V_A]; Cholesky form: X1 = [L^-T; 0], the lower
+        // half of X2 = the rows of Ka (exact projector / exact V_A diag(lambda) V_A^T, see k_sink_update_b)
+        const size_t n2 = (size_t)2 * p;
+        std::vector<double> X1(n2 * r, 0.0), X2(n2 * r);
+        for (int k = 0; k < r; ++k)
+            for (int a = 0; a < p; ++a) {
+                const double b = ny.B[(size_t)k * p + a];
+                const double va = ny.chol ? ny.Ka[(size_t)k * p + a] : ny.VA[(size_t)k * p + a];  // Ka symmetric
+                X1[(size_t)k * n2 + a] = b;
+                if (!ny.chol) X1[(size_t)k * n2 + p + a] = va;
+                X2[(size_t)a * r + k] = b;
+                X2[(size_t)(p + a) * r + k] = va;
+            }
+        d_X1.alloc(X1.size());
+        d_X2.alloc(X2.size());
+        d_lam.alloc(r);
+        HIP_OK(hipMemcpyAsync(d_X1.p, X1.data(), X1.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_X2.p, X2.data(), X2.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        if (ny.chol) {  // full rank: the projector is I and V_A diag(lambda) V_A^T is Ka, exactly
-            d_Ka.alloc(ny.Ka.size());
-            HIP_OK(hipMemcpyAsync(d_Ka.p, ny.Ka.data(), ny.Ka.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        }
-        PROFILED(c, NLE_K_SMALL, nlek::update_matrix(c->stream, p, r, d_B.p, d_VA.p, d_lam.p, d_Ka.p, d_Mu.p));
-    }  // (the arena keeps the three buffers alive until the stream has used them: frees are stream-ordered)
+        HIP_OK(hipStreamSynchronize(c->stream));  // the staging vectors go out of scope (the column-sum pass is done by now)
+    }
     pass_update(0, nlek::ROWPASS_COLSUM);
     for (int n = 1; n < 2 * T; ++n) {
         pass_pixels(nlek::ROWPASS_RECIP, n == 2 * T - 1 ? d_cbuf.p : nullptr);
