@@ -14,6 +14,12 @@ N > 1: the SAME image is sharded by image-row slabs over the ranks (strong scali
 exchange steps are the small fp64 all-reduces of the Sinkhorn column sums, the Gram partials and
 V^T x (torch.distributed "nccl" == RCCL over xGMI).
 
+`value` is the HBM-resident figure (the bench contract: inputs already in HBM when the timed region starts).
+SURVEY.md section 8d's own metric -- wall time from the fp32 plane in HOST memory to the L per-layer planes back in
+HOST memory: H2D + train + apply + D2H, median of >= 5 runs after 2 warm-ups -- is measured in the same run and
+reported beside it as `host_to_host` (nle_train_host + nle_apply_layers_host on page-locked buffers; one upload, the
+download of a finished layer overlapped with the next one's kernels).
+
 The JSON line also carries
   roofline      the dominant kernel of the timed region: algorithmic bytes (or flops) per launch
                 divided by its average launch duration, measured with HIP events recorded on the
@@ -134,6 +140,7 @@ def main():
                          "meaningless, the per-rank compute time at 1/W of the rows is not)")
     ap.add_argument("--inflight", type=int, default=1, help="images in flight on one GPU (throughput mode, opt-in)")
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 materialised Phi, 2 Phi-free (NLE_MODE_*)")
+    ap.add_argument("--h2h-runs", type=int, default=7, help="host-to-host (section 8d) runs after 2 warm-ups; 0 skips")
     ap.add_argument("--cpu-sample", type=int, default=768, help="side of the CPU-baseline sample image")
     ap.add_argument("--cpu-threads", type=int, default=16, help="BLAS threads for the CPU baseline (<= visible cores)")
     args = ap.parse_args()
@@ -241,6 +248,32 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = (H * W / 1e6) / (elapsed / args.steps)
 
+    # ---- SURVEY.md section 8d's metric: host plane -> host layers, median of >= 5 runs after 2 warm-ups (N = 1)
+    h2h = None
+    if world == 1 and args.simulate_world <= 1 and args.h2h_runs > 0:
+        h_lum = ctx.host_alloc((H, W))
+        h_lum[...] = synth.synthetic_luminance(H, W).astype(np.float32)
+        h_out = ctx.host_alloc((L, H * W))
+        f2 = nle.NLEFilter(ctx)
+        ts = []
+        for it in range(2 + args.h2h_runs):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            f2.train_filter_host(h_lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"])
+            f2.apply_layers_host(None, L, h_out)          # returns when the last layer is in host memory
+            ts.append(time.perf_counter() - t1)
+        ts = ts[2:]
+        ref = out.cpu().numpy()
+        same = bool(np.array_equal(ref, h_out)) or float(np.abs(ref - h_out).max() / max(np.abs(ref).max(), 1e-30))
+        med = float(np.median(ts))
+        h2h = {"value": (H * W / 1e6) / med, "unit": "MP/s", "ms_median": med * 1e3, "ms_min": min(ts) * 1e3,
+               "ms_max": max(ts) * 1e3, "runs": len(ts), "warmup": 2,
+               "bytes_h2d": int(h_lum.nbytes), "bytes_d2h": int(h_out.nbytes),
+               "what": "SURVEY.md section 8d: fp32 plane in page-locked host memory -> train -> L per-layer planes back in "
+                       "page-locked host memory, one image at a time (nle_train_host + nle_apply_layers_host)",
+               "matches_device_resident_output": same}
+        f2.close()
+
     # ---- roofline of the dominant kernel (this rank's launches)
     ran = {k for k, v in stats.items() if v[0] > 0}
     form = "materialised" if "nystrom_extend" in ran else ("phi_free_tables" if "gram_gemm" in ran else "phi_free_exp")
@@ -335,6 +368,7 @@ def main():
                        "formulation": form + (" (V implicit, apply in sample space)" if lazy else ""),
                        "storage": ("fp64 tables, histograms, reductions and MFMA; fp32 output planes; V implicit" if lazy else
                                    "fp64 reductions and Gram/projection MFMA; fp32 affinities, V and outputs")},
+            "host_to_host": h2h,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": per_kernel,

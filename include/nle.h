@@ -61,6 +61,10 @@ int nle_ctx_trim(nle_ctx* ctx);
  * the ctx's device, synchronous with respect to the ctx's stream. */
 int nle_dev_alloc(nle_ctx* ctx, size_t bytes, void** d_ptr);
 void nle_dev_free(nle_ctx* ctx, void* d_ptr);
+/* page-locked host memory (hipHostMalloc): host buffers handed to the *_host entry points are copied at PCIe speed
+ * and asynchronously only when they are pinned */
+int nle_host_alloc(nle_ctx* ctx, size_t bytes, void** h_ptr);
+void nle_host_free(nle_ctx* ctx, void* h_ptr);
 int nle_dev_upload(nle_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 
@@ -193,7 +197,9 @@ int nle_apply(nle_filter* f, const float* d_x, int H, int W, const double* h_fS,
 /* the L per-layer outputs y_l = V ((lambda^l - lambda^(l+1)) o V^T x), base layer
  * lambda^(L-1) (src/filter.cpp:334-347); d_y: L x n_local fp32 (layer-major). */
 int nle_apply_layers(nle_filter* f, const float* d_x, int H, int W, int L, float* d_y);
-/* host-buffer forms */
+/* host-buffer forms.  h_x == NULL: filter the plane the filter was trained on (kept on the device by
+ * nle_train_host), which is what `enhance` does (src/enhance.cpp:43-44) -- one upload for train + apply.  Finished
+ * layers are copied back on a second stream while the next one is computed. */
 int nle_apply_host(nle_filter* f, const float* h_x, int H, int W, const double* h_fS,
                    float* h_y);
 int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, float* h_y);

@@ -36,6 +36,8 @@ _SIGNATURES = {
     "nle_ctx_trim": (C.c_int, [_P]),
     "nle_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "nle_dev_free": (None, [_P, _P]),
+    "nle_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "nle_host_free": (None, [_P, _P]),
     "nle_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "nle_dev_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "nle_ctx_set_mode": (C.c_int, [_P, C.c_int]),
@@ -206,6 +208,7 @@ class Context:
         self.device = int(device)
         torch.cuda.set_device(self.device)
         self._h = C.c_void_p()
+        self._pinned = []
         # A dedicated torch stream: its handle is never the null stream (a NULL stream argument means
         # "create your own" in the C ABI), torch collectives issued under it are ordered with the
         # kernels of the ctx, and `_sync_in` orders the ctx after whatever produced its inputs.
@@ -259,6 +262,15 @@ class Context:
         """0 auto, 1 materialised Phi, 2 Phi-free (NLE_MODE_* in include/nle.h)."""
         _check(lib().nle_ctx_set_mode(self._h, int(mode)), self._h)
 
+    def host_alloc(self, shape, dtype=np.float32):
+        """page-locked host array (nle_host_alloc); freed with the returned array's `.base.free()` or at ctx close"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = C.c_void_p()
+        _check(lib().nle_host_alloc(self._h, n, C.byref(ptr)), self._h)
+        buf = (C.c_char * max(n, 1)).from_address(ptr.value)
+        self._pinned.append(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
     def trim(self):
         """release the cached device workspace"""
         _check(lib().nle_ctx_trim(self._h), self._h)
@@ -280,6 +292,9 @@ class Context:
 
     def close(self):
         if self._h:
+            for ptr in self._pinned:
+                lib().nle_host_free(self._h, ptr)
+            self._pinned = []
             lib().nle_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -478,6 +493,29 @@ class NLEFilter:
                self.ctx._h)
         self.shape = (H, W)
         return self
+
+    def train_filter_host(self, lum, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter=10, n_eigen_vectors=5):
+        """nle_train_host: the H x W fp32 plane is a HOST array (pinned: Context.host_alloc); the filter keeps the
+        uploaded plane for apply_layers_host(None, ...)"""
+        self.close()
+        lum = np.ascontiguousarray(lum, dtype=np.float32)
+        H, W = lum.shape
+        _check(lib().nle_train_host(self.ctx._h, _np_ptr(lum), H, W, int(n_row_samples), int(n_col_samples), float(hx),
+                                    float(hy), int(n_sinkhorn_iter), int(n_eigen_vectors), C.byref(self._f)), self.ctx._h)
+        self.shape = (H, W)
+        return self
+
+    def apply_layers_host(self, x, n_layers, out):
+        """nle_apply_layers_host: x a HOST H x W fp32 array or None (= the training plane kept by
+        train_filter_host); out: HOST (L, n_local) fp32 array"""
+        H, W = self.shape
+        xp = None
+        if x is not None:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            xp = _np_ptr(x)
+        assert out.dtype == np.float32 and out.flags.c_contiguous
+        _check(lib().nle_apply_layers_host(self._f, xp, H, W, int(n_layers), _np_ptr(out)), self.ctx._h)
+        return out
 
     def info(self):
         n = C.c_longlong()

@@ -44,6 +44,8 @@ struct nle_ctx {
     size_t arena_bytes = 0;
     double* d_lut = nullptr;        // sRGB decode table of the colour wrapper
     std::set<nle_filter*> filters;  // live filters trained on this ctx (orphaned if the ctx dies first)
+    hipStream_t copy_stream = nullptr;  // device-to-host copies of finished output layers (host-buffer entry points)
+    hipEvent_t copy_ev[2] = {nullptr, nullptr};
     int mode = 0;  // nle_ctx_set_mode: 0 auto, 1 materialised Phi, 2 Phi-free, 3 Phi-free without look-up tables
     bool profiling = false;
     bool profile_all = false;  // level 2: also the small / second-stage kernels (each timed launch costs ~10 us of gaps)
@@ -75,6 +77,8 @@ struct nle_filter {
     nlek::GridSpec gs{};
     float nsw = 0.f, npw = 0.f;
     int ldd = 0, P64 = 0;
+    float* d_plane = nullptr;  // nle_train_host: the uploaded training plane (full image), kept for apply(h_x == NULL)
+    size_t plane_bytes = 0;
     float* d_lum = nullptr;  // this rank's slab of the training luminance
     double *d_c = nullptr, *d_er = nullptr, *d_ecT = nullptr, *d_Ep = nullptr, *d_D = nullptr, *d_Vrows = nullptr;
     float4* d_samples = nullptr;
@@ -1201,7 +1205,11 @@ void ensure_V(nle_filter* f) {
 
 // apply on the p-sized side of a lazy filter: reduce half (column sums m = sum_i k_i c_i x_i through the
 // tables), the p/K-sized middle (k_apply_small), and one table pass per output layer
-void apply_sample_space(nle_filter* f, const float* d_x, const double* h_g /* L x K */, int L, float* d_y) {
+// `done(l0, nl)`, when given, is called after layers [l0, l0 + nl) are complete on the stream (the host-buffer entry
+// points start their download there); `group` caps the layers per launch (0: as many as fit)
+using LayersDone = std::function<void(int, int)>;
+void apply_sample_space(nle_filter* f, const float* d_x, const double* h_g /* L x K */, int L, float* d_y,
+                        const LayersDone& done = nullptr, int group = 0) {
     nle_ctx* c = f->ctx;
     const long long M = f->n_local, pix0 = (long long)f->row0 * f->W;
     const int p = f->p, K = f->K, P64 = f->P64, nrows_local = (int)(M / f->W);
@@ -1222,15 +1230,23 @@ void apply_sample_space(nle_filter* f, const float* d_x, const double* h_g /* L 
                                                f->d_sample_pix, d_resp.p, d_t.p, d_Wp.p, d_YA.p));
     if (M > 0) {
         static const int emap[4] = {NLE_K_SINK_TABLES, NLE_K_APPLY_EXPAND, NLE_K_REDUCE, NLE_K_REDUCE};
-        const int lb = std::min(L, nlek::apply_layers_per_launch(f->gs));
+        int lb = std::min(L, nlek::apply_layers_per_launch(f->gs));
+        if (group > 0) lb = std::min(lb, group);
         DevBuf<double> d_gws((size_t)lb * nrows_local * 256 * f->gs.nSelCols);
         for (int l = 0; l < L; l += lb) {
-            ProfObserver obs(c, emap);
-            HIP_OK(nlek::apply_hist_layers(c->stream, lum, f->gs, p, f->row0, nrows_local, f->d_er, f->d_ecT, f->d_Ep,
-                                           d_Wp.p + (size_t)l * P64, P64, std::min(lb, L - l), f->d_c, d_gws.p,
-                                           d_y + (size_t)l * M, M, &obs));
+            const int nl = std::min(lb, L - l);
+            {
+                ProfObserver obs(c, emap);
+                HIP_OK(nlek::apply_hist_layers(c->stream, lum, f->gs, p, f->row0, nrows_local, f->d_er, f->d_ecT, f->d_Ep,
+                                               d_Wp.p + (size_t)l * P64, P64, nl, f->d_c, d_gws.p, d_y + (size_t)l * M, M,
+                                               &obs));
+            }
+            PROFILED(c, NLE_K_SMALL, nlek::scatter_samples(c->stream, p, nl, f->d_sample_loc, d_YA.p + (size_t)l * p,
+                                                           d_y + (size_t)l * M, M));
+            if (done) done(l, nl);
         }
-        PROFILED(c, NLE_K_SMALL, nlek::scatter_samples(c->stream, p, L, f->d_sample_loc, d_YA.p, d_y, M));
+    } else if (done) {
+        done(0, L);
     }
     HIP_OK(hipStreamSynchronize(c->stream));
     prof_flush(c);
@@ -1320,14 +1336,14 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
 
 // t = V^T x (all ranks), then Y[l] = V (g_l o t)
 void apply_impl(nle_filter* f, const float* d_x, int H, int W, const double* h_g /* L x K */, int L,
-                float* d_y) {
+                float* d_y, const LayersDone& done = nullptr, int group = 0) {
     nle_ctx* c = f->ctx;
     if ((long long)H * W != (long long)f->H * f->W)  // reference src/filter.cpp:447-449
         throw Fail{NLE_ERR_INVALID, "Number of values in channel must match that of training image."};
     if (L < 1 || L > 64) throw Fail{NLE_ERR_INVALID, "number of layers must be in [1, 64]"};
     HIP_OK(hipSetDevice(c->device));
     if (f->lazy && std::getenv("NLE_APPLY_WITH_V") == nullptr) {
-        apply_sample_space(f, d_x, h_g, L, d_y);
+        apply_sample_space(f, d_x, h_g, L, d_y, done, group);
         return;
     }
     ensure_V(f);
@@ -1348,6 +1364,7 @@ void apply_impl(nle_filter* f, const float* d_x, int H, int W, const double* h_g
     for (int l = 0; l < L; ++l)
         PROFILED(c, NLE_K_SMALL, nlek::scale_vec(c->stream, d_resp.p + (size_t)l * ld, d_t.p, ld, d_g.p + (size_t)l * ld));
     PROFILED(c, NLE_K_APPLY_EXPAND, nlek::apply_expand(c->stream, f->d_V, M, ld, d_g.p, L, d_y, M));
+    if (done) done(0, L);
     HIP_OK(hipStreamSynchronize(c->stream));
     prof_flush(c);
 }
@@ -1425,6 +1442,12 @@ void nle_ctx_destroy(nle_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto* f : ctx->filters) f->ctx = nullptr;  // their V is freed directly when they are destroyed
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
+    for (auto e : ctx->copy_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
     for (auto& kv : ctx->arena_free) (void)hipFree(kv.second);
     ctx->arena_free.clear();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1452,6 +1475,21 @@ void nle_dev_free(nle_ctx* ctx, void* d_ptr) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_ptr);
+}
+
+int nle_host_alloc(nle_ctx* ctx, size_t bytes, void** h_ptr) {
+    if (!ctx || !h_ptr) return NLE_ERR_INVALID;
+    *h_ptr = nullptr;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        HIP_OK(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    });
+}
+
+void nle_host_free(nle_ctx* ctx, void* h_ptr) {
+    if (!ctx || !h_ptr) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipHostFree(h_ptr);
 }
 
 int nle_dev_upload(nle_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
@@ -1757,7 +1795,10 @@ int nle_train_host(nle_ctx* ctx, const float* h_lum, int H, int W, int n_row_sam
         HIP_OK(hipSetDevice(ctx->device));
         DevBuf<float> d_lum((size_t)H * W);
         HIP_OK(hipMemcpyAsync(d_lum.p, h_lum, (size_t)H * W * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        *out = train_impl(ctx, d_lum.p, H, W, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter, n_eigen_vectors);
+        nle_filter* f = train_impl(ctx, d_lum.p, H, W, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter, n_eigen_vectors);
+        f->plane_bytes = d_lum.n * sizeof(float);  // kept: nle_apply*_host(h_x == NULL) filters the training plane
+        f->d_plane = d_lum.take();
+        *out = f;
     });
 }
 
@@ -1765,6 +1806,7 @@ void nle_filter_destroy(nle_filter* f) {
     if (!f) return;
     if (f->ctx) f->ctx->filters.erase(f);
     if (f->d_V) arena_release(f->ctx, f->d_V, f->v_bytes);  // back to the ctx's workspace cache (or hipFree)
+    if (f->d_plane) arena_release(f->ctx, f->d_plane, f->plane_bytes);
     for (auto& b : f->owned) arena_release(f->ctx, b.first, b.second);
     delete f;
 }
@@ -1889,21 +1931,43 @@ static void apply_host_common(nle_filter* f, const float* h_x, int H, int W, con
     nle_ctx* c = f->ctx;
     if ((long long)H * W != (long long)f->H * f->W)
         throw Fail{NLE_ERR_INVALID, "Number of values in channel must match that of training image."};
+    if (!h_x && !f->d_plane)
+        throw Fail{NLE_ERR_INVALID, "h_x == NULL needs a filter trained by nle_train_host (it keeps the training plane)"};
     HIP_OK(hipSetDevice(c->device));
-    DevBuf<float> d_x((size_t)H * W), d_y((size_t)L * std::max<long long>(f->n_local, 1));
-    HIP_OK(hipMemcpyAsync(d_x.p, h_x, (size_t)H * W * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    apply_impl(f, d_x.p, H, W, g, L, d_y.p);
-    HIP_OK(hipMemcpyAsync(h_y, d_y.p, (size_t)L * f->n_local * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    DevBuf<float> d_xbuf, d_y((size_t)L * std::max<long long>(f->n_local, 1));
+    const float* d_x = f->d_plane;
+    if (h_x) {
+        d_xbuf.alloc((size_t)H * W);
+        HIP_OK(hipMemcpyAsync(d_xbuf.p, h_x, (size_t)H * W * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        d_x = d_xbuf.p;
+    }
+    // each finished group of layers goes home on the copy stream while the next one is computed (the copies are only
+    // asynchronous when h_y is pinned: nle_host_alloc)
+    if (!c->copy_stream) {
+        HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (auto& e : c->copy_ev) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    int flip = 0;
+    const size_t n = (size_t)f->n_local;
+    apply_impl(f, d_x, H, W, g, L, d_y.p, [&](int l0, int nl) {
+        hipEvent_t ev = c->copy_ev[flip ^= 1];
+        HIP_OK(hipEventRecord(ev, c->stream));
+        HIP_OK(hipStreamWaitEvent(c->copy_stream, ev, 0));
+        HIP_OK(hipMemcpyAsync(h_y + (size_t)l0 * n, d_y.p + (size_t)l0 * n, (size_t)nl * n * sizeof(float),
+                              hipMemcpyDeviceToHost, c->copy_stream));
+    }, 1);
+    HIP_OK(hipStreamSynchronize(c->copy_stream));
+    // d_y returns to the ctx's cache: order its next use on the main stream behind the copies
     HIP_OK(hipStreamSynchronize(c->stream));
 }
 
 int nle_apply_host(nle_filter* f, const float* h_x, int H, int W, const double* h_fS, float* h_y) {
-    if (!f || !f->ctx || !h_x || !h_fS || !h_y) return NLE_ERR_INVALID;
+    if (!f || !f->ctx || !h_fS || !h_y) return NLE_ERR_INVALID;
     return guard(f->ctx, [&] { apply_host_common(f, h_x, H, W, h_fS, 1, h_y); });
 }
 
 int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, float* h_y) {
-    if (!f || !f->ctx || !h_x || !h_y || L < 1) return NLE_ERR_INVALID;
+    if (!f || !f->ctx || !h_y || L < 1) return NLE_ERR_INVALID;
     return guard(f->ctx, [&] {
         std::vector<double> resp((size_t)L * f->K);
         layer_resp(f->eigvals.data(), f->K, L, resp.data());

@@ -328,3 +328,34 @@ def test_large_sample_grids_on_the_table_path(nle, oracle, ctx, case):
         for j in range(L):
             assert rel_l2(Y[j], Y_o[j]) < PER_LAYER_TOL * slack, (m, j)
         f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pinned", [True, False])
+def test_host_buffer_entry_points_match_the_device_ones(nle, oracle, ctx, pinned):
+    """nle_train_host + nle_apply_layers_host (SURVEY.md section 8d's host plane -> host layers path): same numbers as
+    the device-pointer entry points, with x = NULL (the kept training plane) and with x passed again; per-layer
+    downloads run on the copy stream"""
+    H, W, nr, nc, hx, hy, T, K, L = 120, 160, 6, 8, 40.0, 30.0, 6, 12, 5
+    x = oracle.synthetic_luminance(H, W).astype(np.float32)
+    f_dev = nle.NLEFilter(ctx).train_filter(x, nr, nc, hx, hy, T, K)
+    Y_dev = f_dev.apply_layers(x, L).cpu().numpy()
+    if pinned:
+        h_x = ctx.host_alloc((H, W))
+        h_x[...] = x
+        h_y = ctx.host_alloc((L, H * W))
+    else:
+        h_x, h_y = x.copy(), np.empty((L, H * W), dtype=np.float32)
+    f = nle.NLEFilter(ctx).train_filter_host(h_x, nr, nc, hx, hy, T, K)
+    np.testing.assert_allclose(f.eigvals, f_dev.eigvals, rtol=1e-9)
+    h_y[...] = -1.0
+    f.apply_layers_host(None, L, h_y)
+    assert rel_l2(h_y, Y_dev) < 1e-6
+    h_y[...] = -1.0
+    f.apply_layers_host(h_x, L, h_y)
+    assert rel_l2(h_y, Y_dev) < 1e-6
+    # a filter trained from a device pointer keeps no plane: NULL is refused, loudly
+    with pytest.raises(nle.NLEError):
+        f_dev.apply_layers_host(None, L, h_y)
+    f.close()
+    f_dev.close()
