@@ -1250,7 +1250,7 @@ size_t hist_tiled_workspace_elems(GridSpec gs, int nrows_local) {
 hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec gs, int p, int ldp, int row0,
                            int nrows_local, const double* d_er, const double* d_ecT, const double* d_Ep,
                            const double* d_w, double eps, double* d_ybuf, double* d_ws, double* d_z,
-                           LaunchObserver* obs, const double* d_cvec, const float* d_xvec) {
+                           LaunchObserver* obs, const double* d_cvec, const float* d_xvec, const SortedRows* sorted) {
     const int nC = gs.nSelCols, nR = gs.nSelRows;
     if (nC > 36 || nR > 32) return hipErrorInvalidValue;
     struct Scope {
@@ -1268,7 +1268,12 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
         hipError_t eg = launch_hist_g(s, gs, p, nrows_local, d_er, d_Ep, d_w, d_g);
         if (eg != hipSuccess) return eg;
     }
-    {
+    if (sorted != nullptr) {
+        Scope sc(obs, SUB_HIST_PIX);
+        hipError_t ep = sorted_pass(s, mode, gs, row0, nrows_local, sorted->scol, sorted->desc, sorted->first, sorted->E, d_g,
+                                    eps, d_ybuf, d_h, d_cvec, d_xvec);
+        if (ep != hipSuccess) return ep;
+    } else {
         Scope sc(obs, SUB_HIST_PIX);
 #define NLE_HP(NCV)                                                                                                 \
     case NCV:                                                                                                       \
@@ -1632,7 +1637,7 @@ size_t ghist_workspace_elems(GridSpec gs, int nrows_local) {
 // d_ws: ghist_workspace_elems doubles; d_Gk: p x p doubles (full symmetric matrix of this rank's rows)
 hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
                      const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_c, double* d_ws,
-                     double* d_Gk, LaunchObserver* obs) {
+                     double* d_Gk, LaunchObserver* obs, const SortedRows* sorted) {
     const int nC = gs.nSelCols, nR = gs.nSelRows;
     if (nC > kGhistMaxCols) return hipErrorInvalidValue;
     const int NP = nC * (nC + 1) / 2;
@@ -1643,7 +1648,10 @@ hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int 
     double* d_C = d_EE + (size_t)nrows_local * ldm;
     hipError_t e;
     if (obs) obs->begin(SUB_GHIST_ROWS);
-    if (nC <= 11) {
+    if (sorted != nullptr && nC <= sorted_gram_max_cols()) {
+        e = sorted_gram_rows(s, gs, nrows_local, sorted->scol, sorted->desc, sorted->first, sorted->E, d_c, d_A);
+        if (e != hipSuccess) return e;
+    } else if (nC <= 11) {
         const size_t shm = (size_t)kLevels * NP * sizeof(double);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ghist_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm);

@@ -130,13 +130,33 @@ hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, i
                      int nrows_local, const double* d_er, const double* d_ecT, const double* d_Ep,
                      const double* d_w, double eps, double* d_ybuf, double* d_partial);
 
+// ---- level-sorted rows (sorted.hip): the pixel halves of the table passes without LDS atomics
+constexpr int kSortedThreads = 512;
+struct SortedRows {
+    const unsigned short* scol;   // [nrows][W]   columns of each row sorted by level (sample pixels left out)
+    const uint2* desc;            // [nrows][kSortedThreads] chunk of each pass thread
+    const unsigned short* first;  // [nrows][258] first chunk of each level; [257] tree steps
+    const double* E;              // [W + 1] exp(-d^2 / hx^2)
+};
+int sorted_max_width();
+int sorted_gram_max_cols();
+hipError_t dist_table(hipStream_t s, int W, double hx, double* d_E);
+hipError_t sort_rows(hipStream_t s, const float* d_lum, GridSpec gs, int row0, int nrows_local, unsigned short* d_scol,
+                     uint2* d_desc, unsigned short* d_first);
+hipError_t sorted_pass(hipStream_t s, int mode, GridSpec gs, int row0, int nrows_local, const unsigned short* d_scol,
+                       const uint2* d_desc, const unsigned short* d_first, const double* d_E, const double* d_g, double eps,
+                       double* d_ybuf, double* d_h, const double* d_cvec, const float* d_xvec);
+hipError_t sorted_gram_rows(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
+                            const unsigned short* d_first, const double* d_E, const double* d_cvec, double* d_Aout);
+
 // tiled form of sink_hist (three kernels, Ep read once per pass); writes the full column sums to d_z
 size_t hist_tiled_workspace_elems(GridSpec gs, int nrows_local);
 hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec gs, int p, int ldp, int row0,
                            int nrows_local, const double* d_er, const double* d_ecT, const double* d_Ep,
                            const double* d_w, double eps, double* d_ybuf, double* d_ws, double* d_z,
                            LaunchObserver* obs = nullptr, const double* d_cvec = nullptr,
-                           const float* d_xvec = nullptr);  // mode XVEC: y_i = cvec_i * xvec_i (apply, reduce half)
+                           const float* d_xvec = nullptr,   // mode XVEC: y_i = cvec_i * xvec_i (apply, reduce half)
+                           const SortedRows* sorted = nullptr);  // given: the pixel kernel runs on the level-sorted rows
 // sample-space apply (tables): expand half for one layer, the p/K-sized middle, and the sample-pixel outputs
 int apply_layers_per_launch(GridSpec gs);
 hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
@@ -154,7 +174,7 @@ int ghist_max_cols();
 size_t ghist_workspace_elems(GridSpec gs, int nrows_local);
 hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
                      const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_c, double* d_ws,
-                     double* d_Gk, LaunchObserver* obs = nullptr);
+                     double* d_Gk, LaunchObserver* obs = nullptr, const SortedRows* sorted = nullptr);
 
 // projection through the tables (quantised luminance): V = diag(c) K D, one workgroup per image row
 bool project_hist_ok(GridSpec gs, int p, int K);

@@ -83,6 +83,8 @@ struct nle_filter {
     double *d_c = nullptr, *d_er = nullptr, *d_ecT = nullptr, *d_Ep = nullptr, *d_D = nullptr, *d_Vrows = nullptr;
     float4* d_samples = nullptr;
     long long *d_sample_pix = nullptr, *d_sample_loc = nullptr;
+    bool has_sorted = false;  // level-sorted rows (sorted.hip) of the training plane, for the apply's reduce half
+    nlek::SortedRows sorted{};
     std::vector<std::pair<void*, size_t>> owned;  // workspace-cache buffers that live as long as the filter
     std::vector<double> h_Vrows;                  // p x K col-major: exact rows of V at the sample pixels
     std::vector<long long> h_sample_pix;
@@ -982,6 +984,23 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     const bool hist_tiled = hist && ss.gs.nSelCols <= 36 && ss.gs.nSelRows <= 32 && std::getenv("NLE_HIST_UNTILED") == nullptr;
     DevBuf<double> d_hws;
     if (hist_tiled) d_hws.alloc(nlek::hist_tiled_workspace_elems(ss.gs, nrows_local));
+    // level-sorted rows: the pixel halves of every table pass run without LDS atomics (sorted.hip); sorted once here
+    const bool sorted = hist_tiled && ss.gs.W <= nlek::sorted_max_width() && std::getenv("NLE_NO_SORTED_ROWS") == nullptr;
+    DevBuf<unsigned short> d_scol, d_first;
+    DevBuf<uint2> d_desc;
+    DevBuf<double> d_E;
+    nlek::SortedRows sr{};
+    if (sorted) {
+        d_scol.alloc((size_t)nrows_local * ss.gs.W);
+        d_first.alloc((size_t)nrows_local * 258);
+        d_desc.alloc((size_t)nrows_local * nlek::kSortedThreads);
+        d_E.alloc((size_t)ss.gs.W + 1);
+        PROFILED(c, NLE_K_SMALL, nlek::dist_table(c->stream, ss.gs.W, hx, d_E.p));
+        PROFILED(c, NLE_K_SMALL, nlek::sort_rows(c->stream, d_lum, ss.gs, row0, nrows_local, d_scol.p, d_desc.p, d_first.p));
+        HIP_OK(hipMemsetAsync(d_cbuf.p, 0, d_cbuf.n * sizeof(double), c->stream));  // sample pixels are never visited
+        sr = nlek::SortedRows{d_scol.p, d_desc.p, d_first.p, d_E.p};
+    }
+    const nlek::SortedRows* srp = sorted ? &sr : nullptr;
     const int nrows = hist ? nrows_local : nlek::sink_pass_rows(std::max<long long>(M, 1));
     tr.mark("ss: alloc+upload");
     // pass n uses the scaling whose sample row sums are sAh[n-1] (and w) and produces sAh[n]; pass 0 is the
@@ -992,7 +1011,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
             static const int kmap[4] = {NLE_K_SINK_TABLES, NLE_K_SINKHORN_PASS, NLE_K_REDUCE, NLE_K_REDUCE};
             ProfObserver obs(c, kmap);
             HIP_OK(nlek::sink_hist_tiled(c->stream, mode, d_lum, ss.gs, p, P64, row0, nrows_local, d_er.p, d_ecT.p,
-                                         d_Ep.p, d_w.p, NLE_EPS, ybuf, d_hws.p, d_z.p, &obs));
+                                         d_Ep.p, d_w.p, NLE_EPS, ybuf, d_hws.p, d_z.p, &obs, nullptr, nullptr, srp));
         } else if (M > 0) {
             if (hist)
                 PROFILED(c, NLE_K_SINKHORN_PASS, nlek::sink_hist(c->stream, mode, d_lum, ss.gs, p, P64, row0, nrows_local,
@@ -1080,7 +1099,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         static const int gmap[4] = {NLE_K_GRAM_ROWS, NLE_K_SMALL, NLE_K_GRAM_GEMM, NLE_K_SMALL};
         ProfObserver obs(c, gmap);
         HIP_OK(nlek::gram_hist(c->stream, d_lum, ss.gs, p, row0, nrows_local, d_er.p, d_ecT.p, d_Ep.p, d_cbuf.p,
-                               d_gpart.p, d_tiles.p, &obs));
+                               d_gpart.p, d_tiles.p, &obs, srp));
     } else {
         d_gpart.alloc(std::max<size_t>(nlek::gram64_partial_elems(M, p), 1));
         PROFILED(c, NLE_K_GRAM, nlek::gram64(c->stream, d_lum, ss.gs, d_samples.p, p, nsw, npw, pix0, M, d_cbuf.p,
@@ -1162,6 +1181,10 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         f->d_samples = own(d_samples);
         f->d_sample_pix = own(d_spix);
         f->d_sample_loc = own(d_sloc);
+        if (sorted) {
+            f->has_sorted = true;
+            f->sorted = nlek::SortedRows{own(d_scol), own(d_desc), own(d_first), own(d_E)};
+        }
         f->h_Vrows = o.Vrows;
         f->h_sample_pix = ss.pix;
         tm_p.stop();
@@ -1221,7 +1244,8 @@ void apply_sample_space(nle_filter* f, const float* d_x, const double* h_g /* L 
         static const int rmap[4] = {NLE_K_SINK_TABLES, NLE_K_APPLY_REDUCE, NLE_K_REDUCE, NLE_K_REDUCE};
         ProfObserver obs(c, rmap);
         HIP_OK(nlek::sink_hist_tiled(c->stream, nlek::ROWPASS_XVEC, lum, f->gs, p, P64, f->row0, nrows_local, f->d_er,
-                                     f->d_ecT, f->d_Ep, nullptr, NLE_EPS, nullptr, d_ws.p, d_m.p, &obs, f->d_c, d_x));
+                                     f->d_ecT, f->d_Ep, nullptr, NLE_EPS, nullptr, d_ws.p, d_m.p, &obs, f->d_c, d_x,
+                                     f->has_sorted ? &f->sorted : nullptr));
     } else {
         HIP_OK(hipMemsetAsync(d_m.p, 0, P64 * sizeof(double), c->stream));
     }

@@ -6,6 +6,8 @@ Tolerances (fp32 storage on the device, fp64 in the oracle):
   * kernels checked in isolation against fp64 numpy on the SAME fp32 inputs: 1e-5 (fp32
     MFMA accumulation) or 1e-9 (fp64 reductions)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -359,3 +361,49 @@ def test_host_buffer_entry_points_match_the_device_ones(nle, oracle, ctx, pinned
         f_dev.apply_layers_host(None, L, h_y)
     f.close()
     f_dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["noise", "flat", "two-level", "tiny"])
+def test_level_sorted_rows_agree_with_the_histogram_kernels_and_are_bitwise_reproducible(nle, oracle, kind):
+    """sorted.hip (level-sorted rows, register accumulation, fixed combine tree) against the LDS-atomic histogram
+    kernels it replaces (NLE_NO_SORTED_ROWS=1), on images that stress the chunking: noise, one flat level (every
+    thread of a row on one level), a two-level checkerboard, and an image narrower than a workgroup.  The sorted form
+    has no atomics, so two runs must agree bit for bit."""
+    rng = np.random.default_rng(5)
+    if kind == "tiny":
+        H, W, nr, nc = 40, 37, 4, 5
+    else:
+        H, W, nr, nc = 150, 700, 6, 10
+    if kind == "noise" or kind == "tiny":
+        x = rng.integers(0, 256, (H, W)).astype(np.float32)
+    elif kind == "flat":
+        x = np.full((H, W), 97.0, dtype=np.float32)
+        x[::7, ::5] = 140.0          # a few other pixels so that Ka is not singular
+        x += rng.integers(0, 2, (H, W)).astype(np.float32) * (rng.random((H, W)) < 0.01)
+    else:
+        rr, cc = np.mgrid[0:H, 0:W]
+        x = np.where((rr + cc) & 1, 60.0, 200.0).astype(np.float32)
+        x[rng.random((H, W)) < 0.02] = 128.0
+    hx, hy, T, K, L = W / 3.0, 40.0, 5, 8, 3
+
+    def run():
+        c = nle.Context(0)
+        f = nle.NLEFilter(c).train_filter(x, nr, nc, hx, hy, T, K)
+        ev = f.eigvals.copy()
+        Y = f.apply_layers(x, L).cpu().numpy()
+        f.close()
+        c.close()
+        return ev, Y
+
+    ev1, Y1 = run()
+    ev2, Y2 = run()
+    assert np.array_equal(ev1, ev2) and np.array_equal(Y1, Y2)          # bitwise reproducible
+    os.environ["NLE_NO_SORTED_ROWS"] = "1"
+    try:
+        ev0, Y0 = run()
+    finally:
+        del os.environ["NLE_NO_SORTED_ROWS"]
+    assert rel_l2(ev1, ev0) < 1e-9
+    for j in range(L):
+        assert rel_l2(Y1[j], Y0[j]) < 1e-6, (kind, j)
