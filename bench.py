@@ -83,11 +83,14 @@ def roofline_models(info, L, form, grid, lazy=False):
             npair = nC * (nC + 1) / 2.0
             ldm = ((nR * (nR + 1) // 2) + 15) // 16 * 16
             m["sink_tables"] = ("hbm", tab, HBM_PEAK_GBS)                # g written
-            m["sinkhorn_pass"] = ("hbm", n * s + 2.0 * tab, HBM_PEAK_GBS)  # luminance + g in + h out
-            m["gram_rows"] = ("hbm", n * (s + 8.0) + rows * 256.0 * npair * 8.0, HBM_PEAK_GBS)
+            # level-sorted rows (sorted.hip): 2 B of sorted column index per pixel + the row's chunk table (512 x 8 B
+            # + 516 B) instead of 4 B of luminance
+            srt = n * 2.0 + rows * (512 * 8.0 + 516.0)
+            m["sinkhorn_pass"] = ("hbm", srt + 2.0 * tab, HBM_PEAK_GBS)  # sorted row + g in + h out
+            m["gram_rows"] = ("hbm", srt + n * 8.0 + rows * 256.0 * npair * 8.0, HBM_PEAK_GBS)
             m["gram_gemm"] = ("mfma", 2.0 * ldm * 256.0 * npair * rows, FP64_MFMA_PEAK_TF)
             if lazy:  # V stays implicit: apply runs on the tables too (bytes the two kernels really move)
-                m["apply_reduce"] = ("hbm", n * (s + 8.0 + s) + tab, HBM_PEAK_GBS)        # luminance, c, x in; h out
+                m["apply_reduce"] = ("hbm", srt + n * (8.0 + s) + tab, HBM_PEAK_GBS)      # sorted row, c, x in; h out
                 lb = max(1, min(L, 4, (144 * 1024) // (256 * (nC | 1) * 8)))             # layers per k_hist_dot launch
                 m["apply_expand"] = ("hbm", n * (s + 8.0) + lb * (tab + n * s), HBM_PEAK_GBS)  # luminance, c; per layer g in, y out
     return m
@@ -118,10 +121,10 @@ def kernel_symbols(form, lazy):
     if form == "phi_free_exp":
         sym.update({"sinkhorn_pass": ("k_sink_pass",), "gram": ("k_gram64",)})
     else:
-        sym.update({"sinkhorn_pass": ("k_hist_pix",), "sink_tables": ("k_hist_g",), "gram_rows": ("k_ghist_rows",),
-                    "gram_gemm": ("k_ghist_gemm",)})
-        if lazy:  # the apply's reduce half is k_hist_pix in its XVEC mode: same symbol as the Sinkhorn pass
-            sym.update({"apply_expand": ("k_hist_dot",), "apply_reduce": ("k_hist_pix",)})
+        sym.update({"sinkhorn_pass": ("k_sorted_pass", "k_hist_pix"), "sink_tables": ("k_hist_g",),
+                    "gram_rows": ("k_sorted_gram", "k_ghist_rows"), "gram_gemm": ("k_ghist_gemm",)})
+        if lazy:  # the apply's reduce half is the pass kernel in its XVEC mode: same symbol as the Sinkhorn pass
+            sym.update({"apply_expand": ("k_hist_dot",), "apply_reduce": ("k_sorted_pass", "k_hist_pix")})
     return sym
 
 
@@ -298,13 +301,13 @@ def main():
             if name == "sinkhorn_pass" and form != "materialised":
                 rec["hbm_equivalent_GBs"] = info["n_local"] * info["r"] * 4.0 / (avg_ms * 1e-3) / 1e9
             if form == "phi_free_tables" and name in ("sinkhorn_pass", "apply_reduce", "gram_rows"):
-                # what actually bounds the histogram kernels: LDS fp64 atomics (one per pixel and table column /
-                # column pair), against the chip's measured ds_add_f64 rate on this histogram shape
-                # (tools/micro/lds_atomic_bench.hip, profiles/r1_lds_atomic_micro.jsonl: random levels)
-                per_px = g["n_sel_cols"] if name != "gram_rows" else g["n_sel_cols"] * (g["n_sel_cols"] + 1) // 2
-                rate = info["n_local"] * per_px / (avg_ms * 1e-3)
-                rec["lds_atomics"] = {"achieved": rate, "measured_peak": LDS_F64_ATOMIC_PEAK, "unit": "lane-atomics/s",
-                                      "frac": rate / LDS_F64_ATOMIC_PEAK}
+                # what bounds the level-sorted pixel kernels: fp64 multiply-adds on the vector pipe (2 nC per pixel
+                # for a pass + the reciprocal, nC(nC+1)/2 + nC for the Gram) and nC LDS table reads per pixel
+                nc_ = g["n_sel_cols"]
+                fma = (2 * nc_ + 8) if name != "gram_rows" else (nc_ * (nc_ + 1) // 2 + nc_)
+                rec["valu_f64"] = {"achieved": 2.0 * fma * info["n_local"] / (avg_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TF,
+                                   "unit": "TFLOP/s (fp64 vector == matrix peak)",
+                                   "frac": 2.0 * fma * info["n_local"] / (avg_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF}
             rec["traffic"] = None
             for sym in kernel_symbols(form, lazy).get(name, ()):
                 hit = [v for k, v in traffic.items() if sym in k]
@@ -317,8 +320,8 @@ def main():
     roofline = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
                 "frac": d["frac"], "traffic": d.get("traffic"), "avg_launch_ms": d["avg_ms"],
                 "launches_per_step": d["launches_per_step"]}
-    if "lds_atomics" in d:
-        roofline["lds_atomics"] = d["lds_atomics"]
+    if "valu_f64" in d:
+        roofline["valu_f64"] = d["valu_f64"]
 
     # ---- CPU baseline: the fp64 numpy oracle on a bounded sample (rank 0, N = 1 only)
     cpu = None

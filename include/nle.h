@@ -68,9 +68,15 @@ void nle_host_free(nle_ctx* ctx, void* h_ptr);
 int nle_dev_upload(nle_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 
-/* Which formulation nle_train uses for the N-sized passes (results agree to rounding):
- *   NLE_MODE_AUTO          Phi-free when it applies (<= 256 samples, <= 128 eigenvectors, at least
- *                          64 pixels per sample), else materialised
+/* Which formulation nle_train uses for the N-sized passes:
+ *   NLE_MODE_AUTO          the table form of NLE_MODE_PHI_FREE when it applies (integer-valued luminance plane -- what the
+ *                          reference always feeds, the L channel of 8-bit Lab, src/filter.cpp:460-469 -- a sample grid of at
+ *                          most 32 x 36, <= 128 eigenvectors), else NLE_MODE_MATERIALISED_F64.  Both are fp64 from the
+ *                          affinities to the last reduction and meet the 1e-4 per-layer bar wherever the reference
+ *                          algorithm itself is well posed; nle_filter_diag reports which one ran.  The two fp32
+ *                          formulations below run only when asked for: they are the north star's literal kernels
+ *                          (fp32 MFMA GEMMs, HBM-streamed Sinkhorn) and can miss the bar on inputs whose detail layers
+ *                          are small differences (DESIGN.md "Numerics").
  *   NLE_MODE_MATERIALISED  Phi = K_AB^T V_A Lambda^-1 is written once (N x r fp32) and streamed
  *   NLE_MODE_PHI_FREE      every pass regenerates its affinity rows in registers; when the luminance
  *                          plane is integer valued in [0, 255] (the L channel of 8-bit Lab, what the
@@ -81,6 +87,9 @@ int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
 #define NLE_MODE_MATERIALISED 1
 #define NLE_MODE_PHI_FREE 2
 #define NLE_MODE_PHI_FREE_EXP 3
+/*   NLE_MODE_MATERIALISED_F64  the literal decomposition with Phi (N x r) and V (N x K') in fp64: fp64 affinities,
+ *                          fp64-MFMA products, any luminance, up to 2048 samples (Phi must fit in device memory) */
+#define NLE_MODE_MATERIALISED_F64 4
 int nle_ctx_set_mode(nle_ctx* ctx, int mode);
 
 /* Multi-GPU (one process per GPU).  Rank `rank` of `world` owns image rows
@@ -148,6 +157,17 @@ int nle_gram(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r, const
 /* per-row scalings c_i = recip(phi_i . h_u) (inplaceReciprocal, src/filter.cpp:42-54) */
 int nle_row_scalings(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r,
                      const double* h_u, double* d_out);
+
+/* The same stages on fp64 device matrices (row-per-pixel, leading dimension any value >= the logical width; outputs use
+ * nle_ld(width)), all products and sums in fp64: what include/nle/filter.hpp's free functions run on, so that the
+ * reference's unit tests (test/test_filter.cpp, tolerance 1e-10) hold at their own tolerance. */
+int nle_compute_kernel64(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples, int n_col_samples, double hx,
+                         double hy, double* h_Ka, double* d_kab);
+int nle_ts_gemm64(nle_ctx* ctx, const double* d_A, long long M, int lda, int kd, const double* h_B, int nc, double* d_C);
+int nle_sinkhorn_scalings64(nle_ctx* ctx, const double* d_phi, long long M, int ld, int r, const double* h_eigvals,
+                            int max_iter, double* h_u_c, double* h_u_r);
+int nle_gram64(nle_ctx* ctx, const double* d_phi, long long M, int ld, int r, const double* h_u, double* h_G);
+int nle_row_scalings64(nle_ctx* ctx, const double* d_phi, long long M, int ld, int r, const double* h_u, double* d_out);
 
 /* ---- the fused path ---------------------------------------------------------------- */
 /* NLEFilter::trainFilter, src/filter.cpp:480-502.  d_lum: FULL H x W fp32 luminance on the

@@ -55,6 +55,11 @@ _SIGNATURES = {
     "nle_sinkhorn_scalings": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     "nle_gram": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, _P]),
     "nle_row_scalings": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, _P]),
+    "nle_compute_kernel64": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P]),
+    "nle_ts_gemm64": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "nle_sinkhorn_scalings64": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
+    "nle_gram64": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, _P]),
+    "nle_row_scalings64": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, _P]),
     "nle_train": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
                             C.POINTER(_P)]),
     "nle_train_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
@@ -86,7 +91,7 @@ _SIGNATURES = {
     "nle_bench_sinkhorn_pass": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-MODE_AUTO, MODE_MATERIALISED, MODE_PHI_FREE, MODE_PHI_FREE_EXP = 0, 1, 2, 3   # NLE_MODE_* of include/nle.h
+MODE_AUTO, MODE_MATERIALISED, MODE_PHI_FREE, MODE_PHI_FREE_EXP, MODE_MATERIALISED_F64 = 0, 1, 2, 3, 4   # NLE_MODE_* of include/nle.h
 
 _lib = None
 

@@ -1,0 +1,344 @@
+// The literal decomposition of the hot path with every N-sized matrix in fp64 (gfx950).
+//
+// Why it exists.  The table formulation (fused.hip / sorted.hip) is all-fp64 but needs an integer-valued luminance plane
+// and a sample grid of at most 32 x 36; the fp32 formulations (kernels.hip: Phi, V and the affinities in fp32) miss the
+// 1e-4 per-layer bar on some well-posed inputs (profiles/r1_parity_fuzz.txt: detail layers that are small differences
+// 1 - lambda at spatial bandwidths of a few pixels).  This file is what auto mode falls back to for any other input
+// and what the stage-level API of include/nle/filter.hpp runs on, so that the reference's own unit tests
+// (test/test_filter.cpp, tolerance 1e-10) hold unchanged: same stages as the reference, same fp64 arithmetic,
+//   k_affinity64      src/filter.cpp:104-112,139-145   Kab(i,j) = exp(negativeWeightedDistance), libm exp
+//   k_tsgemm64        :275, :327, :250                  tall-skinny products on v_mfma_f64_16x16x4_f64
+//   k_rowpass64       :239,243 + :42-54, :456           phi (D (phi^T r)) with inplaceReciprocal, one pass; V^T x
+//   k_gram64d         :296                              Wab Wab^T (its N-sized part) on the fp64 MFMA
+//   k_apply_expand64  :456                              V (diag f) (V^T x), all layers in one pass
+// It is a fallback, sized for correctness first: operands come straight from global memory (L2), one wave per 16 x 16
+// output tile; N x r fp64 is 26.8 GB at cfg4, which 288 GB of HBM holds comfortably.
+#include "kernels.h"
+
+#include <algorithm>
+
+namespace nlek {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ double recip0_g(double s, double eps) {
+    return (fabs(s) >= eps) ? 1.0 / s : 0.0;  // inplaceReciprocal, src/filter.cpp:42-54
+}
+}  // namespace
+
+// ------------------------------------------------------------------ affinity rows, fp64
+// kab[i][s] = exp(-sw (dr^2 + dc^2) - pw (x_i - y_s)^2), natural pixel order, i in [pix0, pix0 + M); columns >= p zero
+__global__ __launch_bounds__(256) void k_affinity64(const float* __restrict__ lum, GridSpec gs,
+                                                    const Sample4* __restrict__ samples, int p, int ld, double sw,
+                                                    double pw, long long pix0, long long M, double* __restrict__ kab) {
+    const long long total = M * ld;
+    for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (long long)gridDim.x * blockDim.x) {
+        const long long il = f / ld;
+        const int s = (int)(f - il * ld);
+        double v = 0.0;
+        if (s < p) {
+            const long long gi = pix0 + il;
+            const int row = (int)(gi / gs.W), col = (int)(gi - (long long)row * gs.W);
+            const Sample4 sm = samples[s];
+            const long long dr = row - (int)sm.x, dc = col - (int)sm.y;  // integer spatial term (:109)
+            const double dv = (double)lum[gi] - (double)sm.z;
+            v = exp(-sw * (double)(dr * dr + dc * dc) - pw * (dv * dv));
+        }
+        kab[f] = v;
+    }
+}
+
+hipError_t affinity64(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples, int p, int ld, double sw,
+                      double pw, long long pix0, long long M, double* d_kab) {
+    if (M <= 0) return hipSuccess;
+    const long long nb = std::min<long long>((M * ld + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_affinity64, dim3((unsigned)nb), dim3(256), 0, s, d_lum, gs, d_samples, p, ld, sw, pw, pix0, M, d_kab);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ per-row scalings
+// out[i] = recip(X_i . u)  (one wave per row)
+__global__ __launch_bounds__(256) void k_row_scalings64(const double* __restrict__ X, long long M, int ld, int r,
+                                                        const double* __restrict__ u, double eps, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    for (long long i = wv; i < M; i += nw) {
+        double s = 0.0;
+        for (int j = lane; j < r; j += 64) s += X[(size_t)i * ld + j] * u[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) out[i] = recip0_g(s, eps);
+    }
+}
+
+hipError_t row_scalings64(hipStream_t s, const double* d_X, long long M, int ld, int r, const double* d_u, double eps,
+                          double* d_out) {
+    if (M <= 0) return hipSuccess;
+    const long long nb = std::min<long long>((M + 3) / 4, 8192);
+    hipLaunchKernelGGL(k_row_scalings64, dim3((unsigned)nb), dim3(256), 0, s, d_X, M, ld, r, d_u, eps, d_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ tall-skinny product on the fp64 MFMA
+// C (M x ldc, columns < nc) = diag(rs) A (M x lda, logical width kd) B (kd x nc, COLUMN-major, leading dimension kd)
+// rs: optional per-row scale (null: 1).  One wave per 16 rows x 16 columns; v_mfma_f64_16x16x4_f64: lane (l15, kq)
+// feeds A[row l15][k kq] and B[k kq][col l15] and receives rows kq + 4 e of column l15.
+__global__ __launch_bounds__(256) void k_tsgemm64(const double* __restrict__ A, long long M, int lda, int kd,
+                                                  const double* __restrict__ B, int nc, const double* __restrict__ rs,
+                                                  double* __restrict__ C, int ldc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int ctiles = (nc + 15) / 16;
+    const long long rtiles = (M + 15) / 16, ntiles = rtiles * ctiles;
+    for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += (long long)gridDim.x * 4) {
+        const long long rt = t / ctiles;
+        const int ct = (int)(t - rt * ctiles);
+        const long long arow = rt * 16 + l15;
+        const int bcol = ct * 16 + l15;
+        const bool aok = arow < M, bok = bcol < nc;
+        f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < kd; k0 += 4) {
+            const int k = k0 + kq;
+            const double a = (aok && k < kd) ? A[(size_t)arow * lda + k] : 0.0;
+            const double b = (bok && k < kd) ? B[(size_t)bcol * kd + k] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        if (bok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long long ro = rt * 16 + kq + 4 * e;
+                if (ro < M) C[(size_t)ro * ldc + bcol] = (rs ? rs[ro] : 1.0) * acc[e];
+            }
+        }
+    }
+}
+
+hipError_t ts_gemm64(hipStream_t s, const double* d_A, long long M, int lda, int kd, const double* d_B, int nc,
+                     const double* d_rs, double* d_C, int ldc) {
+    if (M <= 0 || nc <= 0) return hipSuccess;
+    const long long ntiles = ((M + 15) / 16) * ((nc + 15) / 16);
+    const long long nb = std::min<long long>((ntiles + 3) / 4, 65535);
+    hipLaunchKernelGGL(k_tsgemm64, dim3((unsigned)nb), dim3(256), 0, s, d_A, M, lda, kd, d_B, nc, d_rs, d_C, ldc);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ one pass over X (M x ld fp64)
+// partial[b][j] = sum over the rows of block b of X[i][j] y_i;  COLSUM: y = 1;  RECIP: y_i = recip(X_i . (lam o t_in));
+// XVEC: y_i = xvec[i].  One wave per row at a time; lane l owns columns l, l + 64, ... (<= kRp64Cols per lane).
+constexpr int kRp64Cols = 32;  // ld <= 2048
+
+template <int NCL>  // columns per lane: ld <= 64 NCL
+__global__ __launch_bounds__(256) void k_rowpass64(int mode, const double* __restrict__ X, long long M, int ld,
+                                                   const double* __restrict__ t_in, const double* __restrict__ lam,
+                                                   const float* __restrict__ xvec, double eps, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* sred = reinterpret_cast<double*>(smem_raw);  // [4][ld]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double u[NCL], acc[NCL];
+#pragma unroll
+    for (int k = 0; k < NCL; ++k) {
+        const int j = lane + 64 * k;
+        u[k] = (mode == ROWPASS_RECIP && j < ld) ? lam[j] * t_in[j] : 0.0;
+        acc[k] = 0.0;
+    }
+    const long long wv = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+    for (long long i = wv; i < M; i += nw) {
+        double v[NCL];
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NCL; ++k) {
+            const int j = lane + 64 * k;
+            v[k] = (j < ld) ? X[(size_t)i * ld + j] : 0.0;
+            s += v[k] * u[k];
+        }
+        double y = 1.0;
+        if (mode == ROWPASS_RECIP) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            y = recip0_g(s, eps);
+        } else if (mode == ROWPASS_XVEC) {
+            y = (double)xvec[i];
+        }
+#pragma unroll
+        for (int k = 0; k < NCL; ++k) acc[k] += v[k] * y;
+    }
+#pragma unroll
+    for (int k = 0; k < NCL; ++k) {
+        const int j = lane + 64 * k;
+        if (j < ld) sred[wave * ld + j] = acc[k];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < ld; j += 256)
+        partial[(size_t)blockIdx.x * ld + j] = (sred[j] + sred[ld + j]) + (sred[2 * ld + j] + sred[3 * ld + j]);
+}
+
+hipError_t rowpass64(hipStream_t s, int mode, const double* d_X, long long M, int ld, const double* d_t_in,
+                     const double* d_lam, const float* d_xvec, double eps, double* d_partial, int* nblocks) {
+    if (ld > 64 * kRp64Cols) return hipErrorInvalidValue;
+    long long nb = (M + 3) / 4;
+    nb = std::max<long long>(1, std::min<long long>(nb, kRowpassMaxBlocks));
+    *nblocks = (int)nb;
+    const size_t shm = (size_t)4 * ld * sizeof(double);
+#define NLE_RP64(NCLV)                                                                                                  \
+    {                                                                                                                   \
+        if (shm > 48 * 1024) {                                                                                          \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpass64<NCLV>),                       \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                  \
+            if (ea != hipSuccess) return ea;                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL((k_rowpass64<NCLV>), dim3((unsigned)nb), dim3(256), shm, s, mode, d_X, M, ld, d_t_in, d_lam,  \
+                           d_xvec, eps, d_partial);                                                                     \
+    }
+    if (ld <= 64) NLE_RP64(1)
+    else if (ld <= 128) NLE_RP64(2)
+    else if (ld <= 256) NLE_RP64(4)
+    else if (ld <= 512) NLE_RP64(8)
+    else if (ld <= 1024) NLE_RP64(16)
+    else NLE_RP64(32)
+#undef NLE_RP64
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ Gram on the fp64 MFMA
+// G (r x r, full, column-major == row-major: symmetric) = sum_i c_i^2 x_i x_i^T, c_i = cs[i] (null: 1).
+// grid (upper-triangular 16 x 16 tile pairs, row chunks); partial[chunk][r*r]; a second kernel sums the chunks in order
+// and mirrors the triangle.
+__global__ __launch_bounds__(256) void k_gram64d(const double* __restrict__ X, long long M, int ld, int r,
+                                                 const double* __restrict__ cs, long long rows_per_chunk,
+                                                 double* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int nt = (r + 15) / 16;
+    // tile pair index -> (ti <= tj)
+    int t = blockIdx.x * 4 + wave;
+    const int npairs = nt * (nt + 1) / 2;
+    if (t >= npairs) return;  // wave-uniform
+    int ti = 0;
+    while (t >= nt - ti) {
+        t -= nt - ti;
+        ++ti;
+    }
+    const int tj = ti + t;
+    const long long i0 = (long long)blockIdx.y * rows_per_chunk, i1 = min(M, i0 + rows_per_chunk);
+    const int ca = ti * 16 + l15, cb = tj * 16 + l15;
+    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (long long i = i0; i < i1; i += 4) {
+        const long long row = i + kq;
+        const bool ok = row < i1;
+        const double c = ok ? (cs ? cs[row] : 1.0) : 0.0;
+        const double a = (ok && ca < r) ? c * X[(size_t)row * ld + ca] : 0.0;
+        const double b = (ok && cb < r) ? c * X[(size_t)row * ld + cb] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    double* out = partial + (size_t)blockIdx.y * r * r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ra = ti * 16 + kq + 4 * e;
+        if (ra < r && cb < r) out[(size_t)cb * r + ra] = acc[e];  // entry (ra, cb), ra in tile ti, cb in tile tj
+    }
+}
+
+__global__ void k_gram64d_reduce(const double* __restrict__ partial, int nchunks, int r, double* __restrict__ G) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)r * r) return;
+    const int a = (int)(idx % r), b = (int)(idx / r);       // column-major (a, b)
+    const int ta = a / 16, tb = b / 16;
+    // the kernel above wrote entry (ra, cb) for tiles ti <= tj only: read the mirrored entry below the tile diagonal
+    const size_t src = (ta <= tb) ? (size_t)b * r + a : (size_t)a * r + b;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * r * r + src];
+    G[idx] = s;
+}
+
+long long gram64d_chunk_rows(long long M) {
+    long long rows = (M + 255) / 256;  // up to 256 chunks
+    rows = std::max<long long>(((rows + 3) / 4) * 4, 256);
+    return rows;
+}
+size_t gram64d_partial_elems(long long M, int r) {
+    const long long rows = gram64d_chunk_rows(M);
+    const long long nchunks = std::max<long long>(1, (M + rows - 1) / rows);
+    return (size_t)nchunks * r * r;
+}
+
+hipError_t gram64d(hipStream_t s, const double* d_X, long long M, int ld, int r, const double* d_cs, double* d_partial,
+                   double* d_G) {
+    const long long rows = gram64d_chunk_rows(M);
+    const int nchunks = (int)std::max<long long>(1, (M + rows - 1) / rows);
+    const int nt = (r + 15) / 16, npairs = nt * (nt + 1) / 2;
+    hipError_t e = hipMemsetAsync(d_partial, 0, (size_t)nchunks * r * r * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    if (M > 0)
+        hipLaunchKernelGGL(k_gram64d, dim3((unsigned)((npairs + 3) / 4), (unsigned)nchunks), dim3(256), 0, s, d_X, M, ld, r, d_cs,
+                           rows, d_partial);
+    hipLaunchKernelGGL(k_gram64d_reduce, dim3((unsigned)(((long long)r * r + 255) / 256)), dim3(256), 0, s, d_partial, nchunks, r,
+                       d_G);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ apply, expand half: Y[l][i] = V_i . g_l
+__global__ __launch_bounds__(256) void k_apply_expand64(const double* __restrict__ V, long long M, int ld, int K,
+                                                        const double* __restrict__ g, int L, float* __restrict__ Y,
+                                                        long long ystride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* sg = reinterpret_cast<double*>(smem_raw);  // [L][K]
+    for (int j = threadIdx.x; j < L * K; j += 256) sg[j] = g[(size_t)(j / K) * ld + (j % K)];
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M; i += (long long)gridDim.x * 256) {
+        const double* v = V + (size_t)i * ld;
+        for (int l = 0; l < L; ++l) {
+            double s0 = 0.0, s1 = 0.0;
+            int k = 0;
+            for (; k + 1 < K; k += 2) {
+                s0 += v[k] * sg[l * K + k];
+                s1 += v[k + 1] * sg[l * K + k + 1];
+            }
+            if (k < K) s0 += v[k] * sg[l * K + k];
+            Y[(size_t)l * ystride + i] = (float)(s0 + s1);
+        }
+    }
+}
+
+hipError_t apply_expand64(hipStream_t s, const double* d_V, long long M, int ld, int K, const double* d_g, int L, float* d_Y,
+                          long long ystride) {
+    if (M <= 0) return hipSuccess;
+    const size_t shm = (size_t)L * K * sizeof(double);
+    if (shm > 64 * 1024) return hipErrorInvalidValue;
+    if (shm > 48 * 1024) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply_expand64),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (ea != hipSuccess) return ea;
+    }
+    const long long nb = std::min<long long>((M + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_apply_expand64, dim3((unsigned)nb), dim3(256), shm, s, d_V, M, ld, K, d_g, L, d_Y, ystride);
+    return hipGetLastError();
+}
+
+// X[idx[k]][0..ld) = src[k][0..ld)
+__global__ void k_scatter_rows64(const double* __restrict__ src, const long long* __restrict__ idx, int n, int ld,
+                                 double* __restrict__ X, long long M) {
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= (long long)n * ld) return;
+    const int k = (int)(f / ld), j = (int)(f % ld);
+    const long long row = idx[k];
+    if (row >= 0 && row < M) X[(size_t)row * ld + j] = src[f];
+}
+
+hipError_t scatter_rows64(hipStream_t s, const double* d_src, const long long* d_idx, int n, int ld, double* d_X, long long M) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_rows64, dim3((unsigned)(((long long)n * ld + 255) / 256)), dim3(256), 0, s, d_src, d_idx, n, ld,
+                       d_X, M);
+    return hipGetLastError();
+}
+
+// out[i] = (float) X[i]  (nle_filter_eigvecs of an fp64 filter)
+__global__ void k_to_f32(const double* __restrict__ X, long long n, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = (float)X[i];
+}
+hipError_t to_f32(hipStream_t s, const double* d_X, long long n, float* d_out) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_to_f32, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, s, d_X, n, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace nlek

@@ -130,6 +130,25 @@ hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, i
                      int nrows_local, const double* d_er, const double* d_ecT, const double* d_Ep,
                      const double* d_w, double eps, double* d_ybuf, double* d_partial);
 
+// ---- the literal decomposition in fp64 (generic64.hip): auto mode's fallback and the stage-level API
+hipError_t affinity64(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples, int p, int ld, double sw,
+                      double pw, long long pix0, long long M, double* d_kab);
+hipError_t row_scalings64(hipStream_t s, const double* d_X, long long M, int ld, int r, const double* d_u, double eps,
+                          double* d_out);
+// C (M x ldc) = diag(rs) A (M x lda, width kd) B (kd x nc column-major on the DEVICE); rs may be null
+hipError_t ts_gemm64(hipStream_t s, const double* d_A, long long M, int lda, int kd, const double* d_B, int nc,
+                     const double* d_rs, double* d_C, int ldc);
+hipError_t rowpass64(hipStream_t s, int mode, const double* d_X, long long M, int ld, const double* d_t_in,
+                     const double* d_lam, const float* d_xvec, double eps, double* d_partial, int* nblocks);
+// G (r x r, full symmetric) = sum_i cs_i^2 x_i x_i^T (cs null: 1); d_partial: gram64d_partial_elems doubles
+size_t gram64d_partial_elems(long long M, int r);
+hipError_t gram64d(hipStream_t s, const double* d_X, long long M, int ld, int r, const double* d_cs, double* d_partial,
+                   double* d_G);
+hipError_t apply_expand64(hipStream_t s, const double* d_V, long long M, int ld, int K, const double* d_g, int L, float* d_Y,
+                          long long ystride);
+hipError_t scatter_rows64(hipStream_t s, const double* d_src, const long long* d_idx, int n, int ld, double* d_X, long long M);
+hipError_t to_f32(hipStream_t s, const double* d_X, long long n, float* d_out);
+
 // ---- level-sorted rows (sorted.hip): the pixel halves of the table passes without LDS atomics
 constexpr int kSortedThreads = 512;
 struct SortedRows {

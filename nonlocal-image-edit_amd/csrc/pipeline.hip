@@ -66,6 +66,8 @@ struct nle_filter {
     int K = 0, ldv = 0, r = 0, p = 0;
     float* d_V = nullptr;  // m_eigvecs (n_local x ldv fp32); in the lazy form it is materialised on first request
     size_t v_bytes = 0;
+    double* d_V64 = nullptr;  // fp64 formulation (generic64.hip): m_eigvecs in fp64, same leading dimension
+    size_t v64_bytes = 0;
     std::vector<double> eigvals;
     double ms[6] = {0, 0, 0, 0, 0, 0};
     // nle_filter_diag: formulation taken, eigenvalues kept by the three cuts (:214 on Ka, Wa, Q), Cholesky shortcuts
@@ -476,7 +478,17 @@ void build_phi(nle_ctx* c, const float* d_lum, const SampleSet& ss, const Nystro
 
 // Sinkhorn (reference :238-245) as 2T passes: t0 = Phi^T 1, then alternately
 // t <- Phi^T recip(Phi (lam o t)).  Returns u_c, u_r (host) and leaves lam o t_c_in on d_u_c.
-void sinkhorn_passes(nle_ctx* c, const float* d_phi, long long M, int ld, int r,
+inline hipError_t rowpass_any(hipStream_t s, int mode, const float* X, long long M, int ld, const double* t, const double* lam,
+                              const float* xv, double eps, double* partial, int* nb) {
+    return nlek::rowpass(s, mode, X, M, ld, t, lam, xv, eps, partial, nb);
+}
+inline hipError_t rowpass_any(hipStream_t s, int mode, const double* X, long long M, int ld, const double* t, const double* lam,
+                              const float* xv, double eps, double* partial, int* nb) {
+    return nlek::rowpass64(s, mode, X, M, ld, t, lam, xv, eps, partial, nb);
+}
+
+template <typename T_>
+void sinkhorn_passes(nle_ctx* c, const T_* d_phi, long long M, int ld, int r,
                      const std::vector<double>& lam, int T, std::vector<double>* u_c,
                      std::vector<double>* u_r, double* d_u_c_out /* ld doubles or null */) {
     if (T < 1) throw Fail{NLE_ERR_INVALID, "nSinkhornIter must be >= 1"};
@@ -487,7 +499,7 @@ void sinkhorn_passes(nle_ctx* c, const float* d_phi, long long M, int ld, int r,
     HIP_OK(hipMemcpyAsync(d_lam.p, lam_pad.data(), ld * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int nb = 0;
     // t_r(0) = Phi^T 1
-    PROFILED(c, NLE_K_SINKHORN_PASS, nlek::rowpass(c->stream, nlek::ROWPASS_COLSUM, d_phi, M, ld, nullptr, nullptr,
+    PROFILED(c, NLE_K_SINKHORN_PASS, rowpass_any(c->stream, nlek::ROWPASS_COLSUM, d_phi, M, ld, nullptr, nullptr,
                                                    nullptr, NLE_EPS, d_partial.p, &nb));
     PROFILED(c, NLE_K_REDUCE, nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t[0].p));
     all_reduce(c, d_t[0].p, ld);
@@ -498,7 +510,7 @@ void sinkhorn_passes(nle_ctx* c, const float* d_phi, long long M, int ld, int r,
         // c = recip(Phi (lam o t_r));  t_c = Phi^T c
         idx_c_in = cur;
         int nxt = (cur + 1) % 3;
-        PROFILED(c, NLE_K_SINKHORN_PASS, nlek::rowpass(c->stream, nlek::ROWPASS_RECIP, d_phi, M, ld, d_t[cur].p,
+        PROFILED(c, NLE_K_SINKHORN_PASS, rowpass_any(c->stream, nlek::ROWPASS_RECIP, d_phi, M, ld, d_t[cur].p,
                                                        d_lam.p, nullptr, NLE_EPS, d_partial.p, &nb));
         PROFILED(c, NLE_K_REDUCE, nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t[nxt].p));
         all_reduce(c, d_t[nxt].p, ld);
@@ -509,7 +521,7 @@ void sinkhorn_passes(nle_ctx* c, const float* d_phi, long long M, int ld, int r,
             // only u_r = lam o t_c enters the W blocks)
             nxt = (cur + 1) % 3;
             if (nxt == idx_c_in) nxt = (nxt + 1) % 3;
-            PROFILED(c, NLE_K_SINKHORN_PASS, nlek::rowpass(c->stream, nlek::ROWPASS_RECIP, d_phi, M, ld, d_t[cur].p,
+            PROFILED(c, NLE_K_SINKHORN_PASS, rowpass_any(c->stream, nlek::ROWPASS_RECIP, d_phi, M, ld, d_t[cur].p,
                                                            d_lam.p, nullptr, NLE_EPS, d_partial.p, &nb));
             PROFILED(c, NLE_K_REDUCE, nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t[nxt].p));
             all_reduce(c, d_t[nxt].p, ld);
@@ -621,7 +633,7 @@ struct Ortho {
 };
 
 Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_c,
-                         const std::vector<double>& u_r, std::vector<double> G, int n_eig) {
+                         const std::vector<double>& u_r, std::vector<double> G, int n_eig, bool device_f32 = true) {
     const int r = ny.r, q = ny.r;  // :247 -- the A block is the first q = r permuted rows
     // phi_A = V_A[:q] (exact, fp64); what the device holds for those rows is float(V_A)
     std::vector<double> cA(q), rA(q), cA32(q);
@@ -630,7 +642,7 @@ Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_
         double sc = 0.0, sr = 0.0, sc32 = 0.0;
         for (int k = 0; k < r; ++k) {
             const double v = ny.VA[(size_t)k * p + a];
-            const double v32 = (double)(float)v;
+            const double v32 = device_f32 ? (double)(float)v : v;  // what the device holds for that row
             phi32[(size_t)k * q + a] = v32;
             sc += v * u_c[k];
             sr += v * u_r[k];
@@ -945,6 +957,122 @@ void train_materialised(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     ms->project = tm_p.ms();
 }
 
+// (1b) the same literal decomposition with Phi and V in fp64 (generic64.hip): what auto mode falls back to when the
+// table form does not apply, and what the 1e-4 bar needs on inputs whose detail layers are small differences
+void build_phi64(nle_ctx* c, const float* d_lum, const SampleSet& ss, const Nystrom& ny, double hx, double hy, long long pix0,
+                 long long M, double* d_phi) {
+    const int p = ss.p, ldp = ld4(p), r = ny.r, ldr = ny.ldr;
+    DevBuf<float4> d_samples(p);
+    HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), p * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    DevBuf<double> d_B(ny.B.size());  // p x r column-major = what ts_gemm64 takes
+    HIP_OK(hipMemcpyAsync(d_B.p, ny.B.data(), ny.B.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemsetAsync(d_phi, 0, (size_t)std::max<long long>(M, 1) * ldr * sizeof(double), c->stream));
+    const long long chunk = 1ll << 20;  // affinity rows of 1 Mi pixels at a time (K_AB is never held whole)
+    DevBuf<double> d_kab((size_t)std::min<long long>(std::max<long long>(M, 1), chunk) * ldp);
+    for (long long i0 = 0; i0 < M; i0 += chunk) {
+        const long long m = std::min(chunk, M - i0);
+        PROFILED(c, NLE_K_AFFINITY, nlek::affinity64(c->stream, d_lum, ss.gs, d_samples.p, p, ldp, 1.0 / (hx * hx),
+                                                     1.0 / (hy * hy), pix0 + i0, m, d_kab.p));
+        PROFILED(c, NLE_K_NYSTROM, nlek::ts_gemm64(c->stream, d_kab.p, m, ldp, p, d_B.p, r, nullptr, d_phi + (size_t)i0 * ldr, ldr));
+    }
+    std::vector<double> rows;
+    std::vector<long long> idx;
+    for (int k = 0; k < p; ++k) {  // sample pixels carry their exact V_A row (top block of phi, reference :275)
+        const long long loc = ss.pix[k] - pix0;
+        if (loc < 0 || loc >= M) continue;
+        idx.push_back(loc);
+        const size_t off = rows.size();
+        rows.resize(off + ldr, 0.0);
+        for (int j = 0; j < r; ++j) rows[off + j] = ny.VA[(size_t)j * p + k];
+    }
+    DevBuf<double> d_rows(rows.size());
+    DevBuf<long long> d_idx(idx.size());
+    if (!idx.empty()) {
+        HIP_OK(hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_idx.p, idx.data(), idx.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+        PROFILED(c, NLE_K_SMALL, nlek::scatter_rows64(c->stream, d_rows.p, d_idx.p, (int)idx.size(), ldr, d_phi, M));
+    }
+    HIP_OK(hipStreamSynchronize(c->stream));  // host staging vectors go out of scope
+}
+
+// G (r x r col-major) = sum over ALL rows of every rank of c_i^2 phi_i phi_i^T, c_i = recip(phi_i . u) (d_u null: 1)
+std::vector<double> gram_all64(nle_ctx* c, const double* d_phi, long long M, int ld, int r, const double* d_u) {
+    DevBuf<double> d_cs, d_part(std::max<size_t>(nlek::gram64d_partial_elems(std::max<long long>(M, 1), r), 1)), d_G((size_t)r * r);
+    if (d_u && M > 0) {
+        d_cs.alloc((size_t)M);
+        PROFILED(c, NLE_K_SMALL, nlek::row_scalings64(c->stream, d_phi, M, ld, r, d_u, NLE_EPS, d_cs.p));
+    }
+    PROFILED(c, NLE_K_GRAM, nlek::gram64d(c->stream, d_phi, M, ld, r, d_cs.p, d_part.p, d_G.p));
+    all_reduce(c, d_G.p, (size_t)r * r);
+    std::vector<double> G((size_t)r * r);
+    HIP_OK(hipMemcpyAsync(G.data(), d_G.p, G.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return G;
+}
+
+void train_generic64(nle_ctx* c, nle_filter* f, const float* d_lum, const SampleSet& ss, const Nystrom& ny, double hx,
+                     double hy, int T, int n_eig, long long pix0, long long M, StageMs* ms) {
+    Timer tm_s(c->stream), tm_g(c->stream), tm_p(c->stream);
+    tm_s.start();
+    const size_t phi_elems = (size_t)std::max<long long>(M, 1) * ny.ldr;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && phi_elems * sizeof(double) > free_b + c->arena_bytes)
+        throw Fail{NLE_ERR_INVALID, "fp64 formulation: Phi (N x r doubles) does not fit in device memory; use an integer-valued "
+                                    "luminance plane with a sample grid of at most 32 x 36 (table formulation) or NLE_MODE_MATERIALISED"};
+    DevBuf<double> d_phi(phi_elems);
+    build_phi64(c, d_lum, ss, ny, hx, hy, pix0, M, d_phi.p);
+    std::vector<double> u_c, u_r;
+    DevBuf<double> d_u_c(ny.ldr);
+    sinkhorn_passes(c, d_phi.p, M, ny.ldr, ny.r, ny.lam, T, &u_c, &u_r, d_u_c.p);
+    tm_s.stop();
+    tm_g.start();
+    std::vector<double> G = gram_all64(c, d_phi.p, M, ny.ldr, ny.r, d_u_c.p);
+    tm_g.stop();
+    double h0 = now_ms();
+    Ortho o = orthogonalize_host(ny, ss.p, u_c, u_r, std::move(G), n_eig, /*device_f32=*/false);
+    ms->host += now_ms() - h0;
+    f->K = o.K;
+    f->ldv = ld4(o.K);
+    f->eigvals = o.Sq;
+    f->formulation = NLE_MODE_MATERIALISED_F64;
+    f->r_wa = o.r_wa;
+    f->r_q = o.r_q;
+    tm_p.start();
+    DevBuf<double> d_Cp(o.Cproj.size()), d_cs((size_t)std::max<long long>(M, 1));  // Cproj: r x K column-major
+    HIP_OK(hipMemcpyAsync(d_Cp.p, o.Cproj.data(), o.Cproj.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    PROFILED(c, NLE_K_SMALL, nlek::row_scalings64(c->stream, d_phi.p, M, ny.ldr, ny.r, d_u_c.p, NLE_EPS, d_cs.p));
+    DevBuf<double> d_V((size_t)std::max<long long>(M, 1) * f->ldv);
+    HIP_OK(hipMemsetAsync(d_V.p, 0, d_V.n * sizeof(double), c->stream));
+    PROFILED(c, NLE_K_PROJECT, nlek::ts_gemm64(c->stream, d_phi.p, M, ny.ldr, ny.r, d_Cp.p, o.K, d_cs.p, d_V.p, f->ldv));
+    {   // exact rows of the A block (top block of :327)
+        std::vector<double> rows;
+        std::vector<long long> idx;
+        for (int a = 0; a < o.q; ++a) {
+            const long long loc = ss.pix[a] - pix0;
+            if (loc < 0 || loc >= M) continue;
+            idx.push_back(loc);
+            const size_t off = rows.size();
+            rows.resize(off + f->ldv, 0.0);
+            for (int k = 0; k < o.K; ++k) rows[off + k] = o.VArows[(size_t)k * o.q + a];
+        }
+        if (!idx.empty()) {
+            DevBuf<double> d_rows(rows.size());
+            DevBuf<long long> d_idx(idx.size());
+            HIP_OK(hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipMemcpyAsync(d_idx.p, idx.data(), idx.size() * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+            PROFILED(c, NLE_K_SMALL, nlek::scatter_rows64(c->stream, d_rows.p, d_idx.p, (int)idx.size(), f->ldv, d_V.p, M));
+            HIP_OK(hipStreamSynchronize(c->stream));
+        }
+    }
+    tm_p.stop();
+    HIP_OK(hipStreamSynchronize(c->stream));
+    f->v64_bytes = d_V.n * sizeof(double);
+    f->d_V64 = d_V.take();
+    ms->sinkhorn = tm_s.ms();
+    ms->gram = tm_g.ms();
+    ms->project = tm_p.ms();
+}
+
 // (2) Phi-free: every N-sized pass regenerates its affinity rows (fused.hip)
 // `solve` factors Ka on the host (solve_Ka); it is called only after the first pass -- the column sum, which
 // needs nothing of it -- is on the stream, so the factorisation runs under that pass.
@@ -1214,8 +1342,17 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
 
 // materialise V = diag(c) K D of a lazy filter (projection kernel + exact sample rows)
 void ensure_V(nle_filter* f) {
-    if (f->d_V || !f->lazy) return;
+    if (f->d_V) return;
     nle_ctx* c = f->ctx;
+    if (f->d_V64) {  // fp64 formulation: an fp32 copy for the accessors that hand out float pointers
+        DevBuf<float> d_V((size_t)std::max<long long>(f->n_local, 1) * f->ldv);
+        HIP_OK(nlek::to_f32(c->stream, f->d_V64, f->n_local * f->ldv, d_V.p));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        f->v_bytes = d_V.n * sizeof(float);
+        f->d_V = d_V.take();
+        return;
+    }
+    if (!f->lazy) return;
     const long long M = f->n_local, pix0 = (long long)f->row0 * f->W;
     DevBuf<float> d_V((size_t)std::max<long long>(M, 1) * f->ldv);
     PROFILED(c, NLE_K_PROJECT, nlek::project64(c->stream, f->d_lum - pix0, f->gs, f->d_samples, f->p, f->nsw, f->npw, pix0,
@@ -1295,10 +1432,10 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         throw Fail{NLE_ERR_INVALID, "Phi-free path without tables supports at most 256 samples and 128 eigenvectors"};
     if (c->mode == 2 && !generic_ok && !tables_ok)
         throw Fail{NLE_ERR_INVALID, "Phi-free path supports at most 128 eigenvectors and a 32 x 36 sample grid"};
-    // auto: the table form (all fp64) whenever it applies; the generic Phi-free form (fp32 affinities) needs
-    // enough non-sample pixels per sample for its rounding to average out (DESIGN.md "Numerics")
-    const bool enough_pixels = (long long)H * W >= 64ll * gs.p();
-    const bool want_fuse = c->mode >= 2 || (c->mode == 0 && (enough_pixels || tables_ok));
+    // auto: the table form (all fp64) whenever it applies, else the literal decomposition in fp64 (generic64.hip).  The
+    // fp32 formulations (materialised Phi, Phi-free with fp32 affinities) run only when asked for by mode: they miss
+    // the 1e-4 bar on some well-posed inputs (DESIGN.md "Numerics").
+    const bool want_fuse = c->mode == 2 || c->mode == 3 || (c->mode == 0 && tables_ok);
     HIP_OK(hipSetDevice(c->device));
 
     auto f = new nle_filter();
@@ -1317,7 +1454,7 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         Timer tm_a(c->stream);
         tm_a.start();
         SampleSet ss = fetch_samples(c, d_lum, gs, want_fuse && tables_ok);
-        const bool fuse = c->mode == 0 ? ((tables_ok && ss.quantised) || (enough_pixels && generic_ok))
+        const bool fuse = c->mode == 0 ? (tables_ok && ss.quantised)
                                        : (want_fuse && (generic_ok || (tables_ok && ss.quantised)));
         if (c->mode == 2 && !fuse)
             throw Fail{NLE_ERR_INVALID, "Phi-free path: more than 256 samples needs an integer-valued luminance plane"};
@@ -1340,7 +1477,10 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         } else {
             const Nystrom ny = solve(false);
             f->r = ny.r;
-            train_materialised(c, f, d_lum, ss, ny, hx, hy, T, n_eig, pix0, M, &sm);
+            if (c->mode == NLE_MODE_MATERIALISED)
+                train_materialised(c, f, d_lum, ss, ny, hx, hy, T, n_eig, pix0, M, &sm);
+            else
+                train_generic64(c, f, d_lum, ss, ny, hx, hy, T, n_eig, pix0, M, &sm);
         }
         tr.mark("train path");
         prof_flush(c);
@@ -1370,7 +1510,7 @@ void apply_impl(nle_filter* f, const float* d_x, int H, int W, const double* h_g
         apply_sample_space(f, d_x, h_g, L, d_y, done, group);
         return;
     }
-    ensure_V(f);
+    if (!f->d_V64) ensure_V(f);
     const int ld = f->ldv;
     const long long M = f->n_local;
     const long long pix0 = (long long)f->row0 * f->W;
@@ -1381,12 +1521,19 @@ void apply_impl(nle_filter* f, const float* d_x, int H, int W, const double* h_g
         for (int k = 0; k < f->K; ++k) resp[(size_t)l * ld + k] = h_g[(size_t)l * f->K + k];
     HIP_OK(hipMemcpyAsync(d_resp.p, resp.data(), resp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int nb = 0;
+    if (f->d_V64)
+        PROFILED(c, NLE_K_APPLY_REDUCE, nlek::rowpass64(c->stream, nlek::ROWPASS_XVEC, f->d_V64, M, ld, nullptr, nullptr,
+                                                        d_x + pix0, NLE_EPS, d_partial.p, &nb));
+    else
     PROFILED(c, NLE_K_APPLY_REDUCE, nlek::rowpass(c->stream, nlek::ROWPASS_XVEC, f->d_V, M, ld, nullptr, nullptr,
                                                   d_x + pix0, NLE_EPS, d_partial.p, &nb));
     PROFILED(c, NLE_K_REDUCE, nlek::reduce_partials(c->stream, d_partial.p, nb, ld, d_t.p));
     all_reduce(c, d_t.p, ld);
     for (int l = 0; l < L; ++l)
         PROFILED(c, NLE_K_SMALL, nlek::scale_vec(c->stream, d_resp.p + (size_t)l * ld, d_t.p, ld, d_g.p + (size_t)l * ld));
+    if (f->d_V64)
+        PROFILED(c, NLE_K_APPLY_EXPAND, nlek::apply_expand64(c->stream, f->d_V64, M, ld, f->K, d_g.p, L, d_y, M));
+    else
     PROFILED(c, NLE_K_APPLY_EXPAND, nlek::apply_expand(c->stream, f->d_V, M, ld, d_g.p, L, d_y, M));
     if (done) done(0, L);
     HIP_OK(hipStreamSynchronize(c->stream));
@@ -1632,7 +1779,7 @@ int nle_ctx_trim(nle_ctx* ctx) {
 }
 
 int nle_ctx_set_mode(nle_ctx* ctx, int mode) {
-    if (!ctx || mode < 0 || mode > 3) return NLE_ERR_INVALID;
+    if (!ctx || mode < 0 || mode > NLE_MODE_MATERIALISED_F64) return NLE_ERR_INVALID;
     ctx->mode = mode;
     return NLE_OK;
 }
@@ -1801,6 +1948,86 @@ int nle_row_scalings(nle_ctx* ctx, const float* d_phi, long long M, int ld, int 
     });
 }
 
+// ---- the same five stage entry points on fp64 device matrices (generic64.hip) ----
+int nle_compute_kernel64(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples, int n_col_samples, double hx,
+                         double hy, double* h_Ka, double* d_kab) {
+    if (!ctx || !d_lum) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        check_image_size(H, W);
+        if (n_row_samples > H || n_col_samples > W)
+            throw Fail{NLE_ERR_INVALID, "Number of samples per row and col must be <= that of image."};
+        GridSpec gs;
+        if (!make_grid(H, W, n_row_samples, n_col_samples, &gs)) throw Fail{NLE_ERR_INVALID, "invalid sample counts"};
+        HIP_OK(hipSetDevice(ctx->device));
+        SampleSet ss = fetch_samples(ctx, d_lum, gs);
+        if (h_Ka) {
+            std::vector<double> Ka = build_Ka(ss, hx, hy);
+            std::copy(Ka.begin(), Ka.end(), h_Ka);
+        }
+        if (d_kab) {
+            int row0, row1;
+            slab(H, ctx->rank, ctx->world, &row0, &row1);
+            DevBuf<float4> d_samples(ss.p);
+            HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), ss.p * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+            PROFILED(ctx, NLE_K_AFFINITY,
+                     nlek::affinity64(ctx->stream, d_lum, gs, d_samples.p, ss.p, ld4(ss.p), 1.0 / (hx * hx), 1.0 / (hy * hy),
+                                      (long long)row0 * W, (long long)(row1 - row0) * W, d_kab));
+            HIP_OK(hipStreamSynchronize(ctx->stream));
+            prof_flush(ctx);
+        }
+    });
+}
+
+int nle_ts_gemm64(nle_ctx* ctx, const double* d_A, long long M, int lda, int kd, const double* h_B, int nc, double* d_C) {
+    if (!ctx || !d_A || !h_B || !d_C || M < 0 || kd < 1 || nc < 1 || lda < kd) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        const int ldc = ld4(nc);
+        DevBuf<double> d_B((size_t)kd * nc);
+        HIP_OK(hipMemcpyAsync(d_B.p, h_B, (size_t)kd * nc * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(hipMemsetAsync(d_C, 0, (size_t)std::max<long long>(M, 0) * ldc * sizeof(double), ctx->stream));
+        HIP_OK(nlek::ts_gemm64(ctx->stream, d_A, M, lda, kd, d_B.p, nc, nullptr, d_C, ldc));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int nle_sinkhorn_scalings64(nle_ctx* ctx, const double* d_phi, long long M, int ld, int r, const double* h_eigvals,
+                            int max_iter, double* h_u_c, double* h_u_r) {
+    if (!ctx || !d_phi || !h_eigvals || !h_u_c || !h_u_r || M < 0 || r < 1 || ld < r) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        std::vector<double> lam(h_eigvals, h_eigvals + r), uc, ur;
+        sinkhorn_passes(ctx, d_phi, M, ld, r, lam, max_iter, &uc, &ur, nullptr);
+        std::copy(uc.begin(), uc.end(), h_u_c);
+        std::copy(ur.begin(), ur.end(), h_u_r);
+    });
+}
+
+int nle_gram64(nle_ctx* ctx, const double* d_phi, long long M, int ld, int r, const double* h_u, double* h_G) {
+    if (!ctx || !d_phi || !h_G || M < 0 || r < 1 || ld < r) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        DevBuf<double> d_u;
+        if (h_u) {
+            d_u.alloc(r);
+            HIP_OK(hipMemcpy(d_u.p, h_u, r * sizeof(double), hipMemcpyHostToDevice));
+        }
+        std::vector<double> G = gram_all64(ctx, d_phi, M, ld, r, d_u.p);
+        std::copy(G.begin(), G.end(), h_G);
+    });
+}
+
+int nle_row_scalings64(nle_ctx* ctx, const double* d_phi, long long M, int ld, int r, const double* h_u, double* d_out) {
+    if (!ctx || !d_phi || !h_u || !d_out || M < 0 || r < 1 || ld < r) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        HIP_OK(hipSetDevice(ctx->device));
+        DevBuf<double> d_u(r);
+        HIP_OK(hipMemcpyAsync(d_u.p, h_u, r * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(nlek::row_scalings64(ctx->stream, d_phi, M, ld, r, d_u.p, NLE_EPS, d_out));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
 int nle_train(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples, int n_col_samples, double hx,
               double hy, int n_sinkhorn_iter, int n_eigen_vectors, nle_filter** out) {
     if (!ctx || !d_lum || !out) return NLE_ERR_INVALID;
@@ -1831,6 +2058,7 @@ void nle_filter_destroy(nle_filter* f) {
     if (f->ctx) f->ctx->filters.erase(f);
     if (f->d_V) arena_release(f->ctx, f->d_V, f->v_bytes);  // back to the ctx's workspace cache (or hipFree)
     if (f->d_plane) arena_release(f->ctx, f->d_plane, f->plane_bytes);
+    if (f->d_V64) arena_release(f->ctx, f->d_V64, f->v64_bytes);
     for (auto& b : f->owned) arena_release(f->ctx, b.first, b.second);
     delete f;
 }

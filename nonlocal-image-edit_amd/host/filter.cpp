@@ -64,6 +64,14 @@ std::vector<float> cols_as_rows_f32(const Mat& m, int ld) {
     return v;
 }
 
+// the same in fp64 (the stage-level API runs on fp64 device matrices: nle_*64)
+std::vector<double> cols_as_rows_f64(const Mat& m, int ld) {
+    std::vector<double> v((size_t)m.cols() * ld, 0.0);
+    for (int j = 0; j < m.cols(); ++j)
+        for (int i = 0; i < m.rows(); ++i) v[(size_t)j * ld + i] = m(i, j);
+    return v;
+}
+
 }  // namespace
 
 Mat operator*(const Mat& a, const Mat& b) {
@@ -104,12 +112,12 @@ std::tuple<Permutation, Mat, Mat> computeKernel(const Image& mat, int nRowSample
         throw std::runtime_error("Number of samples per row and col must be <= that of image.");
     const int p = nr * nc, ld = nle_ld(p);
     std::vector<float> lum = plane_f32(mat);
-    Dev d_lum(c, (size_t)N * 4), d_kab(c, (size_t)N * ld * 4);
+    Dev d_lum(c, (size_t)N * 4), d_kab(c, (size_t)N * ld * 8);
     check(nle_dev_upload(c, d_lum.p, lum.data(), (size_t)N * 4), c);
     Mat Ka(p, p);
-    check(nle_compute_kernel(c, d_lum.f(), H, W, nRowSamples, nColSamples, hx, hy, Ka.data(), d_kab.f()), c);
-    std::vector<float> kab((size_t)N * ld);
-    check(nle_dev_download(c, kab.data(), d_kab.p, kab.size() * 4), c);
+    check(nle_compute_kernel64(c, d_lum.f(), H, W, nRowSamples, nColSamples, hx, hy, Ka.data(), d_kab.d()), c);
+    std::vector<double> kab((size_t)N * ld);
+    check(nle_dev_download(c, kab.data(), d_kab.p, kab.size() * 8), c);
     // [selected; rest] order, both in row-major scan order (:56-80, :156-164)
     Permutation P;
     P.idx.resize((size_t)N);
@@ -126,7 +134,7 @@ std::tuple<Permutation, Mat, Mat> computeKernel(const Image& mat, int nRowSample
     for (long long pix = 0; pix < N; ++pix) {
         if (sel[(size_t)pix]) continue;
         P.idx[(size_t)(p + jrest)] = (int)pix;
-        const float* row = kab.data() + (size_t)pix * ld;
+        const double* row = kab.data() + (size_t)pix * ld;
         for (int i = 0; i < p; ++i) Kab(i, jrest) = row[i];
         ++jrest;
     }
@@ -165,12 +173,12 @@ std::pair<Vec, Mat> nystromApproximation(const Mat& Ka, const Mat& Kab) {
         for (int s = 0; s < p; ++s) phi(s, k) = eigvecs(s, k);
     if (n_rest > 0 && r > 0) {
         const int lda = nle_ld(p), ldc = nle_ld(r);
-        std::vector<float> rows = cols_as_rows_f32(Kab, lda);
-        Dev d_A(c, rows.size() * 4), d_C(c, (size_t)n_rest * ldc * 4);
-        check(nle_dev_upload(c, d_A.p, rows.data(), rows.size() * 4), c);
-        check(nle_ts_gemm(c, d_A.f(), n_rest, lda, p, B.data(), r, d_C.f()), c);  // Kab^T * B, :275
-        std::vector<float> out((size_t)n_rest * ldc);
-        check(nle_dev_download(c, out.data(), d_C.p, out.size() * 4), c);
+        std::vector<double> rows = cols_as_rows_f64(Kab, lda);
+        Dev d_A(c, rows.size() * 8), d_C(c, (size_t)n_rest * ldc * 8);
+        check(nle_dev_upload(c, d_A.p, rows.data(), rows.size() * 8), c);
+        check(nle_ts_gemm64(c, d_A.d(), n_rest, lda, p, B.data(), r, d_C.d()), c);  // Kab^T * B, :275
+        std::vector<double> out((size_t)n_rest * ldc);
+        check(nle_dev_download(c, out.data(), d_C.p, out.size() * 8), c);
         for (int j = 0; j < n_rest; ++j)
             for (int k = 0; k < r; ++k) phi(p + j, k) = out[(size_t)j * ldc + k];
     }
@@ -184,23 +192,23 @@ std::pair<Mat, Mat> sinkhorn(const Mat& phi, const Vec& eigvals, int maxIter) {
     if (r == 0 || n == 0) throw std::runtime_error("sinkhorn: empty phi");
     if (maxIter < 1) throw std::runtime_error("sinkhorn: maxIter must be >= 1");
     const int ld = nle_ld(r);
-    std::vector<float> rows((size_t)n * ld, 0.f);
+    std::vector<double> rows((size_t)n * ld, 0.0);
     for (int k = 0; k < r; ++k)
-        for (int i = 0; i < n; ++i) rows[(size_t)i * ld + k] = (float)phi(i, k);
-    Dev d_phi(c, rows.size() * 4), d_c(c, (size_t)n * 8);
-    check(nle_dev_upload(c, d_phi.p, rows.data(), rows.size() * 4), c);
+        for (int i = 0; i < n; ++i) rows[(size_t)i * ld + k] = phi(i, k);
+    Dev d_phi(c, rows.size() * 8), d_c(c, (size_t)n * 8);
+    check(nle_dev_upload(c, d_phi.p, rows.data(), rows.size() * 8), c);
     std::vector<double> u_c(r), u_r(r);
-    check(nle_sinkhorn_scalings(c, d_phi.f(), n, ld, r, eigvals.data(), maxIter, u_c.data(), u_r.data()), c);
-    check(nle_row_scalings(c, d_phi.f(), n, ld, r, u_c.data(), d_c.d()), c);
+    check(nle_sinkhorn_scalings64(c, d_phi.d(), n, ld, r, eigvals.data(), maxIter, u_c.data(), u_r.data()), c);
+    check(nle_row_scalings64(c, d_phi.d(), n, ld, r, u_c.data(), d_c.d()), c);
     std::vector<double> cv((size_t)n);
     check(nle_dev_download(c, cv.data(), d_c.p, cv.size() * 8), c);
     const int q = r;  // :247  p = phi.cols()
     if (q > n) throw std::runtime_error("sinkhorn: phi has more columns than rows");
-    // left = R * (phi_top * D); the device holds float(phi), use the same values here
+    // left = R * (phi_top * D)
     Mat left(q, r), right(q, r);
     for (int a = 0; a < q; ++a) {
         double sr = 0.0;
-        for (int k = 0; k < r; ++k) sr += (double)rows[(size_t)a * ld + k] * u_r[k];
+        for (int k = 0; k < r; ++k) sr += rows[(size_t)a * ld + k] * u_r[k];
         const double ra = recip0(sr);
         for (int k = 0; k < r; ++k) {
             const double v = rows[(size_t)a * ld + k];
@@ -213,12 +221,12 @@ std::pair<Mat, Mat> sinkhorn(const Mat& phi, const Vec& eigvals, int maxIter) {
     if (n > q) {
         const int ldq = nle_ld(q);
         Mat lt = left.transpose();  // r x q
-        Dev d_out(c, (size_t)(n - q) * ldq * 4);
-        check(nle_ts_gemm(c, d_phi.f() + (size_t)q * ld, n - q, ld, r, lt.data(), q, d_out.f()), c);
-        std::vector<float> out((size_t)(n - q) * ldq);
-        check(nle_dev_download(c, out.data(), d_out.p, out.size() * 4), c);
+        Dev d_out(c, (size_t)(n - q) * ldq * 8);
+        check(nle_ts_gemm64(c, d_phi.d() + (size_t)q * ld, n - q, ld, r, lt.data(), q, d_out.d()), c);
+        std::vector<double> out((size_t)(n - q) * ldq);
+        check(nle_dev_download(c, out.data(), d_out.p, out.size() * 8), c);
         for (int j = 0; j < n - q; ++j)
-            for (int a = 0; a < q; ++a) Wab(a, j) = (double)out[(size_t)j * ldq + a] * cv[(size_t)(q + j)];  // :250
+            for (int a = 0; a < q; ++a) Wab(a, j) = out[(size_t)j * ldq + a] * cv[(size_t)(q + j)];  // :250
     }
     return std::make_pair(Wa, Wab);
 }
@@ -239,11 +247,11 @@ std::pair<Mat, Vec> orthogonalize(const Mat& Wa, const Mat& Wab, int nEigVectors
     Mat invRootWa = Us * eigvecs.transpose();  // :292
     Mat G(q, q);
     const int ldq = nle_ld(q);
-    std::vector<float> rows = cols_as_rows_f32(Wab, ldq);  // Wab^T, one row per pixel
-    Dev d_X(c, std::max<size_t>(rows.size(), 1) * 4);
+    std::vector<double> rows = cols_as_rows_f64(Wab, ldq);  // Wab^T, one row per pixel
+    Dev d_X(c, std::max<size_t>(rows.size(), 1) * 8);
     if (nb > 0) {
-        check(nle_dev_upload(c, d_X.p, rows.data(), rows.size() * 4), c);
-        check(nle_gram(c, d_X.f(), nb, ldq, q, nullptr, G.data()), c);  // Wab * Wab^T, :296
+        check(nle_dev_upload(c, d_X.p, rows.data(), rows.size() * 8), c);
+        check(nle_gram64(c, d_X.d(), nb, ldq, q, nullptr, G.data()), c);  // Wab * Wab^T, :296
     }
     Mat Q = invRootWa * G * invRootWa;
     for (int j = 0; j < q; ++j)
@@ -265,10 +273,10 @@ std::pair<Mat, Vec> orthogonalize(const Mat& Wa, const Mat& Wab, int nEigVectors
         for (int i = 0; i < q; ++i) V(i, j) = top(i, j);
     if (nb > 0 && k > 0) {
         const int ldk = nle_ld(k);
-        Dev d_out(c, (size_t)nb * ldk * 4);
-        check(nle_ts_gemm(c, d_X.f(), nb, ldq, q, C.data(), k, d_out.f()), c);  // Wab^T * C, :327
-        std::vector<float> out((size_t)nb * ldk);
-        check(nle_dev_download(c, out.data(), d_out.p, out.size() * 4), c);
+        Dev d_out(c, (size_t)nb * ldk * 8);
+        check(nle_ts_gemm64(c, d_X.d(), nb, ldq, q, C.data(), k, d_out.d()), c);  // Wab^T * C, :327
+        std::vector<double> out((size_t)nb * ldk);
+        check(nle_dev_download(c, out.data(), d_out.p, out.size() * 8), c);
         for (int i = 0; i < nb; ++i)
             for (int j = 0; j < k; ++j) V(q + i, j) = out[(size_t)i * ldk + j];
     }

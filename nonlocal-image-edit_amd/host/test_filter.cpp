@@ -3,9 +3,8 @@
 // vendored ext/catch.hpp belongs to the reference); this is a plain main() that prints one line
 // per check and exits non-zero on failure.
 //
-// Tolerances: the reference checks at 1e-10 because everything is fp64 on the CPU.  Here the
-// N-sized matrices live in fp32 on the device (fp64 reductions), so properties that involve them
-// are checked at 1e-5; the host-only ones (eigenDecomposition, conversions) keep 1e-10.
+// Tolerances: the reference's own, 1e-10 (test/test_filter.cpp:8) -- the stage-level functions of include/nle/filter.hpp
+// run on fp64 device matrices (nle_*64, csrc/generic64.hip), so its assertions hold unchanged.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -73,7 +72,7 @@ static void check_balanced(const Mat& Wa, const Mat& Wab, double tol) {
 }
 
 int main() {
-    const double tol = 1e-10, dev_tol = 1e-5;
+    const double tol = 1e-10;
     std::mt19937 gen(12345);
 
     {  // "OpenCV and Eigen conversions", test/test_filter.cpp:10-40
@@ -115,13 +114,18 @@ int main() {
         CHECK(Wa.rows() == 2 && Wa.cols() == 2 && Wab.cols() == 0);
         check_balanced(Wa, Wab, tol);  // phi = I is exact in fp32
 
-        Mat R = randomUnit(5, 5, gen);  // not symmetrised, like the reference (:96-97)
-        Mat U;
-        Vec D;
-        std::tie(U, D) = nle::eigenDecomposition(R, tol);
-        std::tie(Wa, Wab) = nle::sinkhorn(U, D, 20);
-        CHECK(Wa.rows() == U.cols() && Wab.cols() == 5 - U.cols());
-        if (U.cols() == 5) check_balanced(Wa, Wab, dev_tol);
+        // "Balanced random matrix" (:96-122) on ten draws instead of the reference's one (its Mat::Random values are
+        // platform dependent): R is NOT symmetrised, eigenDecomposition reads its lower triangle and drops the negative
+        // eigenvalues, so phi = U may have fewer than 5 columns and the "A block" is then the first q rows (:247)
+        for (int draw = 0; draw < 10; ++draw) {
+            Mat R = randomUnit(5, 5, gen);
+            Mat U;
+            Vec D;
+            std::tie(U, D) = nle::eigenDecomposition(R, tol);
+            std::tie(Wa, Wab) = nle::sinkhorn(U, D, 20);
+            CHECK(Wa.rows() == U.cols() && Wab.cols() == 5 - U.cols());
+            check_balanced(Wa, Wab, tol);
+        }
     }
     {  // "Orthogonalize", :126-153
         const int p = 10, n = 100, k = 5;
@@ -137,7 +141,7 @@ int main() {
         CHECK(V.cols() > 0);
         CHECK(S.size() == V.cols());
         CHECK(V.rows() == n);
-        CHECK(isApprox(V.transpose() * V, Mat::Identity(V.cols(), V.cols()), dev_tol));
+        CHECK(isApprox(V.transpose() * V, Mat::Identity(V.cols(), V.cols()), tol));  // :148-152
     }
     {  // end to end through the class: train on a small synthetic plane, projector property
         const int H = 48, W = 64;

@@ -64,20 +64,36 @@ def test_sinkhorn_identity(oracle):
     _check_doubly_stochastic(Wa, Wab, TOL)
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3])
-def test_sinkhorn_balanced_random(oracle, seed):
+def _balanced_random(oracle, seed):
     rng = np.random.default_rng(seed)
-    R = (rng.uniform(-1, 1, (5, 5)) + 1) / 2                            # :96-97
-    U, D = oracle.eigen_decomposition(R, TOL)                           # :101
+    R = (rng.uniform(-1, 1, (5, 5)) + 1) / 2                            # :96-97 (NOT symmetrised)
+    U, D = oracle.eigen_decomposition(R, TOL)                           # :101  lower triangle, negative eigenvalues dropped
     Wa, Wab = oracle.sinkhorn(U, D, 20)                                 # :103
     q = U.shape[1]
     assert Wa.shape == (q, q) and Wab.shape == (q, 5 - q)               # q = phi.cols(), :247
-    # the iteration has not fully converged after 20 steps for every draw: the reference's own
-    # check is isApprox at 1e-10 on ITS draw; here the balance must hold to the achieved residual
     rows = np.hstack([Wa, Wab]).sum(axis=1)
     cols = np.vstack([Wa, Wab.T]).sum(axis=0)
-    if q == 5:
-        assert np.abs(rows - 1).max() < 1e-6 and np.abs(cols - 1).max() < 1e-6
+    return q, is_approx(Wa, Wa.T, TOL), is_approx(cols, np.ones(q), TOL), is_approx(rows, np.ones(q), TOL)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_sinkhorn_balanced_random(oracle, seed):
+    """The reference's three assertions (:105-121) at the reference's own tolerance (isApprox, 1e-10) on 24 draws
+    -- ranks 3, 4 and 5 occur among them.  The reference tests ONE draw of Mat::Random (platform dependent)."""
+    q, sym, col, row = _balanced_random(oracle, seed)
+    assert sym and col and row, (q, sym, col, row)
+
+
+def test_sinkhorn_balanced_random_is_a_convergence_property(oracle):
+    """Rows of [Wa Wab] sum to 1 by construction (the last half-iteration sets r = 1 / (K c), :243-244): exact on every
+    draw.  Symmetry of Wa and the column sums are reached only when the 20 iterations have converged: 6 of 200 draws
+    (seeds 33, 35, 73, 97, 125, 179; all of rank 3 or 4) stop at a residual of 4e-11 .. 1e-6.  A draw like that would
+    fail the reference's own test too -- this is the algorithm, not an implementation."""
+    res = [_balanced_random(oracle, seed) for seed in range(200)]
+    assert all(r[3] for r in res)
+    slow = [seed for seed, r in enumerate(res) if not (r[1] and r[2])]
+    assert slow == [33, 35, 73, 97, 125, 179]
+    assert all(res[s][0] < 5 for s in slow)
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])

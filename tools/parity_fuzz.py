@@ -23,9 +23,12 @@ def main():
     rng = np.random.default_rng(seed)
     nle, oracle = entry.load_package(), entry.load_oracle()
     ctx = nle.Context(0)
-    worst = {0: 0.0, 1: 0.0, 2: 0.0, 3: 0.0}
-    skipped = {0: 0, 1: 0, 2: 0, 3: 0}
-    bad = 0
+    MODES = (0, 2, 4, 1, 3)     # auto, tables (fp64), literal decomposition in fp64; the two opt-in fp32 forms
+    FP64 = (0, 2, 4)
+    worst = {m: 0.0 for m in MODES}
+    skipped = {m: 0 for m in MODES}
+    bad = {m: 0 for m in MODES}
+    borderline = {"cases": 0, "rank_mismatch": 0, "worst": 0.0}
     done = 0
     while done < n_cases:
         if big:
@@ -55,10 +58,11 @@ def main():
             continue
         lam = inter["lam"]
         w_all = np.linalg.eigvalsh(inter["Ka"])[::-1]
-        # skip inputs whose rank cut is borderline: results there depend on rounding in the eigensolver itself
+        # inputs whose rank cut is borderline (an eigenvalue of Ka within a factor 100 of the 1e-10 cut on either side):
+        # a separate, reported class -- the README images live there (tests/test_readme_pairs_gpu.py) -- on which the
+        # fp64 formulations must still keep the oracle's rank and meet the bar whenever the oracle itself is stable
         r = lam.size
-        if (r < w_all.size and abs(w_all[r]) > 1e-12) or lam[-1] < 1e-8:
-            continue
+        is_borderline = (r < w_all.size and abs(w_all[r]) > 1e-12) or lam[-1] < 1e-8
         p = inter["Ka"].shape[0]
         Y_o = oracle.apply_layers(V_o, S_o, x, L).reshape(L, -1)
         # How sensitive is the reference algorithm itself on this input?  The same oracle pipeline with independent
@@ -80,12 +84,18 @@ def main():
             continue
         if S_p.size != S_o.size:
             continue
+        if is_borderline:
+            inter_p = oracle.eigen_decomposition(Ka1)[1]
+            if inter_p.size != r:
+                continue          # the oracle's own rank flips under 1e-12 noise: no implementation is defined here
         V_p = np.empty_like(Vp)
         V_p[perm] = Vp
         Y_p = oracle.apply_layers(V_p, S_p, x, L).reshape(L, -1)
         amp = max(rel(Y_p[j], Y_o[j]) for j in range(L)) / 1e-12
         done += 1
-        for mode in ((0, 1, 2) if (big and p > 256) else (0, 1, 2, 3)):   # 0 = auto: what a caller gets
+        if is_borderline:
+            borderline["cases"] += 1
+        for mode in (tuple(m for m in MODES if m != 3) if (big and p > 256) else MODES):   # 0 = auto: what a caller gets
             ctx.set_mode(mode)
             try:
                 f = nle.NLEFilter(ctx).train_filter(x.astype(np.float32), nr, nc, hx, hy, T, K)
@@ -102,28 +112,34 @@ def main():
             m = max(errs)
             # noise each formulation injects into the affinities: fp32 (1e-7) for the materialised and exp forms,
             # fp64 (1e-15) for the tables; predicted output error = noise x amplification
-            took_tables = mode in (0, 2)   # integer planes and grids <= 32 x 36 here: auto takes the table form
-            # fp64 forms: rounding of the p-sized algebra acts like input noise of eps * cond(Ka) (two fp64
-            # algorithms for pinv(Ka) z agree no better than that)
-            noise = max(1e-15, 1e-16 * float(lam[0] / lam[-1])) if took_tables else 1e-7
+            took_tables = mode in FP64     # integer planes and grids <= 32 x 36 here: auto takes the table form
+            # fp64 forms: rounding acts like relative noise of 1e-15 on the affinities (the factored Sinkhorn update
+            # keeps it there also when Ka is near singular: tools/readme_pair_sensitivity.py)
+            noise = 1e-15 if took_tables else 1e-7
             predicted = noise * amp
             if predicted > 2e-5:
                 skipped[mode] += 1
                 continue   # not well posed for this formulation's arithmetic
             tol = 1e-4
             worst[mode] = max(worst[mode], m)
+            if is_borderline and mode in FP64:
+                if info["r"] != r:
+                    borderline["rank_mismatch"] += 1
+                borderline["worst"] = max(borderline["worst"], m)
             if not (m < tol and ev < 1e-3):
-                bad += 1
+                bad[mode] += 1
                 out_dir = os.path.join(ROOT, "gpurun_out")
                 if os.path.isdir(out_dir):   # keep the input for a replay
                     np.savez(os.path.join(out_dir, f"fuzz_fail_{seed}_{done}_{mode}.npz"), x=x,
                              params=np.array([nr, nc, hx, hy, T, K, L, mode], dtype=np.float64))
                 print("FAIL mode", mode, (H, W, nr, nc, round(hx, 2), round(hy, 2), T, K, L), "kind", int(kind), "p", p, "r", r,
                       "lam_min %.2e" % lam[-1], "amp %.1e" % amp, "layers", ["%.1e" % e for e in errs], "eig %.1e" % ev, flush=True)
-    print(f"{done} cases x 4 modes, {bad} failures; asserted (well-posed for the formulation's arithmetic): "
-          f"auto {done - skipped[0]}, materialised {done - skipped[1]}, tables {done - skipped[2]}, exp {done - skipped[3]}; "
-          f"worst per-layer error: auto {worst[0]:.2e}, materialised {worst[1]:.2e}, tables {worst[2]:.2e}, exp {worst[3]:.2e}")
-    return 1 if bad else 0
+    names = {0: "auto", 2: "tables_f64", 4: "materialised_f64", 1: "materialised_f32 (opt-in)", 3: "phi_free_exp_f32 (opt-in)"}
+    print(f"{done} cases ({borderline['cases']} with a borderline rank cut); per formulation: asserted / failures / worst per-layer error")
+    for m in MODES:
+        print(f"  {names[m]:28s} {done - skipped[m]:4d} / {bad[m]:3d} / {worst[m]:.2e}")
+    print(f"borderline class, fp64 formulations: rank mismatches {borderline['rank_mismatch']}, worst per-layer error {borderline['worst']:.2e}")
+    return 1 if any(bad[m] for m in FP64) else 0
 
 
 if __name__ == "__main__":
