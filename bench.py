@@ -136,6 +136,10 @@ def main():
     ap.add_argument("--config", default="cfg4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for rehearsals)")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
+                    help="N > 1: 'rccl' = the library's own ncclAllReduce on its stream (communicator bootstrapped over "
+                         "torch.distributed); 'torch' = torch.distributed.all_reduce through the callback ABI")
+    ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the replica-throughput leg")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--simulate-world", type=int, default=0,
@@ -179,8 +183,23 @@ def main():
     ctx.set_mode(args.mode)
     g = nle.sample_grid(H, W, cfg["n_row"], cfg["n_col"])
     p = g["n_sel_rows"] * g["n_sel_cols"]
+    comm_kind = "none"
     if world > 1:
-        ctx.set_shard(rank, world, p, lambda t: dist.all_reduce(t))
+        comm_kind = "torch.distributed all_reduce via callback"
+        if args.comm == "rccl" and args.backend == "nccl" and not args.same_device:
+            # bootstrap: rank 0's ncclUniqueId travels over the torch process group, then every rank joins the
+            # library's own communicator; from here on the data path never enters Python
+            uid = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
+            if rank == 0:
+                uid = torch.tensor(list(nle.rccl_unique_id()), dtype=torch.uint8, device=f"cuda:{local_rank}")
+            dist.broadcast(uid, 0)
+            try:
+                ctx.init_rccl(rank, world, bytes(uid.cpu().tolist()))
+                comm_kind = "native RCCL (ncclAllReduce in place on the ctx stream)"
+            except Exception as e:  # noqa: BLE001 -- keep the run alive on the callback path and say so
+                print(f"[bench] rank {rank}: native RCCL init failed ({e!r}); using the torch callback", file=sys.stderr, flush=True)
+        if comm_kind.startswith("torch"):
+            ctx.set_shard(rank, world, p, lambda t: dist.all_reduce(t))
     elif args.simulate_world > 1:
         ctx.set_shard(0, args.simulate_world, p, lambda t: None)
 
@@ -250,6 +269,31 @@ def main():
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = (H * W / 1e6) / (elapsed / args.steps)
+
+    # ---- N > 1, second leg: replicas -- every rank filters its OWN image, no collective in the data path (weak scaling)
+    replicas = None
+    if world > 1 and not args.no_replicas and args.simulate_world <= 1:
+        c_r = nle.Context(local_rank)
+        c_r.set_mode(args.mode)
+        f_r = nle.NLEFilter(c_r)
+        out_r = torch.empty((L, H * W), dtype=torch.float32, device=lum.device)
+        for _ in range(args.warmup):
+            f_r.train_filter(lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"])
+            f_r.apply_layers(lum, L, out=out_r)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            f_r.train_filter(lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"])
+            f_r.apply_layers(lum, L, out=out_r)
+        fence()
+        tr_ = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=lum.device)
+        dist.all_reduce(tr_, op=dist.ReduceOp.MAX)
+        el_r = float(tr_.item())
+        replicas = {"value": world * (H * W / 1e6) / (el_r / args.steps), "unit": "MP/s", "scaling": "weak",
+                    "ms_per_step": el_r * 1e3 / args.steps,
+                    "what": f"{world} independent images, one per GPU, no collective in the data path"}
+        f_r.close()
+        c_r.close()
 
     # ---- SURVEY.md section 8d's metric: host plane -> host layers, median of >= 5 runs after 2 warm-ups (N = 1)
     h2h = None
@@ -372,6 +416,8 @@ def main():
                        "storage": ("fp64 tables, histograms, reductions and MFMA; fp32 output planes; V implicit" if lazy else
                                    "fp64 reductions and Gram/projection MFMA; fp32 affinities, V and outputs")},
             "host_to_host": h2h,
+            "replicas": replicas,
+            "comm": comm_kind,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": per_kernel,

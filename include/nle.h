@@ -99,6 +99,16 @@ int nle_ctx_set_mode(nle_ctx* ctx, int mode);
  * buffer of `comm_len` doubles owned by the caller, comm_len >= nle_comm_len(p).
  * world == 1 (default) needs no callback.  New in this build (the reference is
  * single-process). */
+/* Native form (preferred): the library calls RCCL itself -- ncclAllReduce, fp64 sum, IN PLACE on the ctx's stream, no
+ * staging copies and no host callback.  librccl.so is loaded on first use.  One process per GPU: rank 0 obtains an id
+ * with nle_rccl_unique_id and hands the 128 bytes to the other ranks by whatever channel the launcher has (an MPI /
+ * torch.distributed broadcast, a file); every rank then calls nle_ctx_init_rccl (collective: ncclCommInitRank).  A host
+ * that already owns a communicator for the ctx's device passes it to nle_ctx_set_rccl_comm instead (borrowed). */
+#define NLE_RCCL_UNIQUE_ID_BYTES 128
+int nle_rccl_unique_id(void* h_id, size_t size);
+int nle_ctx_init_rccl(nle_ctx* ctx, int rank, int world, const void* h_id, size_t size);
+int nle_ctx_set_rccl_comm(nle_ctx* ctx, int rank, int world, void* nccl_comm);
+/* Callback form (any transport, e.g. gloo in the CPU rehearsal tests): */
 typedef int (*nle_allreduce_fn)(void* user, void* d_buf, size_t count);
 int nle_ctx_set_shard(nle_ctx* ctx, int rank, int world, nle_allreduce_fn allreduce,
                       void* user, double* d_comm, size_t comm_len);

@@ -36,6 +36,9 @@ _SIGNATURES = {
     "nle_ctx_trim": (C.c_int, [_P]),
     "nle_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "nle_dev_free": (None, [_P, _P]),
+    "nle_rccl_unique_id": (C.c_int, [_P, C.c_size_t]),
+    "nle_ctx_init_rccl": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
+    "nle_ctx_set_rccl_comm": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "nle_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "nle_host_free": (None, [_P, _P]),
     "nle_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -141,6 +144,12 @@ def _check(status: int, ctx=None):
 # ------------------------------------------------------------------ host-only helpers
 def ld(n: int) -> int:
     return int(lib().nle_ld(int(n)))
+
+
+def rccl_unique_id() -> bytes:
+    buf = (C.c_char * 128)()
+    _check(lib().nle_rccl_unique_id(buf, 128))
+    return bytes(buf)
 
 
 def sample_grid(H, W, n_row_samples, n_col_samples):
@@ -258,6 +267,13 @@ class Context:
 
         self._cb = ALLREDUCE_FN(_cb)
         _check(lib().nle_ctx_set_shard(self._h, rank, world, self._cb, None, C.c_void_p(base), n), self._h)
+        self.rank, self.world = rank, world
+
+    def init_rccl(self, rank: int, world: int, unique_id: bytes):
+        """native RCCL all-reduces (nle_ctx_init_rccl): collective over the `world` ranks; `unique_id` = the 128 bytes of
+        rccl_unique_id() made by rank 0"""
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        _check(lib().nle_ctx_init_rccl(self._h, int(rank), int(world), buf, 128), self._h)
         self.rank, self.world = rank, world
 
     def synchronize(self):

@@ -61,7 +61,7 @@ def build_lib(force: bool = False) -> str:
                     _run([_hipcc(), "-x", "hip", "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC",
                           "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
             objs.append(o)
-        _run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lpthread"])
+        _run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lpthread", "-ldl"])
     return LIB
 
 

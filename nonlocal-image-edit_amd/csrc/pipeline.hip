@@ -3,6 +3,8 @@
 // apply (:445-458).  Small (p x p, r x r) algebra and the three symmetric eigensolves run
 // on the host in fp64; everything N-sized is a HIP kernel (kernels.hip).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <functional>
@@ -32,6 +34,8 @@ struct nle_ctx {
     int rank = 0, world = 1;
     nle_allreduce_fn allreduce = nullptr;
     void* ar_user = nullptr;
+    ncclComm_t comm = nullptr;  // native RCCL (nle_ctx_init_rccl / nle_ctx_set_rccl_comm): all-reduce in place on `stream`
+    bool own_comm = false;
     double* d_comm = nullptr;
     size_t comm_len = 0;
     std::string err;
@@ -307,8 +311,49 @@ void check_image_size(int H, int W) {
     if ((long long)H * W >= (1ll << 31)) throw Fail{NLE_ERR_INVALID, "image too large (H*W must be < 2^31)"};
 }
 
+// RCCL is loaded on first use (librccl.so is half a gigabyte: a single-GPU `enhance` never pays for it); if the host
+// process already has it (torch.distributed), dlopen by soname returns that same instance
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi& rccl() {
+    static RcclApi api;
+    if (!api.lib) {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) throw Fail{NLE_ERR_COMM, std::string("cannot load librccl.so: ") + dlerror()};
+        auto sym = [&](const char* n) {
+            void* p = dlsym(api.lib, n);
+            if (!p) throw Fail{NLE_ERR_COMM, std::string("librccl.so lacks ") + n};
+            return p;
+        };
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    }
+    return api;
+}
+#define RCCL_OK(expr)                                                                                           \
+    do {                                                                                                        \
+        ncclResult_t r_ = (expr);                                                                               \
+        if (r_ != ncclSuccess) throw Fail{NLE_ERR_COMM, std::string(#expr) + ": " + rccl().GetErrorString(r_)}; \
+    } while (0)
+
 // sum over ranks of n doubles at device pointer d (stream ordered)
 void all_reduce(nle_ctx* c, double* d, size_t n) {
+    if (c->comm) {  // native: one ncclAllReduce in place on the ctx's stream (also for world == 1: same code path)
+        RCCL_OK(rccl().AllReduce(d, d, n, ncclDouble, ncclSum, c->comm, c->stream));
+        return;
+    }
     if (c->world <= 1) return;
     if (!c->allreduce || !c->d_comm || c->comm_len < n)
         throw Fail{NLE_ERR_COMM, "world > 1 but no all-reduce callback / comm buffer too small"};
@@ -1611,6 +1656,7 @@ void nle_ctx_destroy(nle_ctx* ctx) {
     }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm && ctx->own_comm) (void)rccl().CommDestroy(ctx->comm);
     for (auto* f : ctx->filters) f->ctx = nullptr;  // their V is freed directly when they are destroyed
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     for (auto e : ctx->copy_ev)
@@ -1782,6 +1828,48 @@ int nle_ctx_set_mode(nle_ctx* ctx, int mode) {
     if (!ctx || mode < 0 || mode > NLE_MODE_MATERIALISED_F64) return NLE_ERR_INVALID;
     ctx->mode = mode;
     return NLE_OK;
+}
+
+int nle_rccl_unique_id(void* h_id, size_t size) {
+    if (!h_id || size < NCCL_UNIQUE_ID_BYTES) return NLE_ERR_INVALID;
+    return guard(nullptr, [&] {
+        ncclUniqueId id;
+        RCCL_OK(rccl().GetUniqueId(&id));
+        std::memcpy(h_id, id.internal, NCCL_UNIQUE_ID_BYTES);
+    });
+}
+
+int nle_ctx_init_rccl(nle_ctx* ctx, int rank, int world, const void* h_id, size_t size) {
+    if (!ctx || !h_id || size < NCCL_UNIQUE_ID_BYTES) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        if (world < 1 || rank < 0 || rank >= world) throw Fail{NLE_ERR_INVALID, "bad rank/world"};
+        HIP_OK(hipSetDevice(ctx->device));
+        if (ctx->comm && ctx->own_comm) (void)rccl().CommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+        ncclUniqueId id;
+        std::memcpy(id.internal, h_id, NCCL_UNIQUE_ID_BYTES);
+        ncclComm_t comm = nullptr;
+        RCCL_OK(rccl().CommInitRank(&comm, world, id, rank));
+        ctx->comm = comm;
+        ctx->own_comm = true;
+        ctx->rank = rank;
+        ctx->world = world;
+        ctx->allreduce = nullptr;
+    });
+}
+
+int nle_ctx_set_rccl_comm(nle_ctx* ctx, int rank, int world, void* comm) {
+    if (!ctx || !comm) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        if (world < 1 || rank < 0 || rank >= world) throw Fail{NLE_ERR_INVALID, "bad rank/world"};
+        (void)rccl();  // the all-reduce goes through the loaded library
+        if (ctx->comm && ctx->own_comm) (void)rccl().CommDestroy(ctx->comm);
+        ctx->comm = reinterpret_cast<ncclComm_t>(comm);
+        ctx->own_comm = false;
+        ctx->rank = rank;
+        ctx->world = world;
+        ctx->allreduce = nullptr;
+    });
 }
 
 int nle_ctx_set_shard(nle_ctx* ctx, int rank, int world, nle_allreduce_fn allreduce, void* user,

@@ -75,3 +75,33 @@ def test_sharded_ranks_match_single_rank(nle, oracle, ctx, tmp_path, world, mode
     Y_o = oracle.apply_layers(V_o, S_o, x, L).reshape(L, -1)
     for j in range(L):
         assert rel_l2(Y[j], Y_o[j]) < 1e-4, j
+
+
+@pytest.mark.gpu
+def test_native_rccl_single_rank(nle, oracle):
+    """the library's own RCCL path (nle_rccl_unique_id / nle_ctx_init_rccl: librccl.so loaded on demand, ncclAllReduce
+    in place on the ctx's stream) at world = 1 -- every all-reduce site of train and apply goes through it -- must
+    reproduce the run without a communicator bit for bit.  (More ranks need more GPUs: two ranks cannot share one
+    device in an RCCL communicator; the row-slab logic itself is covered above and in tests/test_sharding_gloo.py.)"""
+    H, W, nr, nc, hx, hy, T, K, L = 96, 128, 6, 8, 32.0, 30.0, 6, 10, 4
+    x = oracle.synthetic_luminance(H, W).astype(np.float32)
+    c0 = nle.Context(0)
+    f0 = nle.NLEFilter(c0).train_filter(x, nr, nc, hx, hy, T, K)
+    Y0 = f0.apply_layers(x, L).cpu().numpy()
+    ev0 = f0.eigvals.copy()
+    f0.close()
+    c0.close()
+    c1 = nle.Context(0)
+    uid = nle.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    c1.init_rccl(0, 1, uid)
+    for mode in (0, 4):
+        c1.set_mode(mode)
+        f1 = nle.NLEFilter(c1).train_filter(x, nr, nc, hx, hy, T, K)
+        Y1 = f1.apply_layers(x, L).cpu().numpy()
+        if mode == 0:
+            assert np.array_equal(f1.eigvals, ev0) and np.array_equal(Y1, Y0)
+        else:
+            assert rel_l2(Y1, Y0) < 1e-6
+        f1.close()
+    c1.close()
