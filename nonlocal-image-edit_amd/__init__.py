@@ -587,6 +587,8 @@ class NLEFilter:
         x = self.ctx._lum(x)
         H, W = x.shape
         fs = np.ascontiguousarray(f_s, dtype=np.float64)
+        if fs.ndim != 1 or fs.size != self.info()["K"]:   # nle_apply reads K doubles
+            raise NLEError(NLE_ERR_INVALID, f"f_s must hold K' = {self.info()['K']} values, got {fs.shape}")
         n = self.info()["n_local"]
         if out is None:
             out = torch.empty(n, dtype=torch.float32, device=x.device)

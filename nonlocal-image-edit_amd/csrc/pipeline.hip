@@ -1469,6 +1469,9 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
     if (n_eig < 1) throw Fail{NLE_ERR_INVALID, "nEigenVectors must be >= 1"};
     if (!(hx > 0) || !(hy > 0)) throw Fail{NLE_ERR_INVALID, "hx and hy must be > 0"};
     if (gs.p() > 2048) throw Fail{NLE_ERR_INVALID, "more than 2048 samples is not supported"};
+    // every rank owns at least one image row: the formulation, the collective sizes and their order are then the
+    // same on all ranks (an empty slab used to take a different path and mismatch the all-reduces)
+    if (c->world > H) throw Fail{NLE_ERR_INVALID, "more ranks than image rows"};
     // Phi-free needs <= 128 eigenvectors; its generic kernels need <= 256 samples, its table kernels
     // (quantised luminance, checked on the device below) a sample grid of at most 32 x 36.
     const bool generic_ok = gs.p() <= nlek::sink_pass_max_p() && n_eig <= 128;
@@ -1805,6 +1808,13 @@ int nle_bilateral8(nle_ctx* ctx, const float* d_src, int H, int W, double sigma_
         const int d = 2 * r + 1;
         std::vector<float> sw((size_t)d * d), cw(256);
         nle_bilateral_tables(sigma_color, sigma_space, &r, sw.data(), cw.data());
+        // the kernel indexes its 256-entry colour table with |v - v0|: the plane must hold integers 0..255 (CV_8UC1)
+        DevBuf<int> d_flag(1);
+        int flag = 1;
+        HIP_OK(nlek::check_levels(ctx->stream, d_src, (long long)H * W, d_flag.p));
+        HIP_OK(hipMemcpyAsync(&flag, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+        if (flag != 0) throw Fail{NLE_ERR_INVALID, "bilateral filter: the plane must be integer valued in [0, 255] (CV_8UC1)"};
         DevBuf<float> d_sw(sw.size()), d_cw(cw.size());
         HIP_OK(hipMemcpyAsync(d_sw.p, sw.data(), sw.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         HIP_OK(hipMemcpyAsync(d_cw.p, cw.data(), cw.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -37,10 +38,15 @@ Image read_bmp(const std::vector<unsigned char>& b) {
     const int32_t w = (int32_t)rd32(&b[18]), hraw = (int32_t)rd32(&b[22]);
     const uint16_t bpp = rd16(&b[28]);
     const uint32_t comp = rd32(&b[30]);
-    if (w <= 0 || hraw == 0 || (bpp != 24 && bpp != 32) || (comp != 0 && comp != 3)) return Image();
+    // dimensions are bounded before any arithmetic on them: a crafted header must not wrap the size check below or
+    // ask for a huge allocation (hraw == INT_MIN cannot be negated)
+    constexpr int32_t kMaxDim = 65535;
+    if (w <= 0 || w > kMaxDim || hraw == 0 || hraw < -kMaxDim || hraw > kMaxDim || (bpp != 24 && bpp != 32) ||
+        (comp != 0 && comp != 3))
+        return Image();
     const int h = hraw < 0 ? -hraw : hraw;
     const size_t stride = ((size_t)w * (bpp / 8) + 3) & ~(size_t)3;
-    if (off + stride * h > b.size()) return Image();
+    if ((size_t)off > b.size() || stride * (size_t)h > b.size() - (size_t)off) return Image();
     Image img(h, w, NLE_8U, 3);
     for (int r = 0; r < h; ++r) {
         const unsigned char* src = &b[off + stride * (size_t)(hraw < 0 ? r : h - 1 - r)];
@@ -75,7 +81,7 @@ Image read_ppm(const std::vector<unsigned char>& b) {
         return any ? v : -1;
     };
     const long w = next_int(), h = next_int(), mx = next_int();
-    if (w <= 0 || h <= 0 || mx != 255) return Image();
+    if (w <= 0 || h <= 0 || w > 65535 || h > 65535 || mx != 255) return Image();
     ++pos;  // single whitespace after maxval
     if (pos + (size_t)w * h * 3 > b.size()) return Image();
     Image img((int)h, (int)w, NLE_8U, 3);
@@ -84,6 +90,245 @@ Image read_ppm(const std::vector<unsigned char>& b) {
         d[3 * i + 0] = b[pos + 3 * i + 2];
         d[3 * i + 1] = b[pos + 3 * i + 1];
         d[3 * i + 2] = b[pos + 3 * i + 0];
+    }
+    return img;
+}
+
+// ---- PNG reader: zlib inflate (stored, fixed and dynamic Huffman blocks) + the five scanline filters.  8-bit and
+// 16-bit samples (high byte kept), grey / RGB / palette / with alpha (dropped), non-interlaced -- what `enhance` writes
+// and what common tools produce.  Interlaced files are refused.
+struct BitReader {
+    const unsigned char* p;
+    size_t n, pos = 0;
+    uint32_t bits = 0;
+    int nbits = 0;
+    bool ok = true;
+    uint32_t get(int k) {
+        while (nbits < k) {
+            if (pos >= n) {
+                ok = false;
+                return 0;
+            }
+            bits |= (uint32_t)p[pos++] << nbits;
+            nbits += 8;
+        }
+        const uint32_t v = k == 32 ? bits : (bits & ((1u << k) - 1));
+        bits = k == 32 ? 0 : bits >> k;
+        nbits -= k;
+        return v;
+    }
+};
+
+struct Huff {  // canonical Huffman decoding table (counts per length + symbols in code order)
+    uint16_t count[16] = {0}, symbol[288] = {0};
+    bool build(const unsigned char* len, int n) {
+        for (int i = 0; i < 16; ++i) count[i] = 0;
+        for (int i = 0; i < n; ++i) count[len[i]]++;
+        count[0] = 0;
+        int left = 1;
+        for (int l = 1; l < 16; ++l) {
+            left = (left << 1) - count[l];
+            if (left < 0) return false;
+        }
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
+        for (int i = 0; i < n; ++i)
+            if (len[i]) symbol[offs[len[i]]++] = (uint16_t)i;
+        return true;
+    }
+    int decode(BitReader& br) const {
+        int code = 0, first = 0, index = 0;
+        for (int l = 1; l < 16; ++l) {
+            code |= (int)br.get(1);
+            if (!br.ok) return -1;
+            const int c = count[l];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+        return -1;
+    }
+};
+
+bool inflate_zlib(const std::vector<unsigned char>& z, std::vector<unsigned char>* out, size_t expected) {
+    if (z.size() < 6 || (z[0] & 0x0f) != 8 || ((z[0] << 8) | z[1]) % 31 != 0 || (z[1] & 0x20)) return false;
+    BitReader br{z.data() + 2, z.size() - 2};
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint16_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint16_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    out->clear();
+    out->reserve(expected);
+    for (;;) {
+        const uint32_t last = br.get(1), type = br.get(2);
+        if (!br.ok) return false;
+        if (type == 0) {
+            br.bits = 0;
+            br.nbits = 0;  // skip to the byte boundary
+            if (br.pos + 4 > br.n) return false;
+            const uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
+            br.pos += 4;
+            if ((len ^ 0xffffu) != nlen || br.pos + len > br.n || out->size() + len > expected) return false;
+            out->insert(out->end(), br.p + br.pos, br.p + br.pos + len);
+            br.pos += len;
+        } else if (type == 1 || type == 2) {
+            Huff lit, dist;
+            unsigned char lens[320];
+            if (type == 1) {
+                int i = 0;
+                for (; i < 144; ++i) lens[i] = 8;
+                for (; i < 256; ++i) lens[i] = 9;
+                for (; i < 280; ++i) lens[i] = 7;
+                for (; i < 288; ++i) lens[i] = 8;
+                lit.build(lens, 288);
+                for (i = 0; i < 30; ++i) lens[i] = 5;
+                dist.build(lens, 30);
+            } else {
+                const int nlen = (int)br.get(5) + 257, ndist = (int)br.get(5) + 1, ncode = (int)br.get(4) + 4;
+                if (!br.ok || nlen > 286 || ndist > 30) return false;
+                static const unsigned char order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                unsigned char cl[19] = {0};
+                for (int i = 0; i < ncode; ++i) cl[order[i]] = (unsigned char)br.get(3);
+                Huff clh;
+                if (!br.ok || !clh.build(cl, 19)) return false;
+                int idx = 0;
+                while (idx < nlen + ndist) {
+                    const int sym = clh.decode(br);
+                    if (sym < 0) return false;
+                    if (sym < 16) {
+                        lens[idx++] = (unsigned char)sym;
+                    } else {
+                        int rep, val = 0;
+                        if (sym == 16) {
+                            if (idx == 0) return false;
+                            val = lens[idx - 1];
+                            rep = 3 + (int)br.get(2);
+                        } else if (sym == 17) {
+                            rep = 3 + (int)br.get(3);
+                        } else {
+                            rep = 11 + (int)br.get(7);
+                        }
+                        if (!br.ok || idx + rep > nlen + ndist) return false;
+                        while (rep--) lens[idx++] = (unsigned char)val;
+                    }
+                }
+                if (lens[256] == 0 || !lit.build(lens, nlen) || !dist.build(lens + nlen, ndist)) return false;
+            }
+            for (;;) {
+                const int sym = lit.decode(br);
+                if (sym < 0) return false;
+                if (sym < 256) {
+                    if (out->size() >= expected) return false;
+                    out->push_back((unsigned char)sym);
+                } else if (sym == 256) {
+                    break;
+                } else {
+                    if (sym > 285) return false;
+                    const int len = lbase[sym - 257] + (int)br.get(lext[sym - 257]);
+                    const int ds = dist.decode(br);
+                    if (ds < 0 || ds > 29) return false;
+                    const size_t d = dbase[ds] + br.get(dext[ds]);
+                    if (!br.ok || d > out->size() || out->size() + (size_t)len > expected) return false;
+                    for (int i = 0; i < len; ++i) out->push_back((*out)[out->size() - d]);
+                }
+            }
+        } else {
+            return false;
+        }
+        if (last) break;
+    }
+    return out->size() == expected;
+}
+
+uint32_t rd32be(const unsigned char* p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
+
+Image read_png(const std::vector<unsigned char>& b) {
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (b.size() < 33 || std::memcmp(b.data(), sig, 8) != 0) return Image();
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = -1;
+    std::vector<unsigned char> idat, plte;
+    size_t pos = 8;
+    bool end = false;
+    while (!end && pos + 12 <= b.size()) {
+        const uint32_t len = rd32be(&b[pos]);
+        if (len > b.size() || pos + 12 + len > b.size()) return Image();
+        const unsigned char* type = &b[pos + 4];
+        const unsigned char* data = &b[pos + 8];
+        if (!std::memcmp(type, "IHDR", 4)) {
+            if (len < 13) return Image();
+            w = rd32be(data);
+            h = rd32be(data + 4);
+            depth = data[8];
+            ctype = data[9];
+            if (data[10] != 0 || data[11] != 0 || data[12] != 0) return Image();  // interlaced: not supported
+        } else if (!std::memcmp(type, "PLTE", 4)) {
+            plte.assign(data, data + len);
+        } else if (!std::memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (!std::memcmp(type, "IEND", 4)) {
+            end = true;
+        }
+        pos += 12 + (size_t)len;
+    }
+    if (w == 0 || h == 0 || w > 65535 || h > 65535) return Image();
+    int ch;
+    switch (ctype) {
+        case 0: ch = 1; break;
+        case 2: ch = 3; break;
+        case 3: ch = 1; break;
+        case 4: ch = 2; break;
+        case 6: ch = 4; break;
+        default: return Image();
+    }
+    if (ctype == 3 ? !(depth == 1 || depth == 2 || depth == 4 || depth == 8) : !(depth == 8 || depth == 16)) return Image();
+    if (ctype == 3 && plte.size() < 3) return Image();
+    const size_t bits_pp = (size_t)ch * depth, bpp = (bits_pp + 7) / 8, stride = ((size_t)w * bits_pp + 7) / 8;
+    std::vector<unsigned char> raw;
+    if (!inflate_zlib(idat, &raw, (stride + 1) * (size_t)h)) return Image();
+    std::vector<unsigned char> prev(stride, 0), cur(stride);
+    Image img((int)h, (int)w, NLE_8U, 3);
+    for (uint32_t r = 0; r < h; ++r) {
+        const unsigned char* line = &raw[(stride + 1) * (size_t)r];
+        const int ft = line[0];
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, up = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int pred;
+            switch (ft) {
+                case 0: pred = 0; break;
+                case 1: pred = a; break;
+                case 2: pred = up; break;
+                case 3: pred = (a + up) >> 1; break;
+                case 4: {
+                    const int pa = std::abs(up - c), pb = std::abs(a - c), pc = std::abs(a + up - 2 * c);
+                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? up : c);
+                } break;
+                default: return Image();
+            }
+            cur[i] = (unsigned char)(line[1 + i] + pred);
+        }
+        unsigned char* dst = img.ptr<unsigned char>((int)r);
+        const int step = depth == 16 ? 2 : 1;
+        for (uint32_t x = 0; x < w; ++x) {
+            unsigned char R, G, B;
+            if (ctype == 3) {
+                const size_t bit = (size_t)x * depth;
+                const unsigned idx = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1);
+                if ((size_t)idx * 3 + 2 >= plte.size()) return Image();
+                R = plte[idx * 3], G = plte[idx * 3 + 1], B = plte[idx * 3 + 2];
+            } else {
+                const unsigned char* px = &cur[(size_t)x * ch * step];
+                if (ch <= 2) R = G = B = px[0];
+                else R = px[0], G = px[step], B = px[2 * step];
+            }
+            dst[3 * x + 0] = B;  // BGR like cv::imread
+            dst[3 * x + 1] = G;
+            dst[3 * x + 2] = R;
+        }
+        prev.swap(cur);
     }
     return img;
 }
@@ -149,6 +394,7 @@ Image imread(const std::string& path) {
     if (!read_file(path, &b) || b.size() < 2) return Image();
     if (b[0] == 'B' && b[1] == 'M') return read_bmp(b);
     if (b[0] == 'P' && b[1] == '6') return read_ppm(b);
+    if (b[0] == 0x89 && b[1] == 'P') return read_png(b);
     return Image();
 }
 

@@ -125,3 +125,20 @@ def test_denoise_cli_matches_the_oracle_pipeline(oracle, tmp_path):
     lab_in, lab_out = oracle.bgr_to_lab8(src).astype(int), oracle.bgr_to_lab8(got).astype(int)
     for ch in (1, 2):
         assert np.abs(np.diff(lab_out[..., ch], axis=1)).mean() <= np.abs(np.diff(lab_in[..., ch], axis=1)).mean()
+
+
+@pytest.mark.gpu
+def test_bilateral8_refuses_a_plane_that_is_not_8_bit(nle, ctx):
+    """the kernel indexes a 256-entry table with |v - v0|: a non-integer or out-of-range plane is an error, not an
+    out-of-bounds LDS read; and NLEFilter.apply checks that f_s holds K' values before the ABI reads them"""
+    x = np.full((32, 40), 17.5, dtype=np.float32)
+    with pytest.raises(nle.NLEError):
+        ctx.bilateral8(x, 10.0, 3.0)
+    x[:] = 300.0
+    with pytest.raises(nle.NLEError):
+        ctx.bilateral8(x, 10.0, 3.0)
+    y = np.random.default_rng(0).integers(0, 256, (48, 64)).astype(np.float32)
+    f = nle.NLEFilter(ctx).train_filter(y, 4, 5, 16.0, 30.0, 3, 6)
+    with pytest.raises(nle.NLEError):
+        f.apply(y, np.ones(f.info()["K"] + 1))
+    f.close()
