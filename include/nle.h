@@ -92,6 +92,14 @@ int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
 #define NLE_MODE_MATERIALISED_F64 4
 int nle_ctx_set_mode(nle_ctx* ctx, int mode);
 
+/* How orthogonalize finds the top eigenpairs of Q (src/filter.cpp:310-317).  0 (default): the reference's default build,
+ * eigenDecomposition(Q) -- a full eigensolve, the first min(nEigenVectors, kept) pairs.  1 (opt-in; also
+ * NLE_Q_SOLVER=lanczos in the environment): the reference's USE_SPECTRA build, topkEigenDecomposition (:170-199) --
+ * Lanczos for the nev = min(nEigenVectors, q - 1) pairs of largest magnitude, Krylov dimension min(2 nev, q), tolerance
+ * 1e-10, at most 1000 restarts, the FULL (not triangle-mirrored) Q, converged pairs only.  Results agree with the
+ * full solver to the tolerance; K' is capped at q - 1. */
+int nle_ctx_set_topk_solver(nle_ctx* ctx, int solver);
+
 /* Multi-GPU (one process per GPU).  Rank `rank` of `world` owns image rows
  * [rank*H/world, (rank+1)*H/world).  `allreduce(user, d_buf, count)` must sum, in place
  * and stream-ordered with the ctx's stream, `count` doubles at DEVICE pointer d_buf over
@@ -127,6 +135,10 @@ int nle_slab_rows(int H, int rank, int world, int* row0, int* row1);
  * h_U: n x n col-major (first *r columns valid), h_D: n (first *r valid). */
 int nle_eigen_decomposition(const double* h_M, int n, double eps, double* h_U, double* h_D,
                             int* r);
+/* topkEigenDecomposition, src/filter.cpp:170-199 (the USE_SPECTRA build's solver for Q): the min(n_largest, n - 1)
+ * eigenpairs of largest magnitude of the FULL n x n matrix by Lanczos (tolerance 1e-10, <= 1000 restarts), algebraic
+ * value descending, leading run >= eps kept.  h_U: n x min(n_largest, n - 1) col-major, h_D likewise; *r valid pairs. */
+int nle_topk_eigen_decomposition(const double* h_M, int n, int n_largest, double eps, double* h_U, double* h_D, int* r);
 /* transformEigenValues, src/filter.cpp:334-347 */
 int nle_transform_eigenvalues(const double* h_eigvals, int K, const double* h_weights, int L,
                               double* h_fS);

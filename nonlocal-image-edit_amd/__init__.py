@@ -36,6 +36,7 @@ _SIGNATURES = {
     "nle_ctx_trim": (C.c_int, [_P]),
     "nle_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "nle_dev_free": (None, [_P, _P]),
+    "nle_ctx_set_topk_solver": (C.c_int, [_P, C.c_int]),
     "nle_rccl_unique_id": (C.c_int, [_P, C.c_size_t]),
     "nle_ctx_init_rccl": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
     "nle_ctx_set_rccl_comm": (C.c_int, [_P, C.c_int, C.c_int, _P]),
@@ -49,6 +50,7 @@ _SIGNATURES = {
     "nle_sample_grid": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int)] * 6),
     "nle_slab_rows": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_int)] * 2),
     "nle_eigen_decomposition": (C.c_int, [_P, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),
+    "nle_topk_eigen_decomposition": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),
     "nle_transform_eigenvalues": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     "nle_layer_responses": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "nle_compute_kernel": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P]),
@@ -186,6 +188,20 @@ def eigen_decomposition(M: np.ndarray, eps: float = EPS):
     return np.ascontiguousarray(U[:, :r.value]), D[:r.value].copy()
 
 
+def topk_eigen_decomposition(M: np.ndarray, n_largest: int, eps: float = EPS):
+    """`topkEigenDecomposition` (src/filter.cpp:170-199, the USE_SPECTRA build): Lanczos top-k; returns (U, D)."""
+    M = np.asfortranarray(np.asarray(M, dtype=np.float64))
+    n = M.shape[0]
+    nev = min(int(n_largest), n - 1)
+    U = np.zeros((n, nev), dtype=np.float64, order="F")
+    D = np.zeros(nev, dtype=np.float64)
+    r = C.c_int()
+    st = lib().nle_topk_eigen_decomposition(_np_ptr(M), n, int(n_largest), float(eps), _np_ptr(U), _np_ptr(D), C.byref(r))
+    if st != NLE_OK:
+        raise NLEError(st, "Lanczos did not converge")
+    return np.ascontiguousarray(U[:, :r.value]), D[:r.value].copy()
+
+
 def transform_eigenvalues(eigvals, weights):
     """`transformEigenValues` (src/filter.cpp:334-347)."""
     ev = np.ascontiguousarray(eigvals, dtype=np.float64)
@@ -291,6 +307,10 @@ class Context:
         buf = (C.c_char * max(n, 1)).from_address(ptr.value)
         self._pinned.append(ptr)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def set_topk_solver(self, solver: int):
+        """0: full eigensolve of Q (the reference's default build); 1: Lanczos top-K (its USE_SPECTRA build)"""
+        _check(lib().nle_ctx_set_topk_solver(self._h, int(solver)), self._h)
 
     def trim(self):
         """release the cached device workspace"""

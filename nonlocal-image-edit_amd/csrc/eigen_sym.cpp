@@ -762,4 +762,137 @@ bool eigen_decomposition(const double* M, int n, double eps, double* U, double* 
     return eigen_decomposition_top(M, n, eps, n, U, D, r_out);
 }
 
+// ---- opt-in top-K solver with the semantics of the reference's USE_SPECTRA build (src/filter.cpp:170-199) ----
+// Spectra::SymEigsSolver<double, LARGEST_MAGN, DenseGenMatProd> (ext/Spectra/SymEigsBase.h): nev = min(K, n - 1),
+// ncv = min(2 nev, n), tolerance 1e-10 on the Ritz residual |beta s_mi| < tol max(eps^(2/3), |theta_i|), at most 1000
+// restarts, the wanted set is the nev Ritz values of LARGEST MAGNITUDE, the FULL matrix is multiplied (no triangle is
+// mirrored: Q is only symmetric up to the asymmetry of Wa), only converged pairs are returned, sorted by algebraic
+// value descending; the caller then keeps the leading run >= eps (:186-196).
+// Restarting is thick (Wu & Simon) instead of Spectra's implicit QR shifts: the two span the same Krylov subspaces in
+// exact arithmetic, and the converged eigenpairs agree to the tolerance either way.  Full reorthogonalisation, twice.
+int lanczos_topk(const double* A, int n, int nev_in, double tol, int max_restarts, double* U, double* D, int* restarts_out) {
+    if (n <= 1 || nev_in < 1) return 0;
+    const int nev = std::min(nev_in, n - 1), m = std::min(2 * nev, n);
+    const double eps23 = std::pow(2.220446049250313e-16, 2.0 / 3.0);
+    std::vector<double> V((size_t)n * (m + 1), 0.0), T((size_t)m * m, 0.0), w(n), S((size_t)m * m), theta(m), Vn((size_t)n * m);
+    // deterministic start vector (Spectra seeds its own generator with 0; any start reaches the same eigenpairs)
+    {
+        unsigned long long x = 0x9E3779B97F4A7C15ull;
+        double nrm = 0.0;
+        for (int i = 0; i < n; ++i) {
+            x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+            V[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+            nrm += V[i] * V[i];
+        }
+        nrm = std::sqrt(nrm);
+        for (int i = 0; i < n; ++i) V[i] /= nrm;
+    }
+    auto col = [&](int j) { return V.data() + (size_t)j * n; };
+    int k = 0, restarts = 0, nconv = 0;
+    double beta_m = 0.0;
+    std::vector<int> order(m);
+    for (;;) {
+        // extend the factorisation A V_j = V_j T_j + beta_j v_j e_j^T from k to m columns
+        for (int j = k; j < m; ++j) {
+            const double* vj = col(j);
+            for (int i = 0; i < n; ++i) w[i] = 0.0;
+            for (int c = 0; c < n; ++c) {  // w = A v_j (column-major full matrix)
+                const double x = vj[c];
+                const double* a = A + (size_t)c * n;
+#pragma omp simd
+                for (int i = 0; i < n; ++i) w[i] += a[i] * x;
+            }
+            for (int pass = 0; pass < 2; ++pass)  // Gram-Schmidt against every basis vector, twice
+                for (int c = 0; c <= j; ++c) {
+                    const double* vc = col(c);
+                    double h = 0.0;
+#pragma omp simd reduction(+ : h)
+                    for (int i = 0; i < n; ++i) h += vc[i] * w[i];
+                    if (pass == 0 && (c == j || (j == k && c < k) || c == j - 1)) {
+                        if (c == j) T[(size_t)j * m + j] += h;  // alpha_j
+                    }
+#pragma omp simd
+                    for (int i = 0; i < n; ++i) w[i] -= h * vc[i];
+                }
+            double b = 0.0;
+            for (int i = 0; i < n; ++i) b += w[i] * w[i];
+            b = std::sqrt(b);
+            if (j + 1 < m) {
+                T[(size_t)j * m + (j + 1)] = b;
+                T[(size_t)(j + 1) * m + j] = b;
+            } else {
+                beta_m = b;
+            }
+            double* vn = col(j + 1);
+            if (b > 0.0) {
+                for (int i = 0; i < n; ++i) vn[i] = w[i] / b;
+            } else {  // invariant subspace: any unit vector orthogonal to the basis continues the recursion
+                for (int i = 0; i < n; ++i) vn[i] = 0.0;
+            }
+        }
+        // Ritz pairs of the projected matrix (dense symmetric after a thick restart: diagonal + arrow + tridiagonal)
+        if (!sym_eigen(T.data(), m, S.data(), theta.data())) return -1;
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return std::fabs(theta[a]) > std::fabs(theta[b2]); });
+        nconv = 0;
+        for (int i = 0; i < nev; ++i) {
+            const int c = order[i];
+            const double resid = std::fabs(beta_m * S[(size_t)c * m + (m - 1)]);
+            if (resid < tol * std::max(eps23, std::fabs(theta[c]))) ++nconv;
+        }
+        if (nconv >= nev || restarts >= max_restarts || m >= n) break;
+        ++restarts;
+        // thick restart: keep nev + min(nconv, (m - nev) / 2) Ritz vectors (Spectra's nev_adjusted), at most m - 1
+        int keep = nev + std::min(nconv, (m - nev) / 2);
+        keep = std::max(1, std::min(keep, m - 1));
+        for (int c = 0; c < keep; ++c) {
+            const double* sc = S.data() + (size_t)order[c] * m;
+            double* out = Vn.data() + (size_t)c * n;
+            for (int i = 0; i < n; ++i) out[i] = 0.0;
+            for (int j = 0; j < m; ++j) {
+                const double x = sc[j];
+                const double* vj = col(j);
+#pragma omp simd
+                for (int i = 0; i < n; ++i) out[i] += vj[i] * x;
+            }
+        }
+        std::vector<double> tk(keep), sk(keep);
+        for (int c = 0; c < keep; ++c) {
+            tk[c] = theta[order[c]];
+            sk[c] = beta_m * S[(size_t)order[c] * m + (m - 1)];
+        }
+        std::copy(Vn.begin(), Vn.begin() + (size_t)keep * n, V.begin());
+        std::copy(col(m), col(m) + n, col(keep));  // the residual direction becomes basis vector `keep`
+        std::fill(T.begin(), T.end(), 0.0);
+        for (int c = 0; c < keep; ++c) {
+            T[(size_t)c * m + c] = tk[c];
+            T[(size_t)keep * m + c] = sk[c];
+            T[(size_t)c * m + keep] = sk[c];
+        }
+        k = keep;
+    }
+    if (restarts_out) *restarts_out = restarts;
+    // converged wanted pairs, algebraic value descending
+    std::vector<int> sel;
+    for (int i = 0; i < nev; ++i) {
+        const int c = order[i];
+        const double resid = std::fabs(beta_m * S[(size_t)c * m + (m - 1)]);
+        if (m >= n || resid < tol * std::max(eps23, std::fabs(theta[c]))) sel.push_back(c);
+    }
+    std::stable_sort(sel.begin(), sel.end(), [&](int a, int b2) { return theta[a] > theta[b2]; });
+    for (size_t q = 0; q < sel.size(); ++q) {
+        D[q] = theta[sel[q]];
+        const double* sc = S.data() + (size_t)sel[q] * m;
+        double* out = U + q * (size_t)n;
+        for (int i = 0; i < n; ++i) out[i] = 0.0;
+        for (int j = 0; j < m; ++j) {
+            const double x = sc[j];
+            const double* vj = col(j);
+#pragma omp simd
+            for (int i = 0; i < n; ++i) out[i] += vj[i] * x;
+        }
+    }
+    return (int)sel.size();
+}
+
 }  // namespace nleh

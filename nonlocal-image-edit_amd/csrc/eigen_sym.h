@@ -27,6 +27,12 @@ bool eigen_decomposition_top(const double* M, int n, double eps, int kmax, doubl
 // can run on short-lived threads.
 bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, double* D);
 
+// Opt-in top-K solver with the semantics of the reference's USE_SPECTRA build (src/filter.cpp:170-199; see eigen_sym.cpp):
+// the nev = min(nev_in, n - 1) eigenpairs of LARGEST MAGNITUDE of the FULL n x n matrix A (column-major), Krylov
+// dimension min(2 nev, n), residual tolerance `tol`, at most `max_restarts` restarts.  Returns the number of converged
+// pairs (-1: the projected eigenproblem failed), U: n x nev column-major, D sorted by algebraic value DESCENDING.
+int lanczos_topk(const double* A, int n, int nev_in, double tol, int max_restarts, double* U, double* D, int* restarts_out);
+
 // Cholesky factor of a symmetric positive definite matrix (lower triangle of M read): L is n x n
 // column-major lower triangular (zeros above the diagonal), Linv = L^-1 likewise.  Returns false if
 // a pivot is not positive.  *inv_trace = trace(M^-1) = ||Linv||_F^2, so every eigenvalue of M is at

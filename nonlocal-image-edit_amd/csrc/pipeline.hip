@@ -51,6 +51,7 @@ struct nle_ctx {
     hipStream_t copy_stream = nullptr;  // device-to-host copies of finished output layers (host-buffer entry points)
     hipEvent_t copy_ev[2] = {nullptr, nullptr};
     int mode = 0;  // nle_ctx_set_mode: 0 auto, 1 materialised Phi, 2 Phi-free, 3 Phi-free without look-up tables
+    int topk_solver = 0;  // nle_ctx_set_topk_solver: 0 full eigensolve of Q (:313-316), 1 Lanczos top-K (:170-199)
     bool profiling = false;
     bool profile_all = false;  // level 2: also the small / second-stage kernels (each timed launch costs ~10 us of gaps)
     struct ProfRec {
@@ -672,13 +673,41 @@ double now_ms() {
 // G = sum over ALL pixels of c^2 phi phi^T.  Outputs: Sq (K'), Cproj (r x K'), VArows (q x K').
 // reference src/filter.cpp:247-250 (W blocks, q = phi.cols()), :282-331 (orthogonalize).
 namespace {
+// Top eigenpairs of Q (reference src/filter.cpp:310-317).  solver 0: the default build's eigenDecomposition(Q) -- all
+// eigenvalues, the leading run >= eps counted in *rq, eigenvectors of the first min(n_eig, q) only.  solver 1: the
+// USE_SPECTRA build's topkEigenDecomposition (:170-199): nev = min(n_eig, q - 1) pairs of largest magnitude by Lanczos,
+// *rq = converged pairs in the leading run >= eps.  Vq: q x (columns formed), Sq: their eigenvalues, descending.
+void top_eigenpairs(const std::vector<double>& Qm, int q, int n_eig, int solver, std::vector<double>* Vq,
+                    std::vector<double>* Sq, int* rq) {
+    if (solver == 1 && q > 1) {
+        const int nev = std::min(std::max(n_eig, 1), q - 1);
+        Vq->assign((size_t)q * nev, 0.0);
+        Sq->assign(nev, 0.0);
+        int restarts = 0;
+        const int nconv = nleh::lanczos_topk(Qm.data(), q, nev, NLE_EPS, 1000, Vq->data(), Sq->data(), &restarts);
+        if (nconv < 0) throw Fail{NLE_ERR_NUMERIC, "Lanczos: the projected eigenproblem did not converge"};
+        if (nconv < nev)  // Spectra only warns on stderr and goes on with the converged pairs (:180-183)
+            std::fprintf(stderr, "# converged eigenvalues: %d\nEigen decomposition NOT successful. Results might be inaccurate.\n", nconv);
+        int r = 0;
+        while (r < nconv && (*Sq)[r] >= NLE_EPS) ++r;  // :186-196
+        *rq = r;
+        if (std::getenv("NLE_TRACE")) std::fprintf(stderr, "[nle trace] Lanczos top-%d of %d: %d restarts, %d converged\n", nev, q, restarts, nconv);
+        return;
+    }
+    Vq->assign((size_t)q * std::min(q, std::max(n_eig, 1)), 0.0);  // only the kept eigenvectors (:314)
+    Sq->assign(q, 0.0);
+    if (!nleh::eigen_decomposition_top(Qm.data(), q, NLE_EPS, n_eig, Vq->data(), Sq->data(), rq))
+        throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Q"};
+}
+
 struct Ortho {
     int q = 0, K = 0, r_wa = 0, r_q = 0;
     std::vector<double> Sq, Cproj, VArows, Wa;
 };
 
 Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_c,
-                         const std::vector<double>& u_r, std::vector<double> G, int n_eig, bool device_f32 = true) {
+                         const std::vector<double>& u_r, std::vector<double> G, int n_eig, bool device_f32 = true,
+                         int topk_solver = 0) {
     const int r = ny.r, q = ny.r;  // :247 -- the A block is the first q = r permuted rows
     // phi_A = V_A[:q] (exact, fp64); what the device holds for those rows is float(V_A)
     std::vector<double> cA(q), rA(q), cA32(q);
@@ -736,10 +765,9 @@ Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_
     mm(S.data(), WW.data(), T1.data(), q, q, q);
     mm(T1.data(), S.data(), Qm.data(), q, q, q);
     for (size_t i = 0; i < Qm.size(); ++i) Qm[i] += o.Wa[i];
-    std::vector<double> Vq((size_t)q * std::min(q, std::max(n_eig, 1))), Sq(q);  // only the kept eigenvectors (:314)
+    std::vector<double> Vq, Sq;
     int rq = 0;
-    if (!nleh::eigen_decomposition_top(Qm.data(), q, NLE_EPS, n_eig, Vq.data(), Sq.data(), &rq))
-        throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Q"};
+    top_eigenpairs(Qm, q, n_eig, topk_solver, &Vq, &Sq, &rq);
     const int K = std::min(n_eig, rq);  // :314
     if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
     o.K = K;
@@ -853,7 +881,7 @@ void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<do
 }
 
 // second half: needs Gk
-void ortho_ss_finish(OrthoSS& o, std::vector<double> Gk, int n_eig) {
+void ortho_ss_finish(OrthoSS& o, std::vector<double> Gk, int n_eig, int topk_solver = 0) {
     const int p = o.p, r = o.r, q = o.q;
     const std::vector<double>&cA = o.cA, &rA = o.rA, &Kr = o.Kr, &Wa = o.Wa, &S = o.S;
     for (int a = q; a < p; ++a) {  // B-block samples
@@ -876,10 +904,9 @@ void ortho_ss_finish(OrthoSS& o, std::vector<double> Gk, int n_eig) {
     mm(o.St.data(), WW.data(), T1.data(), q, q, q);
     mm(T1.data(), S.data(), Qm.data(), q, q, q);
     for (size_t i = 0; i < Qm.size(); ++i) Qm[i] += o.A2[i];  // :296
-    std::vector<double> Vq((size_t)q * std::min(q, std::max(n_eig, 1))), Sq(q);  // only the kept eigenvectors (:314)
+    std::vector<double> Vq, Sq;
     int rq = 0;
-    if (!nleh::eigen_decomposition_top(Qm.data(), q, NLE_EPS, n_eig, Vq.data(), Sq.data(), &rq))
-        throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Q"};
+    top_eigenpairs(Qm, q, n_eig, topk_solver, &Vq, &Sq, &rq);
     const int K = std::min(n_eig, rq);  // :314
     if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
     o.K = K;
@@ -975,7 +1002,7 @@ void train_materialised(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     std::vector<double> G = gram_all(c, d_phi.p, M, ny.ldr, ny.r, d_u_c.p);
     tm_g.stop();
     double h0 = now_ms();
-    Ortho o = orthogonalize_host(ny, ss.p, u_c, u_r, std::move(G), n_eig);
+    Ortho o = orthogonalize_host(ny, ss.p, u_c, u_r, std::move(G), n_eig, true, c->topk_solver);
     ms->host += now_ms() - h0;
     f->K = o.K;
     f->ldv = ld4(o.K);
@@ -1074,7 +1101,7 @@ void train_generic64(nle_ctx* c, nle_filter* f, const float* d_lum, const Sample
     std::vector<double> G = gram_all64(c, d_phi.p, M, ny.ldr, ny.r, d_u_c.p);
     tm_g.stop();
     double h0 = now_ms();
-    Ortho o = orthogonalize_host(ny, ss.p, u_c, u_r, std::move(G), n_eig, /*device_f32=*/false);
+    Ortho o = orthogonalize_host(ny, ss.p, u_c, u_r, std::move(G), n_eig, /*device_f32=*/false, c->topk_solver);
     ms->host += now_ms() - h0;
     f->K = o.K;
     f->ldv = ld4(o.K);
@@ -1292,7 +1319,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     HIP_OK(hipStreamSynchronize(c->stream));
     tr.mark("ss: gram sync");
     h0 = now_ms();
-    ortho_ss_finish(o, ghist ? std::move(tiles) : unpack_tiles(tiles, nlek::gram64_ld(p), p, 16), n_eig);
+    ortho_ss_finish(o, ghist ? std::move(tiles) : unpack_tiles(tiles, nlek::gram64_ld(p), p, 16), n_eig, c->topk_solver);
     ms->host += now_ms() - h0;
     tr.mark("ss: ortho finish (host)");
     ms->host_overlapped += h_overlapped;
@@ -1637,6 +1664,7 @@ int nle_ctx_create(int device, void* stream, nle_ctx** out) {
         HIP_OK(hipSetDevice(device));
         auto c = new nle_ctx();
         c->device = device;
+        if (const char* e = std::getenv("NLE_Q_SOLVER")) c->topk_solver = (std::string(e) == "lanczos") ? 1 : 0;
         if (stream) {
             c->stream = reinterpret_cast<hipStream_t>(stream);
         } else {
@@ -1832,6 +1860,23 @@ int nle_ctx_trim(nle_ctx* ctx) {
         ctx->arena_free.clear();
         ctx->arena_bytes = 0;
     });
+}
+
+int nle_topk_eigen_decomposition(const double* h_M, int n, int n_largest, double eps, double* h_U, double* h_D, int* r) {
+    if (!h_M || !h_U || !h_D || !r || n < 2 || n_largest < 1) return NLE_ERR_INVALID;
+    const int nev = std::min(n_largest, n - 1);  // :172
+    const int nconv = nleh::lanczos_topk(h_M, n, nev, NLE_EPS, 1000, h_U, h_D, nullptr);
+    if (nconv < 0) return NLE_ERR_NUMERIC;
+    int k = 0;
+    while (k < nconv && h_D[k] >= eps) ++k;  // :186-196
+    *r = k;
+    return NLE_OK;
+}
+
+int nle_ctx_set_topk_solver(nle_ctx* ctx, int solver) {
+    if (!ctx || solver < 0 || solver > 1) return NLE_ERR_INVALID;
+    ctx->topk_solver = solver;
+    return NLE_OK;
 }
 
 int nle_ctx_set_mode(nle_ctx* ctx, int mode) {

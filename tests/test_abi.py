@@ -139,3 +139,31 @@ def test_synthetic_generator_matches_oracle(oracle):
     assert np.array_equal(a, oracle.synthetic_luminance(37, 53))
     assert np.array_equal(synth.synthetic_luminance(37, 53, rows=(5, 20)), a[5:20])
     assert a.min() >= 0 and a.max() <= 255 and np.array_equal(a, np.rint(a))
+
+
+def test_topk_lanczos_matches_the_full_solver(nle, oracle):
+    """nle_topk_eigen_decomposition = the reference's USE_SPECTRA solver for Q (src/filter.cpp:170-199):
+    nev = min(K, n - 1) pairs of largest magnitude, tolerance 1e-10, sorted descending, cut at eps.  Against the full
+    solver (LAPACK) on matrices shaped like Q: eigenvalues in (0, 1] decaying towards a cluster at 0, a few tiny
+    negative ones, and the slight asymmetry Wa gives Q (the FULL matrix is multiplied, like Spectra's DenseGenMatProd)."""
+    rng = np.random.default_rng(3)
+    for n, K in ((40, 5), (200, 50), (200, 10), (333, 100), (64, 200), (12, 11)):
+        X = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        lam = np.concatenate([[1.0], 0.95 * 0.85 ** np.arange(n - 1)])
+        lam[n // 2:] *= 1e-6
+        lam[-3:] = [-1e-7, -2e-8, -1e-12]
+        Q = (X * lam) @ X.T
+        Q = Q + 1e-13 * np.triu(rng.standard_normal((n, n)), 1)       # not symmetric, like Wa + S (..) S
+        w, v = np.linalg.eigh((Q + Q.T) / 2)
+        w, v = w[::-1], v[:, ::-1]
+        U, D = nle.topk_eigen_decomposition(Q, K)
+        nev = min(K, n - 1)
+        want = np.sort(w[np.argsort(-np.abs(w))[:nev]])[::-1]
+        want = want[:np.argmax(want < 1e-10)] if (want < 1e-10).any() else want
+        assert D.size == want.size, (n, K, D.size, want.size)
+        assert np.all(np.diff(D) <= 0)
+        assert np.abs(D - want).max() < 1e-8
+        assert np.abs(U.T @ U - np.eye(D.size)).max() < 1e-8
+        # eigenvectors: same invariant subspaces (compare projectors on the well separated leading block)
+        kk = min(D.size, 5)
+        assert np.abs(U[:, :kk] @ U[:, :kk].T - v[:, :kk] @ v[:, :kk].T).max() < 1e-6

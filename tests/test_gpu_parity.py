@@ -443,3 +443,29 @@ def test_auto_mode_falls_back_to_the_fp64_decomposition(nle, oracle, ctx, kind):
     V = f.eigvecs().cpu().numpy()[:, :S_o.size].astype(np.float64)
     assert rel_l2(_align_signs(V, V_o), V_o) < 1e-6
     f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [SMALL_CASES[1], SMALL_CASES[4], (96, 128, 8, 10, 40.0, 30.0, 8, 79, 4)])
+def test_lanczos_topk_solver_for_Q_is_opt_in_and_agrees(nle, oracle, ctx, case):
+    """the reference's USE_SPECTRA build finds the top eigenpairs of Q by Lanczos
+    (src/filter.cpp:170-199, 310-311).  Opt-in here (nle_ctx_set_topk_solver / NLE_Q_SOLVER=lanczos); against the
+    default full solver: same K' unless K >= q (Spectra's nev = min(K, q - 1)), eigenvalues and layers to the solver's
+    tolerance."""
+    H, W, nr, nc, hx, hy, T, K, L = case
+    x = oracle.synthetic_luminance(H, W)
+    f0, Y0 = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
+    ctx.set_topk_solver(1)
+    try:
+        f1, Y1 = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
+    finally:
+        ctx.set_topk_solver(0)
+    q = f0.diag()["r_Wa"] if False else f0.diag()["r_Ka"]
+    k0, k1 = f0.info()["K"], f1.info()["K"]
+    assert k1 == min(k0, q - 1)
+    assert rel_l2(f1.eigvals, f0.eigvals[:k1]) < 1e-8
+    if k1 == k0:
+        for j in range(L):
+            assert rel_l2(Y1[j], Y0[j]) < 1e-6, j
+    f0.close()
+    f1.close()
