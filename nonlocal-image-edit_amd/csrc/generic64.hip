@@ -122,6 +122,62 @@ hipError_t ts_gemm64(hipStream_t s, const double* d_A, long long M, int lda, int
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ small dense products (p-, q-sized), fp64 MFMA
+// C(i,j) = dl[i] (sum_k A(i,k) dk[k] B(k,j)) dr[j] + add(i,j), every matrix given by (pointer, row stride, column
+// stride) so that transposes, sub-blocks and row- or column-major outputs need no copies; dl, dk, dr, add optional.
+// One wave per 16 x 16 tile of C; the k loop is unrolled four MFMA steps deep so that 8 loads are in flight.
+__global__ __launch_bounds__(256) void k_gemm64s(int m, int n, int kk, const double* __restrict__ A, long long rsA,
+                                                 long long csA, const double* __restrict__ B, long long rsB, long long csB,
+                                                 double* __restrict__ C, long long rsC, long long csC,
+                                                 const double* __restrict__ dl, const double* __restrict__ dk,
+                                                 const double* __restrict__ dr, const double* __restrict__ add,
+                                                 long long rsD, long long csD) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int ct = (n + 15) / 16, rt = (m + 15) / 16;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= rt * ct) return;  // wave-uniform
+    const int ti = t / ct, tj = t - ti * ct;
+    const int ai = ti * 16 + l15, bj = tj * 16 + l15;
+    const bool aok = ai < m, bok = bj < n;
+    const double* ap = A + (long long)ai * rsA;
+    const double* bp = B + (long long)bj * csB;
+    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < kk; k0 += 16) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 4 * u + kq;
+            const bool kok = k < kk;
+            a[u] = (aok && kok) ? ap[(long long)k * csA] * (dk ? dk[k] : 1.0) : 0.0;
+            b[u] = (bok && kok) ? bp[(long long)k * rsB] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+    if (bok) {
+        const double sr = dr ? dr[bj] : 1.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ro = ti * 16 + kq + 4 * e;
+            if (ro < m) {
+                double v = (dl ? dl[ro] : 1.0) * acc[e] * sr;
+                if (add) v += add[(long long)ro * rsD + (long long)bj * csD];
+                C[(long long)ro * rsC + (long long)bj * csC] = v;
+            }
+        }
+    }
+}
+
+hipError_t gemm64s(hipStream_t s, int m, int n, int kk, const double* A, long long rsA, long long csA, const double* B,
+                   long long rsB, long long csB, double* C, long long rsC, long long csC, const double* dl, const double* dk,
+                   const double* dr, const double* add, long long rsD, long long csD) {
+    if (m <= 0 || n <= 0) return hipSuccess;
+    const long long ntiles = (long long)((m + 15) / 16) * ((n + 15) / 16);
+    hipLaunchKernelGGL(k_gemm64s, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, s, m, n, kk, A, rsA, csA, B, rsB, csB, C, rsC,
+                       csC, dl, dk, dr, add, rsD, csD);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ one pass over X (M x ld fp64)
 // partial[b][j] = sum over the rows of block b of X[i][j] y_i;  COLSUM: y = 1;  RECIP: y_i = recip(X_i . (lam o t_in));
 // XVEC: y_i = xvec[i].  One wave per row at a time; lane l owns columns l, l + 64, ... (<= kRp64Cols per lane).
@@ -327,6 +383,17 @@ hipError_t scatter_rows64(hipStream_t s, const double* d_src, const long long* d
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_scatter_rows64, dim3((unsigned)(((long long)n * ld + 255) / 256)), dim3(256), 0, s, d_src, d_idx, n, ld,
                        d_X, M);
+    return hipGetLastError();
+}
+
+// X (m x n column-major, leading dimension m) <- diag(dl) X
+__global__ void k_scale_rows64(double* __restrict__ X, int m, int n, const double* __restrict__ dl) {
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < (long long)m * n) X[f] *= dl[f % m];
+}
+hipError_t scale_rows64(hipStream_t s, double* d_X, int m, int n, const double* d_dl) {
+    if (m <= 0 || n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scale_rows64, dim3((unsigned)(((long long)m * n + 255) / 256)), dim3(256), 0, s, d_X, m, n, d_dl);
     return hipGetLastError();
 }
 

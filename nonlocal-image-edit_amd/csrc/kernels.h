@@ -138,6 +138,11 @@ hipError_t row_scalings64(hipStream_t s, const double* d_X, long long M, int ld,
 // C (M x ldc) = diag(rs) A (M x lda, width kd) B (kd x nc column-major on the DEVICE); rs may be null
 hipError_t ts_gemm64(hipStream_t s, const double* d_A, long long M, int lda, int kd, const double* d_B, int nc,
                      const double* d_rs, double* d_C, int ldc);
+// C(i,j) = dl[i] (sum_k A(i,k) dk[k] B(k,j)) dr[j] + add(i,j); matrices by (pointer, row stride, column stride)
+hipError_t gemm64s(hipStream_t s, int m, int n, int kk, const double* A, long long rsA, long long csA, const double* B,
+                   long long rsB, long long csB, double* C, long long rsC, long long csC, const double* dl = nullptr,
+                   const double* dk = nullptr, const double* dr = nullptr, const double* add = nullptr, long long rsD = 0,
+                   long long csD = 0);
 hipError_t rowpass64(hipStream_t s, int mode, const double* d_X, long long M, int ld, const double* d_t_in,
                      const double* d_lam, const float* d_xvec, double eps, double* d_partial, int* nblocks);
 // G (r x r, full symmetric) = sum_i cs_i^2 x_i x_i^T (cs null: 1); d_partial: gram64d_partial_elems doubles
@@ -148,6 +153,7 @@ hipError_t apply_expand64(hipStream_t s, const double* d_V, long long M, int ld,
                           long long ystride);
 hipError_t scatter_rows64(hipStream_t s, const double* d_src, const long long* d_idx, int n, int ld, double* d_X, long long M);
 hipError_t to_f32(hipStream_t s, const double* d_X, long long n, float* d_out);
+hipError_t scale_rows64(hipStream_t s, double* d_X, int m, int n, const double* d_dl);  // X (m x n col-major) <- diag(dl) X
 
 // ---- level-sorted rows (sorted.hip): the pixel halves of the table passes without LDS atomics
 constexpr int kSortedThreads = 512;

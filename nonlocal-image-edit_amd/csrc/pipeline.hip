@@ -940,6 +940,164 @@ void ortho_ss_finish(OrthoSS& o, std::vector<double> Gk, int n_eig, int topk_sol
     }
 }
 
+// The same orthogonalisation with every p- and q-sized product on the GPU (generic64.hip: gemm64s, fp64 MFMA); the host
+// keeps what is inherently serial -- the two symmetric eigensolves (Wa, Q) or their Cholesky shortcut.  `d_Gk`: the local
+// Gram matrix (p x p, device); `enqueue_gram` puts the Gram kernels on the stream (they run under the host's eigensolve of
+// Wa), `reduce_gram` sums d_Gk over the ranks.  On return o.K, o.Sq, o.D, o.Vrows (host, column-major p x K), o.r_wa,
+// o.r_q, o.chol_wa are set exactly as ortho_ss_prepare + ortho_ss_finish set them.
+// At cfg4 (p = 200) this takes ~0.6 ms of 200^3 host products off the critical path, at cfg5 (p = 900) ~50 ms.
+void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std::vector<double>& sA_c,
+                     const std::vector<double>& sA_r, double* d_Gk, int n_eig, const std::function<void()>& enqueue_gram,
+                     const std::function<void()>& reduce_gram, double* host_ms, double* host_overlapped_ms, Trace& tr) {
+    const int r = ny.r, q = ny.r;
+    hipStream_t st = c->stream;
+    o.p = p;
+    o.r = r;
+    o.q = q;
+    o.cA.resize(p);
+    o.rA.resize(p);
+    for (int a = 0; a < p; ++a) {
+        o.cA[a] = recip0(sA_c[a]);
+        o.rA[a] = recip0(sA_r[a]);
+    }
+    const size_t pp = (size_t)p * p, qq = (size_t)q * q;
+    DevBuf<double> d_rA(p), d_cA(p), d_Kr, d_P, d_VA, d_lam;
+    HIP_OK(hipMemcpyAsync(d_rA.p, o.rA.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_cA.p, o.cA.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
+    if (ny.chol) {
+        o.Kr = ny.Ka;  // r == p: Kr = Ka, P = I
+    } else {  // Kr = V_r L V_r^T, P = V_r V_r^T on the device; Kr comes back for Wa
+        d_VA.alloc((size_t)p * r);
+        d_lam.alloc(r);
+        d_Kr.alloc(pp);
+        HIP_OK(hipMemcpyAsync(d_VA.p, ny.VA.data(), (size_t)p * r * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_OK(nlek::gemm64s(st, p, p, r, d_VA.p, 1, p, d_VA.p, p, 1, d_Kr.p, 1, p, nullptr, d_lam.p));
+        if (r < p) {
+            d_P.alloc(pp);
+            HIP_OK(nlek::gemm64s(st, p, p, r, d_VA.p, 1, p, d_VA.p, p, 1, d_P.p, 1, p));
+        }
+        o.Kr.resize(pp);
+        HIP_OK(hipMemcpyAsync(o.Kr.data(), d_Kr.p, pp * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+    }
+    enqueue_gram();
+    // ---- host: Wa and the factor of its (pseudo-)inverse, under the Gram kernels
+    double h0 = now_ms();
+    o.Wa.resize(qq);
+    for (int b = 0; b < q; ++b)
+        for (int a = 0; a < q; ++a) o.Wa[(size_t)b * q + a] = o.rA[a] * o.Kr[(size_t)b * p + a] * o.cA[b];  // :249
+    // (see ortho_ss_prepare for why any root of the pseudo-inverse serves and when Cholesky is admissible)
+    std::vector<double> L, Li, U2, Us;
+    int r2 = 0;
+    bool chol_wa = false;
+    double inv_diag = 0.0;
+    for (int a = 0; a < q; ++a) inv_diag += o.Wa[(size_t)a * q + a] > 0.0 ? 1.0 / o.Wa[(size_t)a * q + a] : 1e300;
+    if (std::getenv("NLE_FORCE_EIG") == nullptr && inv_diag <= kCholMaxInvTrace) {
+        L.resize(qq);
+        Li.resize(qq);
+        double inv_trace = 0.0;
+        chol_wa = nleh::cholesky_with_inverse(o.Wa.data(), q, L.data(), Li.data(), &inv_trace) && inv_trace <= kCholMaxInvTrace;
+    }
+    if (!chol_wa) {
+        std::vector<double> Uf(qq), l2(q);
+        if (!nleh::eigen_decomposition(o.Wa.data(), q, NLE_EPS, Uf.data(), l2.data(), &r2))
+            throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Wa"};
+        U2.assign(Uf.begin(), Uf.begin() + (size_t)q * std::max(r2, 1));
+        Us.resize((size_t)q * std::max(r2, 1));
+        for (int k = 0; k < r2; ++k) {
+            const double sv = std::sqrt(recip0(l2[k]));
+            for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * sv;
+        }
+        if (std::getenv("NLE_TRACE"))
+            fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e)\n", r2, q, l2[0],
+                    r2 > 0 ? l2[r2 - 1] : 0.0);
+    }
+    o.r_wa = chol_wa ? q : r2;
+    o.chol_wa = chol_wa;
+    *host_overlapped_ms += now_ms() - h0;
+    tr.mark("ss: Wa root (host, under the Gram kernels)");
+    // ---- device: S (q x q; S^T = St), A2, then Q = A2 + St diag(rA) Gk' diag(rA) S
+    DevBuf<double> d_Wa(qq), d_F, d_G2, d_S(qq), d_A2, d_T(pp), d_T1(qq), d_Qm(qq);
+    HIP_OK(hipMemcpyAsync(d_Wa.p, o.Wa.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));
+    const double* A2 = d_Wa.p;  // :296 (the solver reads the lower triangle of the sum)
+    long long rsS = 1, csS = q;  // S(i,j) at i*rsS + j*csS
+    if (chol_wa) {  // S = L^-T: the transposed view of L^-1; A2 = L^T L
+        d_F.alloc(qq);
+        d_G2.alloc(qq);
+        d_A2.alloc(qq);
+        HIP_OK(hipMemcpyAsync(d_S.p, Li.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));  // holds St = L^-1
+        HIP_OK(hipMemcpyAsync(d_F.p, L.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_OK(nlek::gemm64s(st, q, q, q, d_F.p, q, 1, d_F.p, 1, q, d_A2.p, 1, q));
+        A2 = d_A2.p;
+        rsS = q;
+        csS = 1;
+    } else {  // S = Us U2^T (symmetric)
+        const int rk = std::max(r2, 1);
+        d_F.alloc((size_t)q * rk);
+        d_G2.alloc((size_t)q * rk);
+        HIP_OK(hipMemcpyAsync(d_F.p, Us.data(), (size_t)q * rk * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(d_G2.p, U2.data(), (size_t)q * rk * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_OK(nlek::gemm64s(st, q, q, r2, d_F.p, 1, q, d_G2.p, q, 1, d_S.p, 1, q));
+    }
+    reduce_gram();
+    if (q < p) {  // samples that fall in the B block: Gk += Kr[:, q:] diag(cA[q:]^2) Kr[:, q:]^T
+        std::vector<double> c2(p - q);
+        for (int a = q; a < p; ++a) c2[a - q] = o.cA[a] * o.cA[a];
+        DevBuf<double> d_c2(p - q);
+        HIP_OK(hipMemcpyAsync(d_c2.p, c2.data(), (p - q) * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_OK(nlek::gemm64s(st, p, p, p - q, d_Kr.p + (size_t)q * p, 1, p, d_Kr.p + (size_t)q * p, p, 1, d_Gk, 1, p, nullptr,
+                             d_c2.p, nullptr, d_Gk, 1, p));
+        HIP_OK(hipStreamSynchronize(st));  // c2 (host) is consumed
+    }
+    if (r < p) {  // Gk' = P Gk P
+        HIP_OK(nlek::gemm64s(st, p, p, p, d_P.p, 1, p, d_Gk, 1, p, d_T.p, 1, p));
+        HIP_OK(nlek::gemm64s(st, p, p, p, d_T.p, 1, p, d_P.p, 1, p, d_Gk, 1, p));
+    }
+    // T1 = St diag(rA) Gk'[:q,:q]   (St(i,k) = S(k,i));   Qm = T1 diag(rA) S + A2   (:296)
+    HIP_OK(nlek::gemm64s(st, q, q, q, d_S.p, csS, rsS, d_Gk, 1, p, d_T1.p, 1, q, nullptr, d_rA.p));
+    HIP_OK(nlek::gemm64s(st, q, q, q, d_T1.p, 1, q, d_S.p, rsS, csS, d_Qm.p, 1, q, nullptr, d_rA.p, nullptr, A2, 1, q));
+    std::vector<double> Qm(qq);
+    HIP_OK(hipMemcpyAsync(Qm.data(), d_Qm.p, qq * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    tr.mark("ss: Q on the device + download");
+    // ---- host: top eigenpairs of Q
+    h0 = now_ms();
+    std::vector<double> Vq, Sq;
+    int rq = 0;
+    top_eigenpairs(Qm, q, n_eig, c->topk_solver, &Vq, &Sq, &rq);
+    const int K = std::min(n_eig, rq);  // :314
+    if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
+    o.K = K;
+    o.r_q = rq;
+    o.Sq.assign(Sq.begin(), Sq.begin() + K);
+    std::vector<double> sv(K);
+    for (int k = 0; k < K; ++k) sv[k] = std::sqrt(recip0(Sq[k]));  // :319-321
+    *host_ms += now_ms() - h0;
+    tr.mark("ss: eig(Q) (host)");
+    // ---- device: T2 = S Vq Sq^-1/2, D = P[:, :q] diag(rA) T2, Vrows = [Wa T2; diag(cA_B) Kr_B D]
+    DevBuf<double> d_Vq((size_t)q * K), d_sv(K), d_T2((size_t)q * K), d_D((size_t)p * K), d_Vr((size_t)p * K);
+    HIP_OK(hipMemcpyAsync(d_Vq.p, Vq.data(), (size_t)q * K * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_sv.p, sv.data(), K * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_OK(nlek::gemm64s(st, q, K, q, d_S.p, rsS, csS, d_Vq.p, 1, q, d_T2.p, 1, q, nullptr, nullptr, d_sv.p));
+    if (r < p) {
+        HIP_OK(nlek::gemm64s(st, p, K, q, d_P.p, 1, p, d_T2.p, 1, q, d_D.p, 1, p, nullptr, d_rA.p));  // first q columns of P
+    } else {  // P = I, q == p: D = diag(rA) T2 (a product with the 1 x 1 identity scales the rows)
+        HIP_OK(hipMemcpyAsync(d_D.p, d_T2.p, (size_t)q * K * sizeof(double), hipMemcpyDeviceToDevice, st));  // q == p here
+        HIP_OK(nlek::scale_rows64(st, d_D.p, p, K, d_rA.p));
+    }
+    HIP_OK(nlek::gemm64s(st, q, K, q, d_Wa.p, 1, q, d_T2.p, 1, q, d_Vr.p, 1, p));  // top block of :327
+
+    if (q < p)
+        HIP_OK(nlek::gemm64s(st, p - q, K, p, d_Kr.p + q, 1, p, d_D.p, 1, p, d_Vr.p + q, 1, p, d_cA.p + q));
+    o.D.resize((size_t)p * K);
+    o.Vrows.resize((size_t)p * K);
+    HIP_OK(hipMemcpyAsync(o.D.data(), d_D.p, o.D.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(o.Vrows.data(), d_Vr.p, o.Vrows.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    tr.mark("ss: D, Vrows on the device");
+}
+
 // unpack the upper-triangular 32x32 tile list of gram()/gram_fused() into a symmetric n x n matrix
 std::vector<double> unpack_tiles(const std::vector<double>& tiles, int ld, int n, int ts) {
     std::vector<double> G((size_t)n * n, 0.0);
@@ -1292,6 +1450,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     const int ntiles = nlek::gram64_num_tiles(p);
     const size_t g_elems = ghist ? (size_t)p * p : (size_t)ntiles * 256;
     DevBuf<double> d_gpart, d_tiles(g_elems);
+    auto enqueue_gram = [&] {
     if (M <= 0) {
         HIP_OK(hipMemsetAsync(d_tiles.p, 0, g_elems * sizeof(double), c->stream));
     } else if (ghist) {
@@ -1305,8 +1464,16 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         PROFILED(c, NLE_K_GRAM, nlek::gram64(c->stream, d_lum, ss.gs, d_samples.p, p, nsw, npw, pix0, M, d_cbuf.p,
                                              d_gpart.p, d_tiles.p));
     }
-    double h0 = now_ms();
+    };
     OrthoSS o;
+    if (ghist && std::getenv("NLE_HOST_ORTHO") == nullptr) {
+        // the Gram kernels were enqueued above; the q-sized products run on the device, the eigensolves on the host
+        ortho_ss_device(c, o, ny, p, sA_c, sA_r, d_tiles.p, n_eig, enqueue_gram, [&] { all_reduce(c, d_tiles.p, g_elems); },
+                        &ms->host, &ms->host_overlapped, tr);
+        tm_g.stop();
+    } else {
+    enqueue_gram();
+    double h0 = now_ms();
     ortho_ss_prepare(o, ny, p, sA_c, sA_r);  // host, while the Gram kernel runs
     const double h_overlapped = now_ms() - h0;
     tr.mark("ss: ortho prepare (host)");
@@ -1323,6 +1490,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     ms->host += now_ms() - h0;
     tr.mark("ss: ortho finish (host)");
     ms->host_overlapped += h_overlapped;
+    }
     f->K = o.K;
     f->ldv = ld4(o.K);
     f->eigvals = o.Sq;
