@@ -164,6 +164,7 @@ struct SortedRows {
     const double* E;              // [W + 1] exp(-d^2 / hx^2)
 };
 int sorted_max_width();
+size_t sorted_scol_elems(int W, int nrows_local);  // allocation size of SortedRows::scol (padded for the prefetch)
 int sorted_gram_max_cols();
 hipError_t dist_table(hipStream_t s, int W, double hx, double* d_E);
 hipError_t sort_rows(hipStream_t s, const float* d_lum, GridSpec gs, int row0, int nrows_local, unsigned short* d_scol,

@@ -988,7 +988,7 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     for (int b = 0; b < q; ++b)
         for (int a = 0; a < q; ++a) o.Wa[(size_t)b * q + a] = o.rA[a] * o.Kr[(size_t)b * p + a] * o.cA[b];  // :249
     // (see ortho_ss_prepare for why any root of the pseudo-inverse serves and when Cholesky is admissible)
-    std::vector<double> L, Li, U2, Us;
+    std::vector<double> L, Li, U2, Us, l2_kept;
     int r2 = 0;
     bool chol_wa = false;
     double inv_diag = 0.0;
@@ -1004,6 +1004,7 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
         if (!nleh::eigen_decomposition(o.Wa.data(), q, NLE_EPS, Uf.data(), l2.data(), &r2))
             throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Wa"};
         U2.assign(Uf.begin(), Uf.begin() + (size_t)q * std::max(r2, 1));
+        l2_kept.assign(l2.begin(), l2.begin() + r2);
         Us.resize((size_t)q * std::max(r2, 1));
         for (int k = 0; k < r2; ++k) {
             const double sv = std::sqrt(recip0(l2[k]));
@@ -1017,29 +1018,29 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     o.chol_wa = chol_wa;
     *host_overlapped_ms += now_ms() - h0;
     tr.mark("ss: Wa root (host, under the Gram kernels)");
-    // ---- device: S (q x q; S^T = St), A2, then Q = A2 + St diag(rA) Gk' diag(rA) S
-    DevBuf<double> d_Wa(qq), d_F, d_G2, d_S(qq), d_A2, d_T(pp), d_T1(qq), d_Qm(qq);
+    // ---- device: with a factor F of the (pseudo-)inverse of A = sym-lower(Wa), F F^T = A^+, the matrix the reference
+    // diagonalises, Q = Wa + S (Wab Wab^T) S with S = A^+1/2 (:296), is similar on range(A) to
+    //     Qt = F^T A^2 F + F^T WW F          (m x m, m = number of eigenvalues of Wa kept by the cut, :287)
+    // and T2 = S Vq Sq^-1/2 = F Vt Sq^-1/2 for Qt's eigenvectors Vt (:324-327).  Eigensolver form: F = U2 L2^-1/2,
+    // F^T A^2 F = L2 (diagonal); Cholesky form (no eigenvalue cut): F = L^-T, F^T A^2 F = L^T L.  On the subspace the
+    // cut removed, Q acts as Wa alone -- eigenvalues < 1e-10, cut again at :313 -- so nothing is lost, and the rounding
+    // of the S (..) S products (entries of S reach 1e5) can no longer lift one of them back over the cut.
+    const int m = chol_wa ? q : std::max(r2, 0);
+    if (m <= 0) throw Fail{NLE_ERR_NUMERIC, "Wa has no eigenvalue >= 1e-10"};
+    const size_t mm_ = (size_t)m * m;
+    DevBuf<double> d_Wa(qq), d_F((size_t)q * m), d_L, d_T(pp), d_T1((size_t)m * q), d_Qm(mm_);
     HIP_OK(hipMemcpyAsync(d_Wa.p, o.Wa.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));
-    const double* A2 = d_Wa.p;  // :296 (the solver reads the lower triangle of the sum)
-    long long rsS = 1, csS = q;  // S(i,j) at i*rsS + j*csS
-    if (chol_wa) {  // S = L^-T: the transposed view of L^-1; A2 = L^T L
-        d_F.alloc(qq);
-        d_G2.alloc(qq);
-        d_A2.alloc(qq);
-        HIP_OK(hipMemcpyAsync(d_S.p, Li.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));  // holds St = L^-1
-        HIP_OK(hipMemcpyAsync(d_F.p, L.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_OK(nlek::gemm64s(st, q, q, q, d_F.p, q, 1, d_F.p, 1, q, d_A2.p, 1, q));
-        A2 = d_A2.p;
-        rsS = q;
-        csS = 1;
-    } else {  // S = Us U2^T (symmetric)
-        const int rk = std::max(r2, 1);
-        d_F.alloc((size_t)q * rk);
-        d_G2.alloc((size_t)q * rk);
-        HIP_OK(hipMemcpyAsync(d_F.p, Us.data(), (size_t)q * rk * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemcpyAsync(d_G2.p, U2.data(), (size_t)q * rk * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_OK(nlek::gemm64s(st, q, q, r2, d_F.p, 1, q, d_G2.p, q, 1, d_S.p, 1, q));
+    std::vector<double> F;  // q x m column-major
+    if (chol_wa) {
+        F.resize(qq);
+        for (int k = 0; k < q; ++k)
+            for (int a = 0; a < q; ++a) F[(size_t)k * q + a] = Li[(size_t)a * q + k];  // L^-T
+        d_L.alloc(qq);
+        HIP_OK(hipMemcpyAsync(d_L.p, L.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));
+    } else {
+        F = Us;
     }
+    HIP_OK(hipMemcpyAsync(d_F.p, F.data(), (size_t)q * m * sizeof(double), hipMemcpyHostToDevice, st));
     reduce_gram();
     if (q < p) {  // samples that fall in the B block: Gk += Kr[:, q:] diag(cA[q:]^2) Kr[:, q:]^T
         std::vector<double> c2(p - q);
@@ -1054,18 +1055,26 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
         HIP_OK(nlek::gemm64s(st, p, p, p, d_P.p, 1, p, d_Gk, 1, p, d_T.p, 1, p));
         HIP_OK(nlek::gemm64s(st, p, p, p, d_T.p, 1, p, d_P.p, 1, p, d_Gk, 1, p));
     }
-    // T1 = St diag(rA) Gk'[:q,:q]   (St(i,k) = S(k,i));   Qm = T1 diag(rA) S + A2   (:296)
-    HIP_OK(nlek::gemm64s(st, q, q, q, d_S.p, csS, rsS, d_Gk, 1, p, d_T1.p, 1, q, nullptr, d_rA.p));
-    HIP_OK(nlek::gemm64s(st, q, q, q, d_T1.p, 1, q, d_S.p, rsS, csS, d_Qm.p, 1, q, nullptr, d_rA.p, nullptr, A2, 1, q));
-    std::vector<double> Qm(qq);
-    HIP_OK(hipMemcpyAsync(Qm.data(), d_Qm.p, qq * sizeof(double), hipMemcpyDeviceToHost, st));
+    // T1 = F^T diag(rA) Gk'[:q,:q]  (m x q);   Qt = T1 diag(rA) F (+ L^T L in the Cholesky form; + diag(l2) on the host)
+    HIP_OK(nlek::gemm64s(st, m, q, q, d_F.p, q, 1, d_Gk, 1, p, d_T1.p, 1, m, nullptr, d_rA.p));
+    if (chol_wa) {
+        DevBuf<double> d_A2(qq);
+        HIP_OK(nlek::gemm64s(st, q, q, q, d_L.p, q, 1, d_L.p, 1, q, d_A2.p, 1, q));
+        HIP_OK(nlek::gemm64s(st, m, m, q, d_T1.p, 1, m, d_F.p, 1, q, d_Qm.p, 1, m, nullptr, d_rA.p, nullptr, d_A2.p, 1, q));
+    } else {
+        HIP_OK(nlek::gemm64s(st, m, m, q, d_T1.p, 1, m, d_F.p, 1, q, d_Qm.p, 1, m, nullptr, d_rA.p));
+    }
+    std::vector<double> Qm(mm_);
+    HIP_OK(hipMemcpyAsync(Qm.data(), d_Qm.p, mm_ * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     tr.mark("ss: Q on the device + download");
-    // ---- host: top eigenpairs of Q
+    // ---- host: top eigenpairs of Qt
     h0 = now_ms();
+    if (!chol_wa)
+        for (int k = 0; k < m; ++k) Qm[(size_t)k * m + k] += l2_kept[k];
     std::vector<double> Vq, Sq;
     int rq = 0;
-    top_eigenpairs(Qm, q, n_eig, c->topk_solver, &Vq, &Sq, &rq);
+    top_eigenpairs(Qm, m, n_eig, c->topk_solver, &Vq, &Sq, &rq);
     const int K = std::min(n_eig, rq);  // :314
     if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
     o.K = K;
@@ -1075,19 +1084,18 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     for (int k = 0; k < K; ++k) sv[k] = std::sqrt(recip0(Sq[k]));  // :319-321
     *host_ms += now_ms() - h0;
     tr.mark("ss: eig(Q) (host)");
-    // ---- device: T2 = S Vq Sq^-1/2, D = P[:, :q] diag(rA) T2, Vrows = [Wa T2; diag(cA_B) Kr_B D]
-    DevBuf<double> d_Vq((size_t)q * K), d_sv(K), d_T2((size_t)q * K), d_D((size_t)p * K), d_Vr((size_t)p * K);
-    HIP_OK(hipMemcpyAsync(d_Vq.p, Vq.data(), (size_t)q * K * sizeof(double), hipMemcpyHostToDevice, st));
+    // ---- device: T2 = F Vt Sq^-1/2, D = P[:, :q] diag(rA) T2, Vrows = [Wa T2; diag(cA_B) Kr_B D]
+    DevBuf<double> d_Vq((size_t)m * K), d_sv(K), d_T2((size_t)q * K), d_D((size_t)p * K), d_Vr((size_t)p * K);
+    HIP_OK(hipMemcpyAsync(d_Vq.p, Vq.data(), (size_t)m * K * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d_sv.p, sv.data(), K * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_OK(nlek::gemm64s(st, q, K, q, d_S.p, rsS, csS, d_Vq.p, 1, q, d_T2.p, 1, q, nullptr, nullptr, d_sv.p));
+    HIP_OK(nlek::gemm64s(st, q, K, m, d_F.p, 1, q, d_Vq.p, 1, m, d_T2.p, 1, q, nullptr, nullptr, d_sv.p));
     if (r < p) {
         HIP_OK(nlek::gemm64s(st, p, K, q, d_P.p, 1, p, d_T2.p, 1, q, d_D.p, 1, p, nullptr, d_rA.p));  // first q columns of P
-    } else {  // P = I, q == p: D = diag(rA) T2 (a product with the 1 x 1 identity scales the rows)
-        HIP_OK(hipMemcpyAsync(d_D.p, d_T2.p, (size_t)q * K * sizeof(double), hipMemcpyDeviceToDevice, st));  // q == p here
+    } else {  // P = I, q == p: D = diag(rA) T2
+        HIP_OK(hipMemcpyAsync(d_D.p, d_T2.p, (size_t)q * K * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIP_OK(nlek::scale_rows64(st, d_D.p, p, K, d_rA.p));
     }
     HIP_OK(nlek::gemm64s(st, q, K, q, d_Wa.p, 1, q, d_T2.p, 1, q, d_Vr.p, 1, p));  // top block of :327
-
     if (q < p)
         HIP_OK(nlek::gemm64s(st, p - q, K, p, d_Kr.p + q, 1, p, d_D.p, 1, p, d_Vr.p + q, 1, p, d_cA.p + q));
     o.D.resize((size_t)p * K);
@@ -1349,7 +1357,9 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     DevBuf<double> d_E;
     nlek::SortedRows sr{};
     if (sorted) {
-        d_scol.alloc((size_t)nrows_local * ss.gs.W);
+        d_scol.alloc(nlek::sorted_scol_elems(ss.gs.W, nrows_local));
+        HIP_OK(hipMemsetAsync(d_scol.p + (size_t)nrows_local * ss.gs.W, 0,
+                              (d_scol.n - (size_t)nrows_local * ss.gs.W) * sizeof(unsigned short), c->stream));
         d_first.alloc((size_t)nrows_local * 258);
         d_desc.alloc((size_t)nrows_local * nlek::kSortedThreads);
         d_E.alloc((size_t)ss.gs.W + 1);

@@ -31,8 +31,20 @@ constexpr int kLevels = 256;
 constexpr int kT = kSortedThreads;
 constexpr int kSortThreads = 256;
 
+// inplaceReciprocal, src/filter.cpp:42-54.  v_rcp_f64 + two Newton steps (|s| >= eps = 1e-10 keeps every step in range):
+// 1 ulp, 6 instructions instead of the 13 of the IEEE division sequence -- these kernels are instruction-issue bound
 __device__ __forceinline__ double recip0_d(double s, double eps) {
-    return (fabs(s) >= eps) ? 1.0 / s : 0.0;  // inplaceReciprocal, src/filter.cpp:42-54
+    double r = __builtin_amdgcn_rcp(s);
+    r = fma(fma(-s, r, 1.0), r, r);
+    r = fma(fma(-s, r, 1.0), r, r);
+    return (fabs(s) >= eps) ? r : 0.0;
+}
+
+// byte offset of E[|c - c_b|] in the LDS table from the pre-scaled 16-bit operands c8 = 8 c, cb8 = 8 c_b (8 W <= 65536):
+// one v_sad_u16 instead of subtract / negate / max / shift
+__device__ __forceinline__ double e_at(const double* sE, unsigned c8, unsigned cb8) {
+    const unsigned off = __builtin_amdgcn_sad_u16(c8, cb8, 0u);
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sE) + off);
 }
 
 // block-wide sum / max of one int per thread (256 threads), result in every thread; `red`: 8 ints of LDS
@@ -73,8 +85,8 @@ hipError_t dist_table(hipStream_t s, int W, double hx, double* d_E) {
 // ------------------------------------------------------------------ once per train: sort every row by level
 // One workgroup (256 threads) per local image row.  Sample pixels are left out (the N-sized sums skip them: their Phi
 // rows are the exact V_A rows, reference :275).  Outputs, per row:
-//   scol[W]    columns in (level, column) order -- a STABLE counting sort, so that the summation order of every later
-//              pass is a function of the image alone;
+//   scol[W]    8 x column (the byte offset the pass kernels feed to v_sad_u16) in (level, column) order -- a STABLE
+//              counting sort, so that the summation order of every later pass is a function of the image alone;
 //   desc[kT]   one chunk per pass thread: x = start | stride << 16, y = len | level << 16 (len 0: idle thread);
 //   first[258] first[x] = first chunk of level x (x = 0..256), first[257] = number of tree steps = ceil(log2(max m)).
 __global__ __launch_bounds__(kSortThreads) void k_sort_rows(const float* __restrict__ lum, GridSpec gs, int row0,
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_rows(const float* __restr
         if (valid) {
             int prev = 0;
             for (int w2 = 0; w2 < wave; ++w2) prev += cntG[w2][x];
-            srow[off[x] + run[x] + prev + rank] = (unsigned short)c;
+            srow[off[x] + run[x] + prev + rank] = (unsigned short)(c << 3);  // pre-scaled: 8 c (W <= 8192)
         }
         __syncthreads();
         run[tid] += cntG[0][tid] + cntG[1][tid] + cntG[2][tid] + cntG[3][tid];
@@ -186,6 +198,10 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_rows(const float* __restr
     unsigned short* out = scol + (size_t)lrow * W;
     for (int i = tid; i < W; i += kSortThreads) out[i] = i < wn ? srow[i] : (unsigned short)0;
 }
+
+// elements of the scol buffer: the pass kernels prefetch column indices up to two chunk strides (<= 2 x 512 entries)
+// past a thread's chunk, i.e. past the last row's end
+size_t sorted_scol_elems(int W, int nrows_local) { return (size_t)std::max(nrows_local, 0) * W + 2 * kSortedThreads + 8; }
 
 hipError_t sort_rows(hipStream_t s, const float* d_lum, GridSpec gs, int row0, int nrows_local, unsigned short* d_scol,
                      uint2* d_desc, unsigned short* d_first) {
@@ -260,16 +276,24 @@ __global__ __launch_bounds__(kT) void k_sorted_pass(int mode, const unsigned sho
             acc[b] = 0.0;
         }
         __syncthreads();  // sE / sfirst visible; the previous row's reads of sP are done
+        // software pipeline: the (dependent) loads of pixel t + 1 -- its column index, and in the apply its c and x --
+        // are issued, unconditionally, before pixel t is processed
         const unsigned short* sc = scol + (size_t)lrow * W + start;
+        const double* cv_row = cvec ? cvec + (size_t)lrow * W : nullptr;
+        const float* xv_row = xvec ? xvec + (size_t)(row0 + lrow) * W : nullptr;
+        // (the index loads run up to two chunk strides past the chunk: scol is padded for that, sort_rows_elems)
+        unsigned c8 = sc[0], c8n = sc[stride];
+        double yx = (mode == ROWPASS_XVEC) ? cv_row[c8 >> 3] * (double)xv_row[c8 >> 3] : 1.0;
         for (int t = 0; t < len; ++t) {
-            const int c = sc[t * stride];
+            const unsigned c8nn = sc[(t + 2) * stride];
+            const double yxn = (mode == ROWPASS_XVEC) ? cv_row[c8n >> 3] * (double)xv_row[c8n >> 3] : 1.0;
             double e[KEEP_E ? NC : 1];
             double y = 1.0;
             if (mode == ROWPASS_RECIP) {
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                 for (int b = 0; b < NC; ++b) {
-                    const double ev = sE[__sad(c, cb0 + b * cs, 0u)];
+                    const double ev = e_at(sE, c8, (unsigned)(cb0 + b * cs) << 3);
                     if constexpr (KEEP_E) e[b] = ev;
                     if (b & 1) s1 += ev * gv[b];
                     else s0 += ev * gv[b];
@@ -278,17 +302,19 @@ __global__ __launch_bounds__(kT) void k_sorted_pass(int mode, const unsigned sho
             } else {
                 if constexpr (KEEP_E) {
 #pragma unroll
-                    for (int b = 0; b < NC; ++b) e[b] = sE[__sad(c, cb0 + b * cs, 0u)];
+                    for (int b = 0; b < NC; ++b) e[b] = e_at(sE, c8, (unsigned)(cb0 + b * cs) << 3);
                 }
-                if (mode == ROWPASS_XVEC)  // apply: y_i = c_i x_i
-                    y = cvec[(size_t)lrow * W + c] * (double)xvec[(size_t)(row0 + lrow) * W + c];
+                if (mode == ROWPASS_XVEC) y = yx;  // apply: y_i = c_i x_i
             }
-            if (ybuf != nullptr) ybuf[(size_t)lrow * W + c] = y;
+            if (ybuf != nullptr) ybuf[(size_t)lrow * W + (c8 >> 3)] = y;
 #pragma unroll
             for (int b = 0; b < NC; ++b) {
                 if constexpr (KEEP_E) acc[b] += e[b] * y;
-                else acc[b] += sE[__sad(c, cb0 + b * cs, 0u)] * y;
+                else acc[b] += e_at(sE, c8, (unsigned)(cb0 + b * cs) << 3) * y;
             }
+            c8 = c8n;
+            c8n = c8nn;
+            yx = yxn;
         }
         const int steps = sfirst[kLevels + 1], j = tid - sfirst[x], m = stride;
         double* hrow = hout + (size_t)lrow * n;
@@ -373,17 +399,23 @@ __global__ __launch_bounds__(kT) void k_sorted_gram(const unsigned short* __rest
         for (int i = 0; i < NP; ++i) acc[i] = 0.0;
         __syncthreads();
         const unsigned short* sc = scol + (size_t)lrow * W + start;
-        for (int t = 0; t < len; ++t) {
-            const int c = sc[t * stride];
-            const double cf = cvec[(size_t)lrow * W + c];
+        const double* cv_row = cvec + (size_t)lrow * W;
+        unsigned c8 = sc[0], c8n = sc[stride];
+        double cf = cv_row[c8 >> 3];
+        for (int t = 0; t < len; ++t) {  // loads of pixel t + 1 (and the index of t + 2) in flight under pixel t
+            const unsigned c8nn = sc[(t + 2) * stride];
+            const double cfn = cv_row[c8n >> 3];
             double q[NC];
 #pragma unroll
-            for (int b = 0; b < NC; ++b) q[b] = cf * sE[__sad(c, cb0 + b * cs, 0u)];
+            for (int b = 0; b < NC; ++b) q[b] = cf * e_at(sE, c8, (unsigned)(cb0 + b * cs) << 3);
             int idx = 0;
 #pragma unroll
             for (int b = 0; b < NC; ++b)
 #pragma unroll
                 for (int b2 = b; b2 < NC; ++b2) acc[idx++] += q[b] * q[b2];
+            c8 = c8n;
+            c8n = c8nn;
+            cf = cfn;
         }
         const int steps = sfirst[kLevels + 1], j = tid - sfirst[x], m = stride;
         double* out = Aout + (size_t)lrow * kLevels * NP;

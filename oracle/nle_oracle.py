@@ -128,7 +128,8 @@ def eigen_decomposition(M: np.ndarray, eps: float = EPS, info: list | None = Non
         r += 1
     if info is not None:
         info.append(dict(n=int(D.size), kept=r, last_kept=float(D[r - 1]) if r else None,
-                         first_dropped=float(D[r]) if r < D.size else None))
+                         first_dropped=float(D[r]) if r < D.size else None,
+                         near_cut=[float(v) for v in D if 0.9 * eps <= v <= 1.1 * eps]))
     if force_rank is not None:
         r = int(force_rank)
     return np.ascontiguousarray(U[:, :r]), D[:r].copy()
