@@ -135,6 +135,10 @@ int nle_slab_rows(int H, int rank, int world, int* row0, int* row1);
  * h_U: n x n col-major (first *r columns valid), h_D: n (first *r valid). */
 int nle_eigen_decomposition(const double* h_M, int n, double eps, double* h_U, double* h_D,
                             int* r);
+/* the same when only the first kmax eigenvectors are wanted (orthogonalize keeps nEigVectors columns of Q's, :313-316):
+ * h_D receives ALL n eigenvalues (descending), h_U (n x min(kmax, n)) the first min(kmax, n) eigenvectors, *r the length
+ * of the leading run >= eps.  For kmax <= n / 2 the eigenvectors come from inverse iteration on the tridiagonal form. */
+int nle_eigen_decomposition_top(const double* h_M, int n, double eps, int kmax, double* h_U, double* h_D, int* r);
 /* topkEigenDecomposition, src/filter.cpp:170-199 (the USE_SPECTRA build's solver for Q): the min(n_largest, n - 1)
  * eigenpairs of largest magnitude of the FULL n x n matrix by Lanczos (tolerance 1e-10, <= 1000 restarts), algebraic
  * value descending, leading run >= eps kept.  h_U: n x min(n_largest, n - 1) col-major, h_D likewise; *r valid pairs. */

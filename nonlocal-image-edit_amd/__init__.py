@@ -50,6 +50,7 @@ _SIGNATURES = {
     "nle_sample_grid": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int)] * 6),
     "nle_slab_rows": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_int)] * 2),
     "nle_eigen_decomposition": (C.c_int, [_P, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),
+    "nle_eigen_decomposition_top": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, _P, _P, C.POINTER(C.c_int)]),
     "nle_topk_eigen_decomposition": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),
     "nle_transform_eigenvalues": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     "nle_layer_responses": (C.c_int, [_P, C.c_int, C.c_int, _P]),
@@ -186,6 +187,20 @@ def eigen_decomposition(M: np.ndarray, eps: float = EPS):
     if st != NLE_OK:
         raise NLEError(st, "eigensolver did not converge")
     return np.ascontiguousarray(U[:, :r.value]), D[:r.value].copy()
+
+
+def eigen_decomposition_top(M: np.ndarray, kmax: int, eps: float = EPS):
+    """all eigenvalues (descending) and the first min(kmax, n) eigenvectors: (U [n x min(kmax, n)], D [n], r)"""
+    M = np.asfortranarray(np.asarray(M, dtype=np.float64))
+    n = M.shape[0]
+    k = min(int(kmax), n)
+    U = np.zeros((n, k), dtype=np.float64, order="F")
+    D = np.zeros(n, dtype=np.float64)
+    r = C.c_int()
+    st = lib().nle_eigen_decomposition_top(_np_ptr(M), n, float(eps), int(kmax), _np_ptr(U), _np_ptr(D), C.byref(r))
+    if st != NLE_OK:
+        raise NLEError(st, "eigensolver did not converge")
+    return np.ascontiguousarray(U), D, r.value
 
 
 def topk_eigen_decomposition(M: np.ndarray, n_largest: int, eps: float = EPS):

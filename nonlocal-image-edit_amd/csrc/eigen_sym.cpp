@@ -659,6 +659,113 @@ int default_threads(int n, int) {
     return n >= 512 ? 8 : 1;
 }
 
+// Eigenvectors of the symmetric tridiagonal T (diagonal d[0..n), sub-diagonal e[1..n)) for k of its eigenvalues
+// lam[0..k), given in DESCENDING order and accurate to rounding, by inverse iteration -- the scheme of LAPACK's dstein:
+// LU of T - lam I with partial pivoting (tiny pivots perturbed), a few solves from a pseudo-random start, vectors of
+// eigenvalues closer than 1e-3 ||T|| re-orthogonalised against each other (modified Gram-Schmidt, twice).  O(n k)
+// instead of the O(n^2 k)-ish rotation sweeps: what sym_eigen_top uses when only the leading part of the spectrum is
+// wanted (orthogonalize keeps K of q eigenvectors, src/filter.cpp:314).  Z: n x k column-major.  false: a vector did not
+// reach a residual of 1e3 eps ||T|| (the caller falls back to the rotation form).
+bool tridiag_inverse_iteration(int n, const double* d, const double* e, const double* lam, int k, double* Z) {
+    const double eps = std::ldexp(1.0, -52);
+    double onenrm = 0.0;
+    for (int i = 0; i < n; ++i)
+        onenrm = std::max(onenrm, std::fabs(d[i]) + (i > 0 ? std::fabs(e[i]) : 0.0) + (i + 1 < n ? std::fabs(e[i + 1]) : 0.0));
+    if (onenrm == 0.0) onenrm = 1.0;
+    const double ortol = 1e-3 * onenrm, tiny = eps * onenrm;
+    std::vector<double> a(n), b(n), c(n), dd(n), x(n), y(n);
+    std::vector<char> piv(n);
+    int gp = 0;  // first vector of the current cluster
+    double prev = 0.0;
+    unsigned long long seed = 0x2545F4914F6CDD1Dull;
+    for (int j = 0; j < k; ++j) {
+        double xj = lam[j];
+        if (j > 0) {
+            if (std::fabs(lam[j] - lam[j - 1]) > ortol) gp = j;
+            const double pertol = 10.0 * eps * std::max(std::fabs(xj), tiny);
+            if (prev - xj < pertol) xj = prev - pertol;  // keep the shifts distinct (descending order)
+        }
+        prev = xj;
+        // LU of T - xj I with partial pivoting: row k holds (a, b, dd), multipliers in c
+        for (int i = 0; i < n; ++i) {
+            a[i] = d[i] - xj;
+            b[i] = (i + 1 < n) ? e[i + 1] : 0.0;
+            c[i] = (i + 1 < n) ? e[i + 1] : 0.0;
+            dd[i] = 0.0;
+        }
+        for (int i = 0; i + 1 < n; ++i) {
+            if (std::fabs(a[i]) >= std::fabs(c[i])) {
+                if (std::fabs(a[i]) < tiny) a[i] = std::copysign(tiny, a[i] == 0.0 ? 1.0 : a[i]);
+                const double mult = c[i] / a[i];
+                a[i + 1] -= mult * b[i];
+                c[i] = mult;
+                piv[i] = 0;
+            } else {
+                const double mult = a[i] / c[i];
+                a[i] = c[i];
+                const double t = a[i + 1];
+                a[i + 1] = b[i] - mult * t;
+                if (i + 2 < n) {
+                    dd[i] = b[i + 1];
+                    b[i + 1] = -mult * dd[i];
+                }
+                b[i] = t;
+                c[i] = mult;
+                piv[i] = 1;
+            }
+        }
+        if (std::fabs(a[n - 1]) < tiny) a[n - 1] = std::copysign(tiny, a[n - 1] == 0.0 ? 1.0 : a[n - 1]);
+        for (int i = 0; i < n; ++i) {
+            seed ^= seed << 13, seed ^= seed >> 7, seed ^= seed << 17;
+            x[i] = (double)(seed >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+        }
+        double* z = Z + (size_t)j * n;
+        bool ok = false;
+        for (int it = 0; it < 8 && !ok; ++it) {
+            // scale the right-hand side so that the solve cannot overflow (dstein: ||x||_1 = n ||T|| max(eps, |u_nn|))
+            double s1 = 0.0;
+            for (int i = 0; i < n; ++i) s1 += std::fabs(x[i]);
+            const double scl = n * onenrm * std::max(eps, std::fabs(a[n - 1])) / std::max(s1, 1e-300);
+            for (int i = 0; i < n; ++i) y[i] = x[i] * scl;
+            for (int i = 0; i + 1 < n; ++i) {  // forward: apply the row interchanges and multipliers
+                if (piv[i]) std::swap(y[i], y[i + 1]);
+                y[i + 1] -= c[i] * y[i];
+            }
+            for (int i = n - 1; i >= 0; --i) {  // back substitution with the three upper diagonals
+                double t = y[i];
+                if (i + 1 < n) t -= b[i] * x[i + 1];
+                if (i + 2 < n) t -= dd[i] * x[i + 2];
+                x[i] = t / a[i];
+            }
+            for (int pass = 0; pass < 2; ++pass)  // the cluster's earlier vectors
+                for (int q = gp; q < j; ++q) {
+                    const double* zq = Z + (size_t)q * n;
+                    double h = 0.0;
+                    for (int i = 0; i < n; ++i) h += zq[i] * x[i];
+                    for (int i = 0; i < n; ++i) x[i] -= h * zq[i];
+                }
+            double nrm = 0.0;
+            for (int i = 0; i < n; ++i) nrm += x[i] * x[i];
+            nrm = std::sqrt(nrm);
+            if (!(nrm > 0.0) || !std::isfinite(nrm)) return false;
+            for (int i = 0; i < n; ++i) x[i] /= nrm;
+            if (it >= 1) {  // residual ||(T - lam I) x||_2 against the ORIGINAL eigenvalue
+                double res = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    double t = (d[i] - lam[j]) * x[i];
+                    if (i > 0) t += e[i] * x[i - 1];
+                    if (i + 1 < n) t += e[i + 1] * x[i + 1];
+                    res += t * t;
+                }
+                ok = std::sqrt(res) <= 1e3 * eps * onenrm;
+            }
+        }
+        if (!ok) return false;
+        std::copy(x.begin(), x.end(), z);
+    }
+    return true;
+}
+
 bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, double* D) {
     if (n <= 0) return true;
     ncols = std::max(0, std::min(ncols, n));
@@ -672,6 +779,7 @@ bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, d
     for (int c = 0; c < n; ++c)  // mirror the lower triangle (SelfAdjointEigenSolver reads only the lower one)
         for (int r = 0; r < n; ++r) V[(size_t)c * n + r] = (r >= c) ? M[(size_t)c * n + r] : M[(size_t)r * n + c];
     tridiag_reduce(n, V.data(), d.data(), e.data(), hs.data());
+    const std::vector<double> d0(d), e0(e);  // T itself (the QL iteration overwrites d and e)
     std::vector<Sweep> sweeps;
     std::vector<double> cs, sn;
     cs.reserve((size_t)n * n);
@@ -684,6 +792,17 @@ bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, d
     std::reverse(idx.begin(), idx.end());
     for (int j = 0; j < n; ++j) D[j] = d[idx[j]];
     if (ncols == 0) return true;
+    if (2 * ncols <= n && std::getenv("NLE_EIG_NO_INVIT") == nullptr) {
+        // a leading part of the spectrum only: inverse iteration on T for those eigenvalues, then the back-transformation
+        if (tridiag_inverse_iteration(n, d0.data(), e0.data(), D, ncols, U)) {
+            const int cparts0 = std::max(1, std::min(nthreads, (ncols + 3) / 4));
+            run_split(cparts0, nthreads, [&](int q) {
+                const int j0 = (int)((long long)ncols * q / cparts0), j1 = (int)((long long)ncols * (q + 1) / cparts0);
+                back_transform_cols(n, V.data(), hs.data(), U, j0, j1);
+            });
+            return true;
+        }
+    }
     const int ldz = (n + 7) & ~7;  // rows padded to whole 8-row vectors (the padding stays zero)
     // (64-byte aligned: the 64-row blocks of different threads then never share a cache line)
     std::vector<double> Zbuf((size_t)ldz * n + 8, 0.0);

@@ -2040,6 +2040,11 @@ int nle_ctx_trim(nle_ctx* ctx) {
     });
 }
 
+int nle_eigen_decomposition_top(const double* h_M, int n, double eps, int kmax, double* h_U, double* h_D, int* r) {
+    if (!h_M || !h_U || !h_D || !r || n < 1 || kmax < 1) return NLE_ERR_INVALID;
+    return nleh::eigen_decomposition_top(h_M, n, eps, kmax, h_U, h_D, r) ? NLE_OK : NLE_ERR_NUMERIC;
+}
+
 int nle_topk_eigen_decomposition(const double* h_M, int n, int n_largest, double eps, double* h_U, double* h_D, int* r) {
     if (!h_M || !h_U || !h_D || !r || n < 2 || n_largest < 1) return NLE_ERR_INVALID;
     const int nev = std::min(n_largest, n - 1);  // :172

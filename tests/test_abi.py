@@ -167,3 +167,35 @@ def test_topk_lanczos_matches_the_full_solver(nle, oracle):
         # eigenvectors: same invariant subspaces (compare projectors on the well separated leading block)
         kk = min(D.size, 5)
         assert np.abs(U[:, :kk] @ U[:, :kk].T - v[:, :kk] @ v[:, :kk].T).max() < 1e-6
+
+
+def test_leading_eigenvectors_by_inverse_iteration(nle):
+    """nle_eigen_decomposition_top with kmax <= n / 2 takes the eigenvectors from inverse iteration on the tridiagonal
+    form (csrc/eigen_sym.cpp): against LAPACK on spectra like Q's (decaying from 1), with tight clusters, with exactly
+    repeated eigenvalues (the tridiagonal splits), on a diagonal matrix, and with the spectrum of a truncated Wa."""
+    rng = np.random.default_rng(9)
+    cases = []
+    for n, k in ((200, 50), (200, 10), (64, 32), (333, 100), (30, 3)):
+        lam = np.concatenate([[1.0], 0.97 * 0.9 ** np.arange(n - 1)])
+        cases.append(("decay", n, k, lam))
+    n = 120
+    lam = np.sort(np.concatenate([1.0 - 1e-9 * np.arange(6), 0.5 + 1e-12 * np.arange(5), rng.uniform(0, 0.4, n - 11)]))[::-1]
+    cases.append(("clusters", n, 40, lam))
+    lam = np.sort(np.concatenate([[0.9] * 4, [0.7] * 3, rng.uniform(0, 0.5, 93)]))[::-1]
+    cases.append(("repeated", 100, 20, lam))
+    cases.append(("wa", 200, 60, 1.5e-5 * 0.9 ** np.arange(200)))
+    for name, n, k, lam in cases:
+        X = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        A = (X * lam) @ X.T
+        A = (A + A.T) / 2
+        U, D, r = nle.eigen_decomposition_top(A, k)
+        w = np.linalg.eigvalsh(A)[::-1]
+        scale = np.abs(w).max()
+        assert np.abs(D - w).max() < 1e-13 * scale * n, name
+        assert U.shape == (n, k)
+        assert np.abs(U.T @ U - np.eye(k)).max() < 1e-10, (name, np.abs(U.T @ U - np.eye(k)).max())
+        res = np.abs(A @ U - U * D[:k]).max()
+        assert res < 1e-12 * scale * n, (name, res)
+    A = np.diag(np.linspace(1.0, 0.01, 50))
+    U, D, r = nle.eigen_decomposition_top(A, 7)
+    assert np.abs(np.abs(U[:7, :7]) - np.eye(7)).max() < 1e-12
