@@ -1128,31 +1128,41 @@ __global__ __launch_bounds__(256) void k_apply_small(int p, int K, int ldk, int 
                                                      const float* __restrict__ x, const long long* __restrict__ sample_pix,
                                                      const double* __restrict__ resp, double* __restrict__ t_out,
                                                      double* __restrict__ Wp, double* __restrict__ YA) {
+    // one workgroup per layer l = blockIdx.x; each recomputes t (K values, p terms each: cheaper than a second launch)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* sm = reinterpret_cast<double*>(smem_raw);  // [p]
     double* sx = sm + p;                                // [p]
     double* st = sx + p;                                // [K]
-    const int tid = threadIdx.x;
+    double* sp = st + K;                                // [G][KP] partial sums of t
+    const int tid = threadIdx.x, l = blockIdx.x;
+    const int KP = K <= 64 ? 64 : 128, G = 256 / KP;
     for (int a = tid; a < p; a += 256) {
         sm[a] = m[a];
         sx[a] = (double)x[sample_pix[a]];
     }
     __syncthreads();
-    for (int k = tid; k < K; k += 256) {
+    {
+        const int k = tid % KP, g = tid / KP;
         double s0 = 0.0, s1 = 0.0;
-        for (int a = 0; a < p; ++a) {
-            s0 += Dm[(size_t)a * ldk + k] * sm[a];
-            s1 += Vrows[(size_t)a * ldk + k] * sx[a];
-        }
-        st[k] = s0 + s1;
-        t_out[k] = s0 + s1;
+        if (k < K)
+            for (int a = g; a < p; a += G) {
+                s0 += Dm[(size_t)a * ldk + k] * sm[a];
+                s1 += Vrows[(size_t)a * ldk + k] * sx[a];
+            }
+        sp[g * KP + k] = s0 + s1;
     }
     __syncthreads();
-    for (int o = tid; o < L * ldw; o += 256) {
-        const int l = o / ldw, a = o - l * ldw;
+    for (int k = tid; k < K; k += 256) {
+        double s = 0.0;
+        for (int g = 0; g < G; ++g) s += sp[g * KP + k];  // fixed order
+        st[k] = s;
+        if (l == 0) t_out[k] = s;
+    }
+    __syncthreads();
+    const double* rl = resp + (size_t)l * K;
+    for (int a = tid; a < ldw; a += 256) {
         double w = 0.0, ya = 0.0;
         if (a < p) {
-            const double* rl = resp + (size_t)l * K;
             for (int k = 0; k < K; ++k) {
                 const double gk = rl[k] * st[k];
                 w += Dm[(size_t)a * ldk + k] * gk;
@@ -1160,7 +1170,7 @@ __global__ __launch_bounds__(256) void k_apply_small(int p, int K, int ldk, int 
             }
             YA[(size_t)l * p + a] = ya;
         }
-        Wp[o] = w;
+        Wp[(size_t)l * ldw + a] = w;
     }
 }
 
@@ -1177,8 +1187,13 @@ __global__ void k_scatter_samples(int p, int L, const long long* __restrict__ lo
 // (nR x slab_rows) x (slab_rows x 256 nC) product on the fp64 MFMA.  One wave per 16 columns and slab; the
 // slab's 16 row loads of a lane are independent, so they are all in flight together.
 // grid (ceil(16 nC / 4), nslabs), slab_rows == 64.
+// Epilogue: instead of storing the slab's HH tile (and re-reading all of them in a k_hist_z pass), the wave contracts its
+// 16 levels with Ep on the spot: zpart[slab][x tile][a, b] = sum_{x in tile} Ep[x][a, b] HH[a][b, x]; a fixed-order reduce
+// over the slabs and the 16 level tiles (reduce_partials) then gives z.  26 MB of HH written and read per pass become
+// < 1 MB of partials, and one launch goes away.
 __global__ __launch_bounds__(256) void k_hist_hh(int nC, int nR, int nrows, int slab_rows, const double* __restrict__ er,
-                                                 const double* __restrict__ h, double* __restrict__ HH) {
+                                                 const double* __restrict__ h, const double* __restrict__ Ep, int p, int ldp,
+                                                 double* __restrict__ zpart) {
     const int n = kLevels * nC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int n0 = (blockIdx.x * 4 + wave) * 16;
@@ -1207,43 +1222,66 @@ __global__ __launch_bounds__(256) void k_hist_hh(int nC, int nR, int nrows, int 
             }
         }
     }
-    if (col_ok) {
-        double* out = HH + (size_t)blockIdx.y * n * nR + col;  // [slab][a][col]
+    // table columns are b-major (col = b * 256 + x) and a wave's 16 columns share b: lane (l15, kq) holds, for its level
+    // x = x0 + l15, the sums of sample rows a = kq + 4 e (and 16 + kq + 4 e)
+    const int b = n0 / kLevels, x = (n0 & (kLevels - 1)) + l15, xt = (n0 & (kLevels - 1)) >> 4;
+    double v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int a0 = kq + 4 * e, a1 = 16 + kq + 4 * e;
+        v[e] = (col_ok && a0 < nR) ? acc0[e] * Ep[(size_t)x * p + a0 * nC + b] : 0.0;
+        v[4 + e] = (two && col_ok && a1 < nR) ? acc1[e] * Ep[(size_t)x * p + a1 * nC + b] : 0.0;
+    }
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1)  // sum over the 16 levels of the tile (lanes l15 of one kq group), fixed tree
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += __shfl_xor(v[e], off);
+    if (l15 == 0 && col_ok) {
+        double* out = zpart + ((size_t)blockIdx.y * (kLevels / 16) + xt) * ldp;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int a = kq + 4 * e;
-            if (a < nR) out[(size_t)a * n] = acc0[e];
-            if (two && 16 + a < nR) out[(size_t)(16 + a) * n] = acc1[e];
+            const int a0 = kq + 4 * e, a1 = 16 + kq + 4 * e;
+            if (a0 < nR) out[a0 * nC + b] = v[e];
+            if (two && a1 < nR) out[a1 * nC + b] = v[4 + e];
         }
     }
 }
 
-// one block per sample s = (a, b); thread = level x; fixed-order block reduction
-__global__ __launch_bounds__(256) void k_hist_z(int p, int ldp, int nC, int nR, int nslabs, const double* __restrict__ Ep,
-                                                const double* __restrict__ HH, double* __restrict__ z) {
-    __shared__ double sm[kLevels];
-    const int sidx = blockIdx.x, x = threadIdx.x;
-    if (sidx >= p) {
-        if (x == 0) z[sidx] = 0.0;
-        return;
-    }
-    const int a = sidx / nC, b = sidx - a * nC, n = kLevels * nC;
-    double hs = 0.0;
-    for (int sl = 0; sl < nslabs; ++sl) hs += HH[((size_t)sl * nR + a) * n + (size_t)b * kLevels + x];
-    sm[x] = Ep[(size_t)x * p + sidx] * hs;
+// z[s] = sum over the nparts (slab, level tile) partial rows, in a fixed order; columns s >= p come out as 0.
+// 8 columns x 32 row groups per workgroup: ldp / 8 workgroups, each thread adds nparts / 32 values.
+__global__ __launch_bounds__(256) void k_z_reduce(const double* __restrict__ zpart, int nparts, int p, int ldp,
+                                                  double* __restrict__ z) {
+    __shared__ double sm[32][8];
+    const int c = threadIdx.x & 7, g = threadIdx.x >> 3, col = blockIdx.x * 8 + c;
+    double s = 0.0;
+    if (col < p)
+        for (int r = g; r < nparts; r += 32) s += zpart[(size_t)r * ldp + col];
+    sm[g][c] = s;
     __syncthreads();
-    for (int off = kLevels / 2; off > 0; off >>= 1) {
-        if (x < off) sm[x] += sm[x + off];
-        __syncthreads();
+    if (g == 0 && col < ldp) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += sm[k][c];
+        z[col] = t;
     }
-    if (x == 0) z[sidx] = sm[0];
 }
 
 int hist_tiled_max_rows_samples() { return 32; }
+// image rows per slab of the HH stage: enough slabs to fill the chip's 1024 SIMDs about four times over with one wave
+// per (16 table columns, slab), no more -- k_hist_z reads every slab's HH again (cfg4: 128 rows, 32 slabs, 5120 waves)
+static int hist_slab_rows(GridSpec gs, int nrows_local) {
+    const int ncoltiles = kLevels * gs.nSelCols / 16;
+    const int want = std::max(1, (4096 + ncoltiles - 1) / ncoltiles);   // slabs wanted
+    int rows = (nrows_local + want - 1) / want;
+    rows = std::max(64, ((rows + 31) / 32) * 32);
+    return rows;
+}
 size_t hist_tiled_workspace_elems(GridSpec gs, int nrows_local) {
     const size_t n = (size_t)kLevels * gs.nSelCols;
-    const int nslabs = (nrows_local + 63) / 64;
-    return 2 * (size_t)nrows_local * n + (size_t)nslabs * n * gs.nSelRows;
+    const int sr = hist_slab_rows(gs, nrows_local);
+    const int nslabs = (nrows_local + sr - 1) / sr;
+    const size_t ldp = ((size_t)gs.nSelRows * gs.nSelCols + 63) & ~(size_t)63;
+    return 2 * (size_t)nrows_local * n + (size_t)nslabs * std::max(n * gs.nSelRows, (size_t)(kLevels / 16) * ldp);
 }
 
 // one Sinkhorn half-iteration, tiled form; d_ws: hist_tiled_workspace_elems doubles; d_z: ldp doubles
@@ -1259,7 +1297,7 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
         ~Scope() { if (o) o->end(); }
     };
     const size_t n = (size_t)kLevels * nC;
-    const int slab_rows = 64, nslabs = (nrows_local + slab_rows - 1) / slab_rows;
+    const int slab_rows = hist_slab_rows(gs, nrows_local), nslabs = (nrows_local + slab_rows - 1) / slab_rows;
     double* d_g = d_ws;
     double* d_h = d_g + (size_t)nrows_local * n;
     double* d_HH = d_h + (size_t)nrows_local * n;
@@ -1304,8 +1342,8 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
     }
     Scope sc(obs, SUB_HIST_HH);
     hipLaunchKernelGGL(k_hist_hh, dim3((unsigned)((n / 16 + 3) / 4), (unsigned)nslabs), dim3(256), 0, s, nC, nR,
-                       nrows_local, slab_rows, d_er, d_h, d_HH);
-    hipLaunchKernelGGL(k_hist_z, dim3((unsigned)ldp), dim3(kLevels), 0, s, p, ldp, nC, nR, nslabs, d_Ep, d_HH, d_z);
+                       nrows_local, slab_rows, d_er, d_h, d_Ep, p, ldp, d_HH);
+    hipLaunchKernelGGL(k_z_reduce, dim3((unsigned)((ldp + 7) / 8)), dim3(256), 0, s, d_HH, nslabs * (kLevels / 16), p, ldp, d_z);
     return hipGetLastError();
 }
 
@@ -1358,8 +1396,8 @@ hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int
 hipError_t apply_small(hipStream_t s, int p, int K, int ldk, int L, int ldw, const double* d_m, const double* d_D,
                        const double* d_Vrows, const float* d_x, const long long* d_sample_pix, const double* d_resp,
                        double* d_t, double* d_Wp, double* d_YA) {
-    const size_t shm = (size_t)(2 * p + K) * sizeof(double);
-    hipLaunchKernelGGL(k_apply_small, dim3(1), dim3(256), shm, s, p, K, ldk, L, ldw, d_m, d_D, d_Vrows, d_x,
+    const size_t shm = (size_t)(2 * p + K + 256) * sizeof(double);
+    hipLaunchKernelGGL(k_apply_small, dim3((unsigned)L), dim3(256), shm, s, p, K, ldk, L, ldw, d_m, d_D, d_Vrows, d_x,
                        d_sample_pix, d_resp, d_t, d_Wp, d_YA);
     return hipGetLastError();
 }
