@@ -822,6 +822,44 @@ bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, d
     return true;
 }
 
+// All eigenvalues (DESCENDING, in D) and the eigenvectors of D[first .. first + count) only (U: n x count): the reduction
+// without the orthogonal factor, QL on (d, e) for the values, inverse iteration on T for the selected vectors, and their
+// back-transformation.  What the deflated root of Wa needs: the few eigenpairs the 1e-10 cut removes (pipeline.hip).
+bool sym_eigen_select(const double* M, int n, double* D, int first, int count, double* U, double below_eps, int max_below,
+                      int* kept_out) {
+    if (n <= 0) return true;
+    if (n == 1) {
+        D[0] = M[0];
+        if (count > 0) U[0] = 1.0;
+        return true;
+    }
+    std::vector<double> V((size_t)n * n), d(n), e(n), hs(n);
+    for (int c = 0; c < n; ++c)  // mirror the lower triangle (SelfAdjointEigenSolver reads only the lower one)
+        for (int r = 0; r < n; ++r) V[(size_t)c * n + r] = (r >= c) ? M[(size_t)c * n + r] : M[(size_t)r * n + c];
+    tridiag_reduce(n, V.data(), d.data(), e.data(), hs.data());
+    const std::vector<double> d0(d), e0(e);
+    std::vector<Sweep> sweeps;
+    std::vector<double> cs, sn;
+    cs.reserve((size_t)n * n);
+    sn.reserve((size_t)n * n);
+    if (!ql_record(n, d.data(), e.data(), sweeps, cs, sn)) return false;
+    std::sort(d.begin(), d.end(), [](double a, double b) { return a > b; });
+    std::copy(d.begin(), d.end(), D);
+    if (kept_out) {  // select the eigenvalues after the leading run >= below_eps, if there are at most max_below of them
+        int kept = 0;
+        while (kept < n && D[kept] >= below_eps) ++kept;
+        *kept_out = kept;
+        first = kept;
+        count = (n - kept <= max_below) ? n - kept : 0;
+    }
+    first = std::max(0, std::min(first, n));
+    count = std::max(0, std::min(count, n - first));
+    if (count == 0) return true;
+    if (!tridiag_inverse_iteration(n, d0.data(), e0.data(), D + first, count, U)) return false;
+    back_transform_cols(n, V.data(), hs.data(), U, 0, count);
+    return true;
+}
+
 // All eigenvectors on one thread: the classic reduction WITH accumulation of the orthogonal factor (cheaper than
 // back-transforming n vectors one reflector at a time), then the recorded rotations applied to it by cache-resident
 // row blocks instead of column pair by column pair.  U: n x n, D: n, both ASCENDING like sym_eigen.

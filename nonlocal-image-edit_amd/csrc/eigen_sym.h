@@ -27,6 +27,13 @@ bool eigen_decomposition_top(const double* M, int n, double eps, int kmax, doubl
 // can run on short-lived threads.
 bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, double* D);
 
+// All n eigenvalues DESCENDING in D and the eigenvectors of D[first .. first + count) in U (n x count), the latter by
+// inverse iteration on the tridiagonal form (cheap when count << n).  false: no convergence.
+// kept_out != null: the selection is instead "every eigenvalue after the leading run >= below_eps", made only if there
+// are at most max_below of them (*kept_out = length of that run; U must hold n x max_below).
+bool sym_eigen_select(const double* M, int n, double* D, int first, int count, double* U, double below_eps = 0.0,
+                      int max_below = 0, int* kept_out = nullptr);
+
 // Opt-in top-K solver with the semantics of the reference's USE_SPECTRA build (src/filter.cpp:170-199; see eigen_sym.cpp):
 // the nev = min(nev_in, n - 1) eigenpairs of LARGEST MAGNITUDE of the FULL n x n matrix A (column-major), Krylov
 // dimension min(2 nev, n), residual tolerance `tol`, at most `max_restarts` restarts.  Returns the number of converged

@@ -999,7 +999,71 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
         double inv_trace = 0.0;
         chol_wa = nleh::cholesky_with_inverse(o.Wa.data(), q, L.data(), Li.data(), &inv_trace) && inv_trace <= kCholMaxInvTrace;
     }
-    if (!chol_wa) {
+    // Few eigenvalues below the cut (the usual case on large images: 4 of 200 at cfg4): deflate them and take the Cholesky
+    // route after all.  With Vd, Ld the dropped eigenpairs and s = lambda_max, Ahat = A + Vd (s I - Ld) Vd^T has A's kept
+    // eigenpairs and s on span(Vd); Ahat = L L^T, and with Pk = I - Vd Vd^T (which commutes with Ahat)
+    //     F = Pk L^-T  satisfies  F F^T = Pk Ahat^-1 Pk = pinv of the kept part of A,    F^T A^2 F = L^T Pk L
+    // -- the two things the device half needs.  Only the d dropped eigenvectors are formed (inverse iteration), not all q:
+    // reduction + QL values + Cholesky with inverse, ~1.0 ms at q = 200 against 1.5 ms for the full eigensolve.
+    bool deflated = false;
+    std::vector<double> Fdefl, Gdefl;  // F (q x q) and G = L^T Vd (q x d):  F^T A^2 F = L^T L - G G^T
+    int nd = 0;
+    // (tried only where it pays: below q = 512 the eigensolver is single threaded; and for at most q / 32 + 2 dropped
+    // eigenvalues -- more, and their clustered inverse iterations cost what the full solve does)
+    const int max_defl = q / 32 + 2;
+    if (!chol_wa && std::getenv("NLE_FORCE_EIG") == nullptr && std::getenv("NLE_NO_DEFLATE") == nullptr && q >= 16 && q < 512) {
+        std::vector<double> Dall(q), Vd((size_t)q * (max_defl + 1));
+        int kept = 0;
+        if (nleh::sym_eigen_select(o.Wa.data(), q, Dall.data(), 0, 0, Vd.data(), NLE_EPS, max_defl, &kept)) {
+            nd = q - kept;
+            if (kept > 0 && nd <= max_defl && Dall[0] > 0.0) {
+                const double sig = Dall[0];
+                std::vector<double> Ah(qq);
+                for (int cidx = 0; cidx < q; ++cidx)  // the symmetric matrix the reference's solver sees: lower triangle
+                    for (int ridx = 0; ridx < q; ++ridx)
+                        Ah[(size_t)cidx * q + ridx] = ridx >= cidx ? o.Wa[(size_t)cidx * q + ridx] : o.Wa[(size_t)ridx * q + cidx];
+                for (int t = 0; t < nd; ++t) {
+                    const double wgt = sig - Dall[kept + t];
+                    const double* v = Vd.data() + (size_t)t * q;
+                    for (int cidx = 0; cidx < q; ++cidx) {
+                        const double vc = wgt * v[cidx];
+                        for (int ridx = 0; ridx < q; ++ridx) Ah[(size_t)cidx * q + ridx] += v[ridx] * vc;
+                    }
+                }
+                L.resize(qq);
+                Li.resize(qq);
+                double inv_trace = 0.0;
+                if (nleh::cholesky_with_inverse(Ah.data(), q, L.data(), Li.data(), &inv_trace)) {
+                    // F = L^-T - Vd (Vd^T L^-T),  G = L^T Vd
+                    Fdefl.resize(qq);
+                    for (int k = 0; k < q; ++k)
+                        for (int a = 0; a < q; ++a) Fdefl[(size_t)k * q + a] = Li[(size_t)a * q + k];
+                    Gdefl.assign((size_t)q * std::max(nd, 1), 0.0);
+                    std::vector<double> wv(q);
+                    for (int t = 0; t < nd; ++t) {
+                        const double* v = Vd.data() + (size_t)t * q;
+                        for (int k = 0; k < q; ++k) {  // w = (Vd^T L^-T)[t, k] = sum_a v[a] L^-T(a, k) = sum_a v[a] Li(k, a)
+                            double acc = 0.0, g = 0.0;
+                            for (int a = 0; a < q; ++a) {
+                                acc += v[a] * Li[(size_t)a * q + k];
+                                g += L[(size_t)k * q + a] * v[a];  // (L^T v)[k] = sum_a L(a, k) v[a]
+                            }
+                            wv[k] = acc;
+                            Gdefl[(size_t)t * q + k] = g;
+                        }
+                        for (int k = 0; k < q; ++k)
+                            for (int a = 0; a < q; ++a) Fdefl[(size_t)k * q + a] -= v[a] * wv[k];
+                    }
+                    deflated = true;
+                    r2 = kept;
+                    if (std::getenv("NLE_TRACE"))
+                        fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e), %d deflated\n",
+                                kept, q, Dall[0], Dall[kept - 1], nd);
+                }
+            }
+        }
+    }
+    if (!chol_wa && !deflated) {
         std::vector<double> Uf(qq), l2(q);
         if (!nleh::eigen_decomposition(o.Wa.data(), q, NLE_EPS, Uf.data(), l2.data(), &r2))
             throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Wa"};
@@ -1016,6 +1080,7 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     }
     o.r_wa = chol_wa ? q : r2;
     o.chol_wa = chol_wa;
+    const bool chol_form = chol_wa || deflated;  // F is q x q and F^T A^2 F = L^T L (- G G^T)
     *host_overlapped_ms += now_ms() - h0;
     tr.mark("ss: Wa root (host, under the Gram kernels)");
     // ---- device: with a factor F of the (pseudo-)inverse of A = sym-lower(Wa), F F^T = A^+, the matrix the reference
@@ -1025,16 +1090,20 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     // F^T A^2 F = L2 (diagonal); Cholesky form (no eigenvalue cut): F = L^-T, F^T A^2 F = L^T L.  On the subspace the
     // cut removed, Q acts as Wa alone -- eigenvalues < 1e-10, cut again at :313 -- so nothing is lost, and the rounding
     // of the S (..) S products (entries of S reach 1e5) can no longer lift one of them back over the cut.
-    const int m = chol_wa ? q : std::max(r2, 0);
+    const int m = chol_form ? q : std::max(r2, 0);
     if (m <= 0) throw Fail{NLE_ERR_NUMERIC, "Wa has no eigenvalue >= 1e-10"};
     const size_t mm_ = (size_t)m * m;
     DevBuf<double> d_Wa(qq), d_F((size_t)q * m), d_L, d_T(pp), d_T1((size_t)m * q), d_Qm(mm_);
     HIP_OK(hipMemcpyAsync(d_Wa.p, o.Wa.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));
     std::vector<double> F;  // q x m column-major
-    if (chol_wa) {
-        F.resize(qq);
-        for (int k = 0; k < q; ++k)
-            for (int a = 0; a < q; ++a) F[(size_t)k * q + a] = Li[(size_t)a * q + k];  // L^-T
+    if (chol_form) {
+        if (deflated) {
+            F = Fdefl;
+        } else {
+            F.resize(qq);
+            for (int k = 0; k < q; ++k)
+                for (int a = 0; a < q; ++a) F[(size_t)k * q + a] = Li[(size_t)a * q + k];  // L^-T
+        }
         d_L.alloc(qq);
         HIP_OK(hipMemcpyAsync(d_L.p, L.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));
     } else {
@@ -1057,9 +1126,17 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     }
     // T1 = F^T diag(rA) Gk'[:q,:q]  (m x q);   Qt = T1 diag(rA) F (+ L^T L in the Cholesky form; + diag(l2) on the host)
     HIP_OK(nlek::gemm64s(st, m, q, q, d_F.p, q, 1, d_Gk, 1, p, d_T1.p, 1, m, nullptr, d_rA.p));
-    if (chol_wa) {
+    if (chol_form) {
         DevBuf<double> d_A2(qq);
         HIP_OK(nlek::gemm64s(st, q, q, q, d_L.p, q, 1, d_L.p, 1, q, d_A2.p, 1, q));
+        if (deflated && nd > 0) {  // - G G^T
+            DevBuf<double> d_G((size_t)q * nd), d_neg(nd);
+            const std::vector<double> neg(nd, -1.0);
+            HIP_OK(hipMemcpyAsync(d_G.p, Gdefl.data(), (size_t)q * nd * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemcpyAsync(d_neg.p, neg.data(), nd * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_OK(nlek::gemm64s(st, q, q, nd, d_G.p, 1, q, d_G.p, q, 1, d_A2.p, 1, q, nullptr, d_neg.p, nullptr, d_A2.p, 1, q));
+            HIP_OK(hipStreamSynchronize(st));  // `neg` (host) is consumed
+        }
         HIP_OK(nlek::gemm64s(st, m, m, q, d_T1.p, 1, m, d_F.p, 1, q, d_Qm.p, 1, m, nullptr, d_rA.p, nullptr, d_A2.p, 1, q));
     } else {
         HIP_OK(nlek::gemm64s(st, m, m, q, d_T1.p, 1, m, d_F.p, 1, q, d_Qm.p, 1, m, nullptr, d_rA.p));
@@ -1070,7 +1147,7 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     tr.mark("ss: Q on the device + download");
     // ---- host: top eigenpairs of Qt
     h0 = now_ms();
-    if (!chol_wa)
+    if (!chol_form)
         for (int k = 0; k < m; ++k) Qm[(size_t)k * m + k] += l2_kept[k];
     std::vector<double> Vq, Sq;
     int rq = 0;
