@@ -1008,9 +1008,9 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     bool deflated = false;
     std::vector<double> Fdefl, Gdefl;  // F (q x q) and G = L^T Vd (q x d):  F^T A^2 F = L^T L - G G^T
     int nd = 0;
-    // (tried only where it pays: below q = 512 the eigensolver is single threaded; and for at most q / 32 + 2 dropped
-    // eigenvalues -- more, and their clustered inverse iterations cost what the full solve does)
-    const int max_defl = q / 32 + 2;
+    // (tried only where it pays: below q = 512, where the eigensolver is single threaded -- at q = 900 with 100 dropped
+    // eigenvalues it lost 40 ms to the threaded full solve -- and for at most q / 8 dropped eigenvalues)
+    const int max_defl = q / 8;
     if (!chol_wa && std::getenv("NLE_FORCE_EIG") == nullptr && std::getenv("NLE_NO_DEFLATE") == nullptr && q >= 16 && q < 512) {
         std::vector<double> Dall(q), Vd((size_t)q * (max_defl + 1));
         int kept = 0;
