@@ -92,6 +92,13 @@ int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
 #define NLE_MODE_MATERIALISED_F64 4
 int nle_ctx_set_mode(nle_ctx* ctx, int mode);
 
+/* Slab input (multi-GPU, SURVEY.md section 8e "each GPU uploads / downloads only its slab"): with on != 0 every plane
+ * handed to nle_train*, nle_apply* on this ctx holds ONLY the rows [row0, row1) of this rank (nle_slab_rows), n_local
+ * values, instead of the full H x W image; H and W stay the full image's.  The p sample values (and x at the sample
+ * pixels in apply) are then completed across the ranks by one small all-reduce each.  Set it after the shard /
+ * communicator; it has no effect at world == 1. */
+int nle_ctx_set_slab_input(nle_ctx* ctx, int on);
+
 /* How orthogonalize finds the top eigenpairs of Q (src/filter.cpp:310-317).  0 (default): the reference's default build,
  * eigenDecomposition(Q) -- a full eigensolve, the first min(nEigenVectors, kept) pairs.  1 (opt-in; also
  * NLE_Q_SOLVER=lanczos in the environment): the reference's USE_SPECTRA build, topkEigenDecomposition (:170-199) --

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "nle_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "nle_dev_free": (None, [_P, _P]),
     "nle_ctx_set_topk_solver": (C.c_int, [_P, C.c_int]),
+    "nle_ctx_set_slab_input": (C.c_int, [_P, C.c_int]),
     "nle_rccl_unique_id": (C.c_int, [_P, C.c_size_t]),
     "nle_ctx_init_rccl": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
     "nle_ctx_set_rccl_comm": (C.c_int, [_P, C.c_int, C.c_int, _P]),
@@ -323,6 +324,11 @@ class Context:
         self._pinned.append(ptr)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
+    def set_slab_input(self, on: bool = True):
+        """planes passed to train / apply hold this rank's rows only (nle_ctx_set_slab_input); pass shape=(H, W)"""
+        _check(lib().nle_ctx_set_slab_input(self._h, 1 if on else 0), self._h)
+        self.slab_input = bool(on)
+
     def set_topk_solver(self, solver: int):
         """0: full eigensolve of Q (the reference's default build); 1: Lanczos top-K (its USE_SPECTRA build)"""
         _check(lib().nle_ctx_set_topk_solver(self._h, int(solver)), self._h)
@@ -538,24 +544,39 @@ class NLEFilter:
         except Exception:  # noqa: BLE001
             pass
 
-    def train_filter(self, lum, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter=10, n_eigen_vectors=5):
+    def _full_shape(self, plane, shape):
+        """(H, W) of the full image for a plane handed in: the plane's own shape, or -- Context.set_slab_input -- the
+        `shape` given, the plane then being this rank's rows [row0, row1) (nle_slab_rows)"""
+        if not getattr(self.ctx, "slab_input", False) or self.ctx.world == 1:
+            return tuple(int(v) for v in plane.shape)
+        if shape is None:
+            raise NLEError(NLE_ERR_INVALID, "slab input: pass shape=(H, W) of the full image")
+        H, W = int(shape[0]), int(shape[1])
+        r0, r1 = slab_rows(H, self.ctx.rank, self.ctx.world)
+        if tuple(plane.shape) != (r1 - r0, W):
+            raise NLEError(NLE_ERR_INVALID, f"slab input: rank {self.ctx.rank} of {self.ctx.world} must pass rows "
+                                            f"[{r0}, {r1}) x {W}, got {tuple(plane.shape)}")
+        return H, W
+
+    def train_filter(self, lum, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter=10, n_eigen_vectors=5, shape=None):
         """`NLEFilter::trainFilter` (src/filter.cpp:480-502); lum: H x W luminance (CUDA tensor
-        stays on the device; numpy is uploaded)."""
+        stays on the device; numpy is uploaded).  Slab-input contexts pass their rows and shape=(H, W)."""
         self.close()
         lum = self.ctx._lum(lum)
-        H, W = lum.shape
+        H, W = self._full_shape(lum, shape)
         _check(lib().nle_train(self.ctx._h, C.c_void_p(lum.data_ptr()), H, W, int(n_row_samples), int(n_col_samples),
                                float(hx), float(hy), int(n_sinkhorn_iter), int(n_eigen_vectors), C.byref(self._f)),
                self.ctx._h)
         self.shape = (H, W)
         return self
 
-    def train_filter_host(self, lum, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter=10, n_eigen_vectors=5):
+    def train_filter_host(self, lum, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter=10, n_eigen_vectors=5,
+                          shape=None):
         """nle_train_host: the H x W fp32 plane is a HOST array (pinned: Context.host_alloc); the filter keeps the
-        uploaded plane for apply_layers_host(None, ...)"""
+        uploaded plane for apply_layers_host(None, ...).  Slab-input contexts pass their rows and shape=(H, W)."""
         self.close()
         lum = np.ascontiguousarray(lum, dtype=np.float32)
-        H, W = lum.shape
+        H, W = self._full_shape(lum, shape)
         _check(lib().nle_train_host(self.ctx._h, _np_ptr(lum), H, W, int(n_row_samples), int(n_col_samples), float(hx),
                                     float(hy), int(n_sinkhorn_iter), int(n_eigen_vectors), C.byref(self._f)), self.ctx._h)
         self.shape = (H, W)
@@ -620,7 +641,7 @@ class NLEFilter:
         """`NLEFilter::apply` (src/filter.cpp:445-458): y = V diag(fS) V^T x (local slab)."""
         torch = _torch()
         x = self.ctx._lum(x)
-        H, W = x.shape
+        H, W = self._full_shape(x, self.shape)
         fs = np.ascontiguousarray(f_s, dtype=np.float64)
         if fs.ndim != 1 or fs.size != self.info()["K"]:   # nle_apply reads K doubles
             raise NLEError(NLE_ERR_INVALID, f"f_s must hold K' = {self.info()['K']} values, got {fs.shape}")
@@ -634,7 +655,7 @@ class NLEFilter:
     def apply_layers(self, x, n_layers, out=None):
         torch = _torch()
         x = self.ctx._lum(x)
-        H, W = x.shape
+        H, W = self._full_shape(x, self.shape)
         n = self.info()["n_local"]
         if out is None:
             out = torch.empty((n_layers, n), dtype=torch.float32, device=x.device)

@@ -1122,12 +1122,12 @@ __global__ __launch_bounds__(kDotThreads) void k_hist_dot(const float* __restric
 
 // p-, K-sized half of the sample-space apply (one workgroup):
 //   t = D^T m + Vrows^T x_A,  W'[l] = D (resp_l o t),  YA[l][a] = Vrows[a] . (resp_l o t)
-// D, Vrows: p x ldk row-major fp64; m: p column sums sum_i k_i c_i x_i; x: the full image
+// D, Vrows: p x ldk row-major fp64; m: p column sums sum_i k_i c_i x_i; xA: x at the p sample pixels
 __global__ __launch_bounds__(256) void k_apply_small(int p, int K, int ldk, int L, int ldw, const double* __restrict__ m,
                                                      const double* __restrict__ Dm, const double* __restrict__ Vrows,
-                                                     const float* __restrict__ x, const long long* __restrict__ sample_pix,
-                                                     const double* __restrict__ resp, double* __restrict__ t_out,
-                                                     double* __restrict__ Wp, double* __restrict__ YA) {
+                                                     const double* __restrict__ xA, const double* __restrict__ resp,
+                                                     double* __restrict__ t_out, double* __restrict__ Wp,
+                                                     double* __restrict__ YA) {
     // one workgroup per layer l = blockIdx.x; each recomputes t (K values, p terms each: cheaper than a second launch)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* sm = reinterpret_cast<double*>(smem_raw);  // [p]
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(256) void k_apply_small(int p, int K, int ldk, int 
     const int KP = K <= 64 ? 64 : 128, G = 256 / KP;
     for (int a = tid; a < p; a += 256) {
         sm[a] = m[a];
-        sx[a] = (double)x[sample_pix[a]];
+        sx[a] = xA[a];
     }
     __syncthreads();
     {
@@ -1394,11 +1394,11 @@ hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int
 }
 
 hipError_t apply_small(hipStream_t s, int p, int K, int ldk, int L, int ldw, const double* d_m, const double* d_D,
-                       const double* d_Vrows, const float* d_x, const long long* d_sample_pix, const double* d_resp,
-                       double* d_t, double* d_Wp, double* d_YA) {
+                       const double* d_Vrows, const double* d_xA, const double* d_resp, double* d_t, double* d_Wp,
+                       double* d_YA) {
     const size_t shm = (size_t)(2 * p + K + 256) * sizeof(double);
-    hipLaunchKernelGGL(k_apply_small, dim3((unsigned)L), dim3(256), shm, s, p, K, ldk, L, ldw, d_m, d_D, d_Vrows, d_x,
-                       d_sample_pix, d_resp, d_t, d_Wp, d_YA);
+    hipLaunchKernelGGL(k_apply_small, dim3((unsigned)L), dim3(256), shm, s, p, K, ldk, L, ldw, d_m, d_D, d_Vrows, d_xA,
+                       d_resp, d_t, d_Wp, d_YA);
     return hipGetLastError();
 }
 

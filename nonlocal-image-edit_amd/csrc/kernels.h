@@ -49,6 +49,8 @@ enum RowpassMode { ROWPASS_COLSUM = 0, ROWPASS_RECIP = 1, ROWPASS_XVEC = 2 };
 
 // out[k] = lum[sel_index(k)] for the p samples
 hipError_t gather_samples(hipStream_t s, const float* d_lum, GridSpec gs, float* d_out);
+// fp64, 0 for samples outside rows [row0, row1) (d_lum: virtual base of the full image, only those rows exist)
+hipError_t gather_samples_slab(hipStream_t s, const float* d_lum, GridSpec gs, int row0, int row1, double* d_out);
 
 // K_AB rows, natural order: kab[i][s] = exp2(nsw*d2 + npw*dv^2), i in [pix0, pix0+M)
 hipError_t affinity(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples,
@@ -190,7 +192,7 @@ hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int
                              int nl, const double* d_c, double* d_ws, float* d_out, long long ostride,
                              LaunchObserver* obs);
 hipError_t apply_small(hipStream_t s, int p, int K, int ldk, int L, int ldw, const double* d_m, const double* d_D,
-                       const double* d_Vrows, const float* d_x, const long long* d_sample_pix, const double* d_resp,
+                       const double* d_Vrows, const double* d_xA /* x at the p sample pixels */, const double* d_resp,
                        double* d_t, double* d_Wp, double* d_YA);
 hipError_t scatter_samples(hipStream_t s, int p, int L, const long long* d_loc, const double* d_YA, float* d_Y,
                            long long ystride);

@@ -34,6 +34,23 @@ __global__ void k_gather_samples(const float* __restrict__ lum, GridSpec gs, flo
     out[k] = lum[(size_t)r * gs.W + c];
 }
 
+// the same for a plane of which only rows [row0, row1) exist (lum is the virtual base of the full image): samples of
+// other rows come out as 0, so that a sum over the ranks' results (all-reduce) gives every rank all p values; fp64
+__global__ void k_gather_samples_slab(const float* __restrict__ lum, GridSpec gs, int row0, int row1,
+                                      double* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= gs.p()) return;
+    const int ri = k / gs.nSelCols, ci = k % gs.nSelCols;
+    const int r = gs.rowOff + ri * gs.rowStep, c = gs.colOff + ci * gs.colStep;
+    out[k] = (r >= row0 && r < row1) ? (double)lum[(size_t)r * gs.W + c] : 0.0;
+}
+
+hipError_t gather_samples_slab(hipStream_t s, const float* d_lum, GridSpec gs, int row0, int row1, double* d_out) {
+    const int p = gs.p();
+    hipLaunchKernelGGL(k_gather_samples_slab, dim3((p + 255) / 256), dim3(256), 0, s, d_lum, gs, row0, row1, d_out);
+    return hipGetLastError();
+}
+
 hipError_t gather_samples(hipStream_t s, const float* d_lum, GridSpec gs, float* d_out) {
     const int p = gs.p();
     hipLaunchKernelGGL(k_gather_samples, dim3((p + 255) / 256), dim3(256), 0, s, d_lum, gs, d_out);

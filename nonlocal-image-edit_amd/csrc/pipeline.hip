@@ -51,6 +51,7 @@ struct nle_ctx {
     hipStream_t copy_stream = nullptr;  // device-to-host copies of finished output layers (host-buffer entry points)
     hipEvent_t copy_ev[2] = {nullptr, nullptr};
     int mode = 0;  // nle_ctx_set_mode: 0 auto, 1 materialised Phi, 2 Phi-free, 3 Phi-free without look-up tables
+    bool slab_input = false;  // nle_ctx_set_slab_input: planes handed in hold this rank's rows only
     int topk_solver = 0;  // nle_ctx_set_topk_solver: 0 full eigensolve of Q (:313-316), 1 Lanczos top-K (:170-199)
     bool profiling = false;
     bool profile_all = false;  // level 2: also the small / second-stage kernels (each timed launch costs ~10 us of gaps)
@@ -373,21 +374,45 @@ struct SampleSet {
     bool quantised = false;         // whole plane integer valued in [0, 255] (checked on request)
 };
 
-SampleSet fetch_samples(nle_ctx* c, const float* d_lum, const GridSpec& gs, bool check_quantised = false) {
+// d_lum: base of the FULL plane -- real, or virtual when the ctx takes slab input (only rows [row0, row1) of this rank
+// exist; the p sample values and the "integer valued" verdict are then completed by an all-reduce)
+SampleSet fetch_samples(nle_ctx* c, const float* d_lum, const GridSpec& gs, bool check_quantised = false,
+                        bool slab_plane = false) {
     SampleSet s;
     s.gs = gs;
     s.p = gs.p();
-    DevBuf<float> d_val(s.p);
-    DevBuf<int> d_flag(1);
-    int flag = 1;
-    PROFILED(c, NLE_K_SMALL, nlek::gather_samples(c->stream, d_lum, gs, d_val.p));
-    if (check_quantised) {
-        PROFILED(c, NLE_K_SMALL, nlek::check_levels(c->stream, d_lum, (long long)gs.H * gs.W, d_flag.p));
-        HIP_OK(hipMemcpyAsync(&flag, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    }
     s.val.resize(s.p);
-    HIP_OK(hipMemcpyAsync(s.val.data(), d_val.p, s.p * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
+    int flag = 1;
+    if (slab_plane) {
+        int row0, row1;
+        slab(gs.H, c->rank, c->world, &row0, &row1);
+        DevBuf<double> d_v((size_t)s.p + 1);
+        PROFILED(c, NLE_K_SMALL, nlek::gather_samples_slab(c->stream, d_lum, gs, row0, row1, d_v.p));
+        if (check_quantised) {
+            DevBuf<int> d_flag(1);
+            PROFILED(c, NLE_K_SMALL, nlek::check_levels(c->stream, d_lum + (size_t)row0 * gs.W, (long long)(row1 - row0) * gs.W, d_flag.p));
+            HIP_OK(hipMemcpyAsync(&flag, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(hipStreamSynchronize(c->stream));
+        }
+        const double fl = flag != 0 ? 1.0 : 0.0;
+        HIP_OK(hipMemcpyAsync(d_v.p + s.p, &fl, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        all_reduce(c, d_v.p, (size_t)s.p + 1);
+        std::vector<double> v((size_t)s.p + 1);
+        HIP_OK(hipMemcpyAsync(v.data(), d_v.p, v.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < s.p; ++k) s.val[k] = (float)v[k];
+        flag = v[s.p] > 0.0 ? 1 : 0;
+    } else {
+        DevBuf<float> d_val(s.p);
+        DevBuf<int> d_flag(1);
+        PROFILED(c, NLE_K_SMALL, nlek::gather_samples(c->stream, d_lum, gs, d_val.p));
+        if (check_quantised) {
+            PROFILED(c, NLE_K_SMALL, nlek::check_levels(c->stream, d_lum, (long long)gs.H * gs.W, d_flag.p));
+            HIP_OK(hipMemcpyAsync(&flag, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_OK(hipMemcpyAsync(s.val.data(), d_val.p, s.p * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    }
     s.quantised = check_quantised && flag == 0;
     s.pix.resize(s.p);
     s.packed.resize(s.p);
@@ -1714,8 +1739,15 @@ void apply_sample_space(nle_filter* f, const float* d_x, const double* h_g /* L 
         HIP_OK(hipMemsetAsync(d_m.p, 0, P64 * sizeof(double), c->stream));
     }
     all_reduce(c, d_m.p, P64);
-    PROFILED(c, NLE_K_SMALL, nlek::apply_small(c->stream, p, K, f->ldd, L, P64, d_m.p, f->d_D, f->d_Vrows, d_x,
-                                               f->d_sample_pix, d_resp.p, d_t.p, d_Wp.p, d_YA.p));
+    // x at the p sample pixels: every rank's own rows, completed by the all-reduce when the planes are slabs
+    DevBuf<double> d_xA(p);
+    {
+        const bool slabs = c->slab_input && c->world > 1;
+        PROFILED(c, NLE_K_SMALL, nlek::gather_samples_slab(c->stream, d_x, f->gs, slabs ? f->row0 : 0, slabs ? f->row1 : f->H, d_xA.p));
+        if (slabs) all_reduce(c, d_xA.p, p);
+    }
+    PROFILED(c, NLE_K_SMALL, nlek::apply_small(c->stream, p, K, f->ldd, L, P64, d_m.p, f->d_D, f->d_Vrows, d_xA.p,
+                                               d_resp.p, d_t.p, d_Wp.p, d_YA.p));
     if (M > 0) {
         static const int emap[4] = {NLE_K_SINK_TABLES, NLE_K_APPLY_EXPAND, NLE_K_REDUCE, NLE_K_REDUCE};
         int lb = std::min(L, nlek::apply_layers_per_launch(f->gs));
@@ -1740,9 +1772,16 @@ void apply_sample_space(nle_filter* f, const float* d_x, const double* h_g /* L 
     prof_flush(c);
 }
 
-nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, int nCol, double hx,
+// d_lum_in: the full H x W plane, or -- ctx in slab-input mode -- this rank's rows [row0, row1) only
+nle_filter* train_impl(nle_ctx* c, const float* d_lum_in, int H, int W, int nRow, int nCol, double hx,
                        double hy, int T, int n_eig) {
     check_image_size(H, W);
+    const float* d_lum = d_lum_in;
+    if (c->slab_input && c->world > 1) {  // virtual base of the full image: only this rank's rows are ever dereferenced
+        int r0, r1;
+        slab(H, c->rank, c->world, &r0, &r1);
+        d_lum = d_lum_in - (size_t)r0 * W;
+    }
     if (nRow > H || nCol > W)  // reference src/filter.cpp:117-119
         throw Fail{NLE_ERR_INVALID, "Number of samples per row and col must be <= that of image."};
     GridSpec gs;
@@ -1783,7 +1822,7 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
         // --- sample set, Ka and its eigenpairs (:486-491, host fp64)
         Timer tm_a(c->stream);
         tm_a.start();
-        SampleSet ss = fetch_samples(c, d_lum, gs, want_fuse && tables_ok);
+        SampleSet ss = fetch_samples(c, d_lum, gs, want_fuse && tables_ok, c->slab_input && c->world > 1);
         const bool fuse = c->mode == 0 ? (tables_ok && ss.quantised)
                                        : (want_fuse && (generic_ok || (tables_ok && ss.quantised)));
         if (c->mode == 2 && !fuse)
@@ -1829,9 +1868,11 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum, int H, int W, int nRow, i
 }
 
 // t = V^T x (all ranks), then Y[l] = V (g_l o t)
-void apply_impl(nle_filter* f, const float* d_x, int H, int W, const double* h_g /* L x K */, int L,
+void apply_impl(nle_filter* f, const float* d_x_in, int H, int W, const double* h_g /* L x K */, int L,
                 float* d_y, const LayersDone& done = nullptr, int group = 0) {
     nle_ctx* c = f->ctx;
+    // slab-input mode: d_x_in holds this rank's rows only; index it through the virtual base of the full image
+    const float* d_x = (c->slab_input && c->world > 1) ? d_x_in - (size_t)f->row0 * f->W : d_x_in;
     if ((long long)H * W != (long long)f->H * f->W)  // reference src/filter.cpp:447-449
         throw Fail{NLE_ERR_INVALID, "Number of values in channel must match that of training image."};
     if (L < 1 || L > 64) throw Fail{NLE_ERR_INVALID, "number of layers must be in [1, 64]"};
@@ -2130,6 +2171,12 @@ int nle_topk_eigen_decomposition(const double* h_M, int n, int n_largest, double
     int k = 0;
     while (k < nconv && h_D[k] >= eps) ++k;  // :186-196
     *r = k;
+    return NLE_OK;
+}
+
+int nle_ctx_set_slab_input(nle_ctx* ctx, int on) {
+    if (!ctx) return NLE_ERR_INVALID;
+    ctx->slab_input = on != 0;
     return NLE_OK;
 }
 
@@ -2447,8 +2494,14 @@ int nle_train_host(nle_ctx* ctx, const float* h_lum, int H, int W, int n_row_sam
     return guard(ctx, [&] {
         check_image_size(H, W);
         HIP_OK(hipSetDevice(ctx->device));
-        DevBuf<float> d_lum((size_t)H * W);
-        HIP_OK(hipMemcpyAsync(d_lum.p, h_lum, (size_t)H * W * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        size_t npx = (size_t)H * W;  // slab-input mode: h_lum holds this rank's rows only
+        if (ctx->slab_input && ctx->world > 1) {
+            int r0, r1;
+            slab(H, ctx->rank, ctx->world, &r0, &r1);
+            npx = (size_t)(r1 - r0) * W;
+        }
+        DevBuf<float> d_lum(std::max<size_t>(npx, 1));
+        HIP_OK(hipMemcpyAsync(d_lum.p, h_lum, npx * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         nle_filter* f = train_impl(ctx, d_lum.p, H, W, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter, n_eigen_vectors);
         f->plane_bytes = d_lum.n * sizeof(float);  // kept: nle_apply*_host(h_x == NULL) filters the training plane
         f->d_plane = d_lum.take();
@@ -2592,8 +2645,9 @@ static void apply_host_common(nle_filter* f, const float* h_x, int H, int W, con
     DevBuf<float> d_xbuf, d_y((size_t)L * std::max<long long>(f->n_local, 1));
     const float* d_x = f->d_plane;
     if (h_x) {
-        d_xbuf.alloc((size_t)H * W);
-        HIP_OK(hipMemcpyAsync(d_xbuf.p, h_x, (size_t)H * W * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        const size_t npx = (c->slab_input && c->world > 1) ? (size_t)f->n_local : (size_t)H * W;
+        d_xbuf.alloc(std::max<size_t>(npx, 1));
+        HIP_OK(hipMemcpyAsync(d_xbuf.p, h_x, npx * sizeof(float), hipMemcpyHostToDevice, c->stream));
         d_x = d_xbuf.p;
     }
     // each finished group of layers goes home on the copy stream while the next one is computed (the copies are only

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, args, mode, outdir):
+def _worker(rank, world, port, args, mode, outdir, slabs=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -37,8 +37,23 @@ def _worker(rank, world, port, args, mode, outdir):
         ctx.set_mode(mode)
         g = nle.sample_grid(H, W, nr, nc)
         ctx.set_shard(rank, world, g["n_sel_rows"] * g["n_sel_cols"], lambda t: dist.all_reduce(t))
-        f = nle.NLEFilter(ctx).train_filter(x, nr, nc, hx, hy, T, K)
-        Y = f.apply_layers(x, L).cpu().numpy()
+        if slabs:      # every rank hands over (and uploads) only its own rows: nle_ctx_set_slab_input
+            ctx.set_slab_input(True)
+            r0, r1 = nle.slab_rows(H, rank, world)
+            xs = np.ascontiguousarray(x[r0:r1])
+            if slabs == "host":
+                f = nle.NLEFilter(ctx).train_filter_host(xs, nr, nc, hx, hy, T, K, shape=(H, W))
+                Y = np.empty((L, (r1 - r0) * W), dtype=np.float32)
+                f.apply_layers_host(None, L, Y)
+                Y2 = np.empty_like(Y)
+                f.apply_layers_host(xs, L, Y2)
+                assert np.array_equal(Y, Y2)
+            else:
+                f = nle.NLEFilter(ctx).train_filter(xs, nr, nc, hx, hy, T, K, shape=(H, W))
+                Y = f.apply_layers(xs, L).cpu().numpy()
+        else:
+            f = nle.NLEFilter(ctx).train_filter(x, nr, nc, hx, hy, T, K)
+            Y = f.apply_layers(x, L).cpu().numpy()
         info = f.info()
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), Y=Y, S=f.eigvals, rows=np.array([info["row0"], info["row1"]]))
         f.close()
@@ -75,6 +90,28 @@ def test_sharded_ranks_match_single_rank(nle, oracle, ctx, tmp_path, world, mode
     Y_o = oracle.apply_layers(V_o, S_o, x, L).reshape(L, -1)
     for j in range(L):
         assert rel_l2(Y[j], Y_o[j]) < 1e-4, j
+
+
+@pytest.mark.parametrize("how", ["device", "host"])
+@pytest.mark.parametrize("mode", [0, 4, 1], ids=["tables", "materialised_f64", "materialised"])
+def test_slab_input_matches_full_plane_input(nle, tmp_path, mode, how):
+    """nle_ctx_set_slab_input: ranks that hand over only their own rows (device planes, or host buffers of which only
+    n_local * 4 bytes are uploaded) get bit for bit what they get when every rank holds the full plane: the sample
+    values and x at the samples arrive through an all-reduce of exact values (one non-zero contribution each)."""
+    import torch.multiprocessing as mp
+    args = (96, 128, 6, 8, 32.0, 30.0, 6, 10, 4)
+    H, W, nr, nc, hx, hy, T, K, L = args
+    world = 3
+    full, slabs = tmp_path / "full", tmp_path / "slabs"
+    full.mkdir()
+    slabs.mkdir()
+    mp.spawn(_worker, args=(world, _free_port(), args, mode, str(full)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), args, mode, str(slabs), how), nprocs=world, join=True)
+    for r in range(world):
+        a, b = np.load(full / f"rank{r}.npz"), np.load(slabs / f"rank{r}.npz")
+        assert np.array_equal(a["rows"], b["rows"])
+        assert np.array_equal(a["S"], b["S"]), (r, np.abs(a["S"] - b["S"]).max())
+        assert np.array_equal(a["Y"], b["Y"]), (r, np.abs(a["Y"] - b["Y"]).max())
 
 
 @pytest.mark.gpu
