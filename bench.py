@@ -140,6 +140,8 @@ def main():
                     help="N > 1: 'rccl' = the library's own ncclAllReduce on its stream (communicator bootstrapped over "
                          "torch.distributed); 'torch' = torch.distributed.all_reduce through the callback ABI")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the replica-throughput leg")
+    ap.add_argument("--full-plane-input", action="store_true",
+                    help="N > 1: every rank holds the whole plane (default: slab input, a rank holds and uploads its rows only)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--simulate-world", type=int, default=0,
@@ -207,10 +209,18 @@ def main():
     n_local = ctx.local_pixels(H, W)
     out = torch.empty((L, n_local), dtype=torch.float32, device=lum.device)
     flt = nle.NLEFilter(ctx)
+    # N > 1: a rank keeps only its own rows of the image (nle_ctx_set_slab_input); the p sample values travel in one
+    # small all-reduce
+    slab_input = world > 1 and not args.full_plane_input
+    lum_in = lum
+    if slab_input:
+        ctx.set_slab_input(True)
+        r0_, r1_ = nle.slab_rows(H, rank, world)
+        lum_in = lum[r0_:r1_].contiguous()
 
     def step():
-        flt.train_filter(lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"])
-        flt.apply_layers(lum, L, out=out)
+        flt.train_filter(lum_in, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"], shape=(H, W))
+        flt.apply_layers(lum_in, L, out=out)
 
     def fence():
         torch.cuda.synchronize()
@@ -295,21 +305,27 @@ def main():
         f_r.close()
         c_r.close()
 
-    # ---- SURVEY.md section 8d's metric: host plane -> host layers, median of >= 5 runs after 2 warm-ups (N = 1)
+    # ---- SURVEY.md section 8d's metric: host plane -> host layers, median of >= 5 runs after 2 warm-ups.  N > 1 (slab
+    # input): every rank uploads its own rows and downloads its own rows of the layers, max over ranks per run
     h2h = None
-    if world == 1 and args.simulate_world <= 1 and args.h2h_runs > 0:
-        h_lum = ctx.host_alloc((H, W))
-        h_lum[...] = synth.synthetic_luminance(H, W).astype(np.float32)
-        h_out = ctx.host_alloc((L, H * W))
+    if (world == 1 or slab_input) and args.simulate_world <= 1 and args.h2h_runs > 0:
+        rows0, rows1 = nle.slab_rows(H, rank, world) if world > 1 else (0, H)
+        h_lum = ctx.host_alloc((rows1 - rows0, W))
+        h_lum[...] = synth.synthetic_luminance(H, W).astype(np.float32)[rows0:rows1]
+        h_out = ctx.host_alloc((L, n_local))
         f2 = nle.NLEFilter(ctx)
         ts = []
         for it in range(2 + args.h2h_runs):
-            torch.cuda.synchronize()
+            fence()
             t1 = time.perf_counter()
-            f2.train_filter_host(h_lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"])
+            f2.train_filter_host(h_lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"], shape=(H, W))
             f2.apply_layers_host(None, L, h_out)          # returns when the last layer is in host memory
             ts.append(time.perf_counter() - t1)
         ts = ts[2:]
+        if dist is not None:
+            tt = torch.tensor(ts, dtype=torch.float64, device=lum.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ts = tt.tolist()
         ref = out.cpu().numpy()
         same = bool(np.array_equal(ref, h_out)) or float(np.abs(ref - h_out).max() / max(np.abs(ref).max(), 1e-30))
         med = float(np.median(ts))
@@ -317,7 +333,8 @@ def main():
                "ms_max": max(ts) * 1e3, "runs": len(ts), "warmup": 2,
                "bytes_h2d": int(h_lum.nbytes), "bytes_d2h": int(h_out.nbytes),
                "what": "SURVEY.md section 8d: fp32 plane in page-locked host memory -> train -> L per-layer planes back in "
-                       "page-locked host memory, one image at a time (nle_train_host + nle_apply_layers_host)",
+                       "page-locked host memory, one image at a time (nle_train_host + nle_apply_layers_host)"
+                       + ("; per rank: its own rows up, its own rows of the layers down; max over ranks" if world > 1 else ""),
                "matches_device_resident_output": same}
         f2.close()
 
@@ -442,6 +459,7 @@ def main():
                        "storage": ("fp64 tables, histograms, reductions and MFMA; fp32 output planes; V implicit" if lazy else
                                    "fp64 reductions and Gram/projection MFMA; fp32 affinities, V and outputs")},
             "host_to_host": h2h,
+            "slab_input": bool(slab_input),
             "replicas": replicas,
             "comm": comm_kind,
             "roofline": roofline,

@@ -1309,7 +1309,7 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
     if (sorted != nullptr) {
         Scope sc(obs, SUB_HIST_PIX);
         hipError_t ep = sorted_pass(s, mode, gs, row0, nrows_local, sorted->scol, sorted->desc, sorted->first, sorted->E, d_g,
-                                    eps, d_ybuf, d_h, d_cvec, d_xvec);
+                                    eps, d_ybuf, d_h, d_cvec, d_xvec, sorted->rec, sorted->kappa);
         if (ep != hipSuccess) return ep;
     } else {
         Scope sc(obs, SUB_HIST_PIX);
@@ -1687,7 +1687,8 @@ hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int 
     hipError_t e;
     if (obs) obs->begin(SUB_GHIST_ROWS);
     if (sorted != nullptr && nC <= sorted_gram_max_cols()) {
-        e = sorted_gram_rows(s, gs, nrows_local, sorted->scol, sorted->desc, sorted->first, sorted->E, d_c, d_A);
+        e = sorted_gram_rows(s, gs, nrows_local, sorted->scol, sorted->desc, sorted->first, sorted->E, d_c, d_A, sorted->rec,
+                             sorted->kappa);
         if (e != hipSuccess) return e;
     } else if (nC <= 11) {
         const size_t shm = (size_t)kLevels * NP * sizeof(double);

@@ -160,22 +160,26 @@ hipError_t scale_rows64(hipStream_t s, double* d_X, int m, int n, const double* 
 // ---- level-sorted rows (sorted.hip): the pixel halves of the table passes without LDS atomics
 constexpr int kSortedThreads = 512;
 struct SortedRows {
-    const unsigned short* scol;   // [nrows][W]   columns of each row sorted by level (sample pixels left out)
+    const unsigned short* scol;   // [nrows][pitch] per row: one slot of 8 x column per chunk (sample pixels left out)
     const uint2* desc;            // [nrows][kSortedThreads] chunk of each pass thread
     const unsigned short* first;  // [nrows][258] first chunk of each level; [257] tree steps
     const double* E;              // [W + 1] exp(-d^2 / hx^2)
+    bool rec;                     // column factors by recurrence from two table reads (sorted_recurrence)
+    double kappa;                 // exp(-2 colStep^2 / hx^2)
 };
+bool sorted_recurrence(GridSpec gs, double hx, double* kappa);
 int sorted_max_width();
-size_t sorted_scol_elems(int W, int nrows_local);  // allocation size of SortedRows::scol (padded for the prefetch)
+size_t sorted_scol_elems(int W, int nrows_local);  // allocation size of SortedRows::scol
 int sorted_gram_max_cols();
 hipError_t dist_table(hipStream_t s, int W, double hx, double* d_E);
 hipError_t sort_rows(hipStream_t s, const float* d_lum, GridSpec gs, int row0, int nrows_local, unsigned short* d_scol,
                      uint2* d_desc, unsigned short* d_first);
 hipError_t sorted_pass(hipStream_t s, int mode, GridSpec gs, int row0, int nrows_local, const unsigned short* d_scol,
                        const uint2* d_desc, const unsigned short* d_first, const double* d_E, const double* d_g, double eps,
-                       double* d_ybuf, double* d_h, const double* d_cvec, const float* d_xvec);
+                       double* d_ybuf, double* d_h, const double* d_cvec, const float* d_xvec, bool rec, double kappa);
 hipError_t sorted_gram_rows(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
-                            const unsigned short* d_first, const double* d_E, const double* d_cvec, double* d_Aout);
+                            const unsigned short* d_first, const double* d_E, const double* d_cvec, double* d_Aout, bool rec,
+                            double kappa);
 
 // tiled form of sink_hist (three kernels, Ep read once per pass); writes the full column sums to d_z
 size_t hist_tiled_workspace_elems(GridSpec gs, int nrows_local);

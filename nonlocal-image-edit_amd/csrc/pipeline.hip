@@ -1459,16 +1459,15 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     DevBuf<double> d_E;
     nlek::SortedRows sr{};
     if (sorted) {
-        d_scol.alloc(nlek::sorted_scol_elems(ss.gs.W, nrows_local));
-        HIP_OK(hipMemsetAsync(d_scol.p + (size_t)nrows_local * ss.gs.W, 0,
-                              (d_scol.n - (size_t)nrows_local * ss.gs.W) * sizeof(unsigned short), c->stream));
+        d_scol.alloc(nlek::sorted_scol_elems(ss.gs.W, nrows_local));  // k_sort_rows writes every entry a pass reads
         d_first.alloc((size_t)nrows_local * 258);
         d_desc.alloc((size_t)nrows_local * nlek::kSortedThreads);
         d_E.alloc((size_t)ss.gs.W + 1);
         PROFILED(c, NLE_K_SMALL, nlek::dist_table(c->stream, ss.gs.W, hx, d_E.p));
         PROFILED(c, NLE_K_SMALL, nlek::sort_rows(c->stream, d_lum, ss.gs, row0, nrows_local, d_scol.p, d_desc.p, d_first.p));
         HIP_OK(hipMemsetAsync(d_cbuf.p, 0, d_cbuf.n * sizeof(double), c->stream));  // sample pixels are never visited
-        sr = nlek::SortedRows{d_scol.p, d_desc.p, d_first.p, d_E.p};
+        sr = nlek::SortedRows{d_scol.p, d_desc.p, d_first.p, d_E.p, false, 0.0};
+        sr.rec = nlek::sorted_recurrence(ss.gs, hx, &sr.kappa);
     }
     const nlek::SortedRows* srp = sorted ? &sr : nullptr;
     const int nrows = hist ? nrows_local : nlek::sink_pass_rows(std::max<long long>(M, 1));
@@ -1663,7 +1662,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         f->d_sample_loc = own(d_sloc);
         if (sorted) {
             f->has_sorted = true;
-            f->sorted = nlek::SortedRows{own(d_scol), own(d_desc), own(d_first), own(d_E)};
+            f->sorted = nlek::SortedRows{own(d_scol), own(d_desc), own(d_first), own(d_E), sr.rec, sr.kappa};
         }
         f->h_Vrows = o.Vrows;
         f->h_sample_pix = ss.pix;

@@ -17,12 +17,24 @@
 // binary tree through LDS.  No atomics anywhere: results are bitwise reproducible, and a flat image costs what a noisy
 // one does.
 //
+// Storage: the column indices of chunk k of a row sit CONTIGUOUSLY in slot k of the row (CHP = chunk length rounded up
+// to 4 entries, 8-byte aligned), so a pass thread fetches four pixels' indices with one 8-byte load, one block of four
+// ahead of their use; the chunk descriptor and the level's table row of the NEXT image row are requested while the
+// current row is still being combined.  (The round-2 profile of the first form -- one 2-byte index load per pixel, each
+// row starting with three dependent global loads -- showed the kernel waiting on memory latency for most of its time.)
+//
 // Reference arithmetic restated: the Sinkhorn row products / column sums of src/filter.cpp:238-245, the Gram
 // Wab Wab^T of :296 and the reduce half of apply (:456), exactly as fused.hip derives them; only the order of the
 // fp64 sums differs.
 #include "kernels.h"
 
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+// Measurement hooks (tools/abl_run.sh, profiles/r2_pass_ablation.txt): -DNLE_ABL_NOLOOP builds k_sorted_pass without its
+// pixel work, -DNLE_ABL_NOTREE without the combine tree and the table stores.  Never defined in the product build.
+#define NLE_PIXEL_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 namespace nlek {
 
@@ -40,11 +52,47 @@ __device__ __forceinline__ double recip0_d(double s, double eps) {
     return (fabs(s) >= eps) ? r : 0.0;
 }
 
-// byte offset of E[|c - c_b|] in the LDS table from the pre-scaled 16-bit operands c8 = 8 c, cb8 = 8 c_b (8 W <= 65536):
-// one v_sad_u16 instead of subtract / negate / max / shift
-__device__ __forceinline__ double e_at(const double* sE, unsigned c8, unsigned cb8) {
-    const unsigned off = __builtin_amdgcn_sad_u16(c8, cb8, 0u);
-    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sE) + off);
+// E[|c - c_b|] from the LDS table, given the pre-scaled 16-bit operands c8 = 8 c, cb8 = 8 c_b (8 W <= 65536) and the LDS
+// byte address of the table: ONE v_sad_u16 (|c8 - cb8| + base) makes the address -- no subtract / negate / max / shift /
+// base add -- and the value is read through an LDS-address-space pointer
+using lds_cdouble_ptr = const __attribute__((address_space(3))) double*;
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ double e_at(unsigned sE_addr, unsigned c8, unsigned cb8) {
+    const unsigned a = __builtin_amdgcn_sad_u16(c8, cb8, sE_addr);
+    return *(lds_cdouble_ptr)a;
+}
+
+// f(b, e_b) for b = 0 .. NC-1, e_b = exp(-(c - c_b)^2 / hx^2), c_b = cb0 + b cs: the column factors of one pixel.
+//   REC == false: NC reads of the E table.  64 lanes read 64 unrelated addresses: ~3 lanes per bank on average, and at
+//     NC reads per pixel the LDS pipe, not the VALU, bounds the pass kernels (round 2: 10 reads -> 84 us at cfg4).
+//   REC == true: e_0 and e_1 from the table, the rest from the exact recurrence of a Gaussian on an equispaced grid,
+//       e_{b+1} = e_b rho_b,   rho_{b+1} = rho_b kappa,   rho_0 = e_1 / e_0,   kappa = exp(-2 cs^2 / hx^2)
+//     (2 reads + 2 (NC - 2) multiplies + one reciprocal).  Rounding: e_b carries O(b^2 / 2) ulp (NC = 10: ~5e-15
+//     relative) -- the probes of profiles/r2_readme_pair_sensitivity.txt put 1e-13 affinity noise at 1e-11 on the layers.
+//     The host enables it only where no e_b, rho_b leaves the normal range (sorted_recurrence).
+template <int NC, bool REC, class F>
+__device__ __forceinline__ void column_factors(unsigned sEa, unsigned c8, int cb0, int cs, double kappa, F&& f) {
+    if constexpr (!REC || NC <= 2) {
+#pragma unroll
+        for (int b = 0; b < NC; ++b) f(b, e_at(sEa, c8, (unsigned)(cb0 + b * cs) << 3));
+    } else {
+        const double e0 = e_at(sEa, c8, (unsigned)cb0 << 3);
+        double eb = e_at(sEa, c8, (unsigned)(cb0 + cs) << 3);
+        f(0, e0);
+        f(1, eb);
+        double r = __builtin_amdgcn_rcp(e0);  // 1 / e_0 to 1 ulp: two Newton steps (e_0 is a normal number here)
+        r = fma(fma(-e0, r, 1.0), r, r);
+        r = fma(fma(-e0, r, 1.0), r, r);
+        double rho = eb * r;
+#pragma unroll
+        for (int b = 2; b < NC; ++b) {
+            rho *= kappa;
+            eb *= rho;
+            f(b, eb);
+        }
+    }
 }
 
 // block-wide sum / max of one int per thread (256 threads), result in every thread; `red`: 8 ints of LDS
@@ -66,7 +114,7 @@ __device__ __forceinline__ int block_max256(int v, int* red) {
 }
 }  // namespace
 
-int sorted_max_width() { return 8192; }
+int sorted_max_width() { return 8192; }  // 8 W fits 16 bits; chunks of <= 32 pixels (kMaxBlocks)
 
 // E[d] = exp(-d^2 / hx^2), d = 0 .. W: the same expression as ecT in k_hist_tables (fused.hip), so the two agree bit for bit
 __global__ void k_dist_table(int W, double inv_hx2, double* __restrict__ E) {
@@ -83,19 +131,39 @@ hipError_t dist_table(hipStream_t s, int W, double hx, double* d_E) {
 }
 
 // ------------------------------------------------------------------ once per train: sort every row by level
+// Chunk length bound: CH is the smallest length with sum_x ceil(tot[x] / CH) <= kT; with at most 256 non-empty levels
+// that sum is <= wn / CH + 256, so CH <= ceil(W / 256) and a slot never needs more than sorted_chp_max(W) entries.
+__host__ __device__ inline int sorted_chp_max(int W) { return (((W + 255) / 256) + 3) & ~3; }
+constexpr int kMaxBlocks = 8;  // blocks of four indices per chunk: sorted_chp_max(sorted_max_width()) / 4
+// entries per row of the scol buffer: kT slots of the largest size + the 4 entries a thread reads ahead of its slot
+__host__ __device__ inline size_t sorted_row_pitch(int W) { return (size_t)kT * sorted_chp_max(W) + 4; }
+
+// chunk descriptor: x = len | level << 6 | j << 14 | steps << 23,  y = m | CHP << 16
+//   len    pixels of the chunk (0: idle thread),  j, m: the chunk is number j of the m chunks of its level,
+//   steps  ceil(log2(max m of the row)) = depth of the combine tree,  CHP: slot size of this row (entries)
+__device__ __forceinline__ int dsc_len(uint2 d) { return (int)(d.x & 63u); }
+__device__ __forceinline__ int dsc_level(uint2 d) { return (int)((d.x >> 6) & 255u); }
+__device__ __forceinline__ int dsc_j(uint2 d) { return (int)((d.x >> 14) & 511u); }
+__device__ __forceinline__ int dsc_steps(uint2 d) { return (int)((d.x >> 23) & 15u); }
+__device__ __forceinline__ int dsc_m(uint2 d) { return (int)(d.y & 0xffffu); }
+__device__ __forceinline__ int dsc_chp(uint2 d) { return (int)(d.y >> 16); }
+
 // One workgroup (256 threads) per local image row.  Sample pixels are left out (the N-sized sums skip them: their Phi
 // rows are the exact V_A rows, reference :275).  Outputs, per row:
-//   scol[W]    8 x column (the byte offset the pass kernels feed to v_sad_u16) in (level, column) order -- a STABLE
-//              counting sort, so that the summation order of every later pass is a function of the image alone;
-//   desc[kT]   one chunk per pass thread: x = start | stride << 16, y = len | level << 16 (len 0: idle thread);
-//   first[258] first[x] = first chunk of level x (x = 0..256), first[257] = number of tree steps = ceil(log2(max m)).
+//   scol[pitch]  slot k (CHP entries, zero padded) = 8 x column (the byte offset the pass kernels feed to v_sad_u16) of
+//                the pixels of chunk k in column order; chunk j of a level's m chunks holds the level's pixels
+//                j, j + m, j + 2m, ... of a STABLE counting sort, so that the summation order of every later pass is a
+//                function of the image alone;
+//   desc[kT]     one chunk per pass thread (see above);
+//   first[258]   first[x] = first chunk of level x (x = 0..256), first[257] = number of tree steps.
 __global__ __launch_bounds__(kSortThreads) void k_sort_rows(const float* __restrict__ lum, GridSpec gs, int row0,
                                                             unsigned short* __restrict__ scol, uint2* __restrict__ desc,
                                                             unsigned short* __restrict__ first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int W = gs.W;
-    unsigned short* srow = reinterpret_cast<unsigned short*>(smem_raw);  // [W] sorted columns
+    unsigned short* srow = reinterpret_cast<unsigned short*>(smem_raw);  // [kT * CHP + 4] the row's slots
     __shared__ int tot[kLevels], off[kLevels + 1], run[kLevels], fch[kLevels + 1], red[8];
+    __shared__ float rcpm[kLevels];
     __shared__ __attribute__((aligned(16))) unsigned char cntG[4][kLevels];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = blockIdx.x, r = row0 + lrow;
     const float* lrow_p = lum + (size_t)r * W;
@@ -133,9 +201,10 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_rows(const float* __restr
         if (n <= kT) hi = mid;
         else lo = mid + 1;
     }
-    const int CH = lo;
+    const int CH = lo, CHP = (CH + 3) & ~3;
     const int m = (mine + CH - 1) / CH;
     const int maxm = block_max256(m, red);
+    rcpm[tid] = m > 0 ? 1.0f / (float)m : 0.f;
     fch[tid + 1] = m;
     if (tid == 0) fch[0] = 0;
     __syncthreads();
@@ -145,17 +214,17 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_rows(const float* __restr
         if (tid + 1 > d) fch[tid + 1] += v;
         __syncthreads();
     }
+    int steps = 0;
+    while ((1 << steps) < maxm) ++steps;
     unsigned short* frow = first + (size_t)lrow * 258;
     frow[tid] = (unsigned short)fch[tid];
     if (tid == 0) {
         frow[kLevels] = (unsigned short)fch[kLevels];
-        int steps = 0;
-        while ((1 << steps) < maxm) ++steps;
         frow[kLevels + 1] = (unsigned short)steps;
     }
     const int nchunks = fch[kLevels];
     for (int k = tid; k < kT; k += kSortThreads) {
-        uint2 d = make_uint2(1u << 16, 0u);  // idle: stride 1, len 0
+        uint2 d = make_uint2((unsigned)steps << 23, 1u | ((unsigned)CHP << 16));  // idle: len 0, m 1
         if (k < nchunks) {
             int a = 0, b = kLevels;  // largest x with fch[x] <= k
             while (b - a > 1) {
@@ -164,10 +233,15 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_rows(const float* __restr
                 else b = mid;
             }
             const int x = a, j = k - fch[x], mx = fch[x + 1] - fch[x], cnt = tot[x];
-            d = make_uint2((unsigned)(off[x] + j) | ((unsigned)mx << 16), (unsigned)((cnt - j + mx - 1) / mx) | ((unsigned)x << 16));
+            const int len = (cnt - j + mx - 1) / mx;
+            d = make_uint2((unsigned)len | ((unsigned)x << 6) | ((unsigned)j << 14) | ((unsigned)steps << 23),
+                           (unsigned)mx | ((unsigned)CHP << 16));
         }
         desc[(size_t)lrow * kT + k] = d;
     }
+    const int used = nchunks * CHP + 4;  // entries a pass can read: the slots and one block past the last
+    for (int i = tid; i < used; i += kSortThreads) srow[i] = 0;  // padding must be a valid column
+    __syncthreads();
     // stable placement, four 64-column tiles (one per wave) at a time
     for (int c0 = 0; c0 < W; c0 += 4 * 64) {
         const int c = c0 + wave * 64 + lane;
@@ -189,32 +263,37 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_rows(const float* __restr
         if (valid) {
             int prev = 0;
             for (int w2 = 0; w2 < wave; ++w2) prev += cntG[w2][x];
-            srow[off[x] + run[x] + prev + rank] = (unsigned short)(c << 3);  // pre-scaled: 8 c (W <= 8192)
+            // q-th pixel of level x (sorted order) -> chunk q mod m, position q div m; the quotient through a float
+            // reciprocal is exact here: (q + 0.5) / m lies >= 0.5 / 512 from an integer, its value is <= CH + 1 <= 64
+            const int q = run[x] + prev + rank, mx = fch[x + 1] - fch[x];
+            const int pos = (int)(((float)q + 0.5f) * rcpm[x]);
+            const int j = q - pos * mx;
+            srow[(fch[x] + j) * CHP + pos] = (unsigned short)(c << 3);  // pre-scaled: 8 c (W <= 8192)
         }
         __syncthreads();
         run[tid] += cntG[0][tid] + cntG[1][tid] + cntG[2][tid] + cntG[3][tid];
         __syncthreads();
     }
-    unsigned short* out = scol + (size_t)lrow * W;
-    for (int i = tid; i < W; i += kSortThreads) out[i] = i < wn ? srow[i] : (unsigned short)0;
+    unsigned int* out = reinterpret_cast<unsigned int*>(scol + (size_t)lrow * sorted_row_pitch(W));
+    const unsigned int* src = reinterpret_cast<const unsigned int*>(srow);
+    for (int i = tid; i < used / 2; i += kSortThreads) out[i] = src[i];
 }
 
-// elements of the scol buffer: the pass kernels prefetch column indices up to two chunk strides (<= 2 x 512 entries)
-// past a thread's chunk, i.e. past the last row's end
-size_t sorted_scol_elems(int W, int nrows_local) { return (size_t)std::max(nrows_local, 0) * W + 2 * kSortedThreads + 8; }
+// elements of the scol buffer
+size_t sorted_scol_elems(int W, int nrows_local) { return (size_t)std::max(nrows_local, 0) * sorted_row_pitch(W) + 16; }
 
 hipError_t sort_rows(hipStream_t s, const float* d_lum, GridSpec gs, int row0, int nrows_local, unsigned short* d_scol,
                      uint2* d_desc, unsigned short* d_first) {
     if (gs.W > sorted_max_width() || nrows_local <= 0) return nrows_local <= 0 ? hipSuccess : hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)nrows_local), dim3(kSortThreads), (size_t)gs.W * sizeof(unsigned short), s,
-                       d_lum, gs, row0, d_scol, d_desc, d_first);
+    hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)nrows_local), dim3(kSortThreads),
+                       sorted_row_pitch(gs.W) * sizeof(unsigned short), s, d_lum, gs, row0, d_scol, d_desc, d_first);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ LDS layout shared by the two pass kernels
-// sE [W + 1] doubles | sP [kT][PS] doubles | sfirst [258] u16
+// sE [W + 1] doubles | sP [kT][PS] doubles | sfirst [2][260] u16 (this row's and the next row's)
 __host__ __device__ inline size_t sorted_lds_bytes(int W, int ps) {
-    return ((size_t)((W + 2) & ~1) + (size_t)kT * ps) * sizeof(double) + 260 * sizeof(unsigned short);
+    return ((size_t)((W + 2) & ~1) + (size_t)kT * ps) * sizeof(double) + 2 * 260 * sizeof(unsigned short);
 }
 
 // Combines the per-chunk partial sums v[0..NV) of the threads of one level (consecutive threads, j = position in the
@@ -245,93 +324,185 @@ __device__ __forceinline__ void combine_chunks(double (&v)[NV], double* sP, int 
 // For every local image row r (persistent workgroups, rows r = blockIdx.x, + gridDim.x, ...):
 //   y_i = 1 (COLSUM) | recip(sum_b ec[c_i][b] g_r[x_i][b]) (RECIP) | c_i x_i (XVEC),   h_r[x][b] = sum_{i: x_i = x} ec[c_i][b] y_i
 // g, hout: [nrows][b][x] (b-major tables, as k_hist_g writes and k_hist_hh reads them).
-template <int NC>
-__global__ __launch_bounds__(kT) void k_sorted_pass(int mode, const unsigned short* __restrict__ scol,
+template <int NC, bool REC>
+__global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode, const unsigned short* __restrict__ scol,
                                                     const uint2* __restrict__ desc, const unsigned short* __restrict__ first,
                                                     GridSpec gs, int row0, int nrows, const double* __restrict__ Etab,
                                                     const double* __restrict__ g, double eps, double* __restrict__ ybuf,
                                                     double* __restrict__ hout, const double* __restrict__ cvec,
-                                                    const float* __restrict__ xvec) {
+                                                    const float* __restrict__ xvec, double kappa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int n = kLevels * NC;
     constexpr int SL = NC < 11 ? NC : 11;  // sums combined per tree (slices of the nC sums when nC > 11)
     constexpr int PS = SL | 1;             // odd stride: consecutive threads' rows start on different banks
     constexpr bool KEEP_E = NC <= 12;      // keep the column factors of a pixel in registers between the two loops
     const int W = gs.W;
+    const size_t pitch = sorted_row_pitch(W);
     double* sE = reinterpret_cast<double*>(smem_raw);
     double* sP = sE + ((W + 2) & ~1);
-    unsigned short* sfirst = reinterpret_cast<unsigned short*>(sP + (size_t)kT * PS);
+    unsigned short* sfirst = reinterpret_cast<unsigned short*>(sP + (size_t)kT * PS);  // [2][260], rows alternate
     const int tid = threadIdx.x;
     for (int i = tid; i <= W; i += kT) sE[i] = Etab[i];
     const int cb0 = gs.colOff, cs = gs.colStep;
-    for (int lrow = blockIdx.x; lrow < nrows; lrow += gridDim.x) {
-        if (tid < 258) sfirst[tid] = first[(size_t)lrow * 258 + tid];
-        const uint2 dsc = desc[(size_t)lrow * kT + tid];
-        const int start = (int)(dsc.x & 0xffffu), stride = (int)(dsc.x >> 16), len = (int)(dsc.y & 0xffffu),
-                  x = (int)(dsc.y >> 16);
-        double gv[NC], acc[NC];
+    const bool recip = mode == ROWPASS_RECIP, xmode = mode == ROWPASS_XVEC;
+    const unsigned sEa = lds_addr(sE);
+
+    // Software pipeline over the rows of this workgroup: everything a row needs from global memory is requested while
+    // the PREVIOUS row is being combined -- its first indices and its level's table row (their address needs the row's
+    // chunk descriptor, which is therefore requested two rows ahead) -- and taken in before that row's table is stored.
+    // Nothing foreign is pending during the pixel loop, so its waits (the counter retires in order) are exact.
+    const int G = (int)gridDim.x;  // <= nrows
+    int lrow = blockIdx.x, nrow = lrow + G;
+    uint2 dsc = desc[(size_t)lrow * kT + tid];
+    uint2 dsc_n = dsc;
+    if (nrow < nrows) dsc_n = desc[(size_t)nrow * kT + tid];
+    if (tid < 258) sfirst[tid] = first[(size_t)lrow * 258 + tid];
+    // all indices of the chunk (<= kMaxBlocks blocks of four) live in registers: the pixel loop itself loads nothing
+    uint2 idx[kMaxBlocks];
+    auto load_idx = [&](uint2 (&dst)[kMaxBlocks], const int row, const uint2 d) {
+        const uint2* slot = reinterpret_cast<const uint2*>(scol + (size_t)row * pitch + (size_t)tid * dsc_chp(d));
+        const int ln = dsc_len(d);
 #pragma unroll
-        for (int b = 0; b < NC; ++b) {
-            gv[b] = (mode == ROWPASS_RECIP && len > 0) ? g[(size_t)lrow * n + b * kLevels + x] : 0.0;
-            acc[b] = 0.0;
+        for (int b = 0; b < kMaxBlocks; ++b) {  // blocks past the chunk: column 0 (the wave may walk further than this lane)
+            uint2 v = make_uint2(0u, 0u);
+            if (4 * b < ln) v = slot[b];
+            dst[b] = v;
         }
-        __syncthreads();  // sE / sfirst visible; the previous row's reads of sP are done
-        // software pipeline: the (dependent) loads of pixel t + 1 -- its column index, and in the apply its c and x --
-        // are issued, unconditionally, before pixel t is processed
-        const unsigned short* sc = scol + (size_t)lrow * W + start;
+    };
+    load_idx(idx, lrow, dsc);
+    double gv[NC];
+#pragma unroll
+    for (int b = 0; b < NC; ++b) gv[b] = recip ? g[(size_t)lrow * n + b * kLevels + dsc_level(dsc)] : 0.0;
+    __syncthreads();  // sE, sfirst visible
+    for (int par = 0;; par ^= 1) {
+        const bool has_next = nrow < nrows;
+        const int nnrow = nrow + G;
+        const unsigned short* sfc = sfirst + par * 260;
+        const int len = dsc_len(dsc);
+        double acc[NC];
+#pragma unroll
+        for (int b = 0; b < NC; ++b) acc[b] = 0.0;
         const double* cv_row = cvec ? cvec + (size_t)lrow * W : nullptr;
         const float* xv_row = xvec ? xvec + (size_t)(row0 + lrow) * W : nullptr;
-        // (the index loads run up to two chunk strides past the chunk: scol is padded for that, sort_rows_elems)
-        unsigned c8 = sc[0], c8n = sc[stride];
-        double yx = (mode == ROWPASS_XVEC) ? cv_row[c8 >> 3] * (double)xv_row[c8 >> 3] : 1.0;
-        for (int t = 0; t < len; ++t) {
-            const unsigned c8nn = sc[(t + 2) * stride];
-            const double yxn = (mode == ROWPASS_XVEC) ? cv_row[c8n >> 3] * (double)xv_row[c8n >> 3] : 1.0;
+        double* yb_row = ybuf ? ybuf + (size_t)lrow * W : nullptr;
+        // requested BEFORE the pixel loop, in flight under it: the descriptor of the row after next, the next row's
+        // first-chunk table entry and its indices (the pixel loop has no wait on the memory counter)
+        uint2 dsc_nn = dsc_n;
+        unsigned short sf_n = 0;
+        uint2 idx_n[kMaxBlocks];
+        if (has_next) {
+            if (nnrow < nrows) dsc_nn = desc[(size_t)nnrow * kT + tid];
+            sf_n = first[(size_t)nrow * 258 + (tid < 258 ? tid : 257)];
+            load_idx(idx_n, nrow, dsc_n);
+        }
+        // One pixel at a time (the column factors of one pixel fill the registers; the scheduling barrier keeps the
+        // unrolled bodies from being interleaved), up to the longest chunk of the WAVE: a scalar bound, so that a wave
+        // whose chunks are all short skips the rest without per-lane bookkeeping.  Lanes past their own chunk add zeros.
+        auto pixel = [&](const unsigned c8, const bool on) {
             double e[KEEP_E ? NC : 1];
             double y = 1.0;
-            if (mode == ROWPASS_RECIP) {
+            bool keep = on;
+            if (recip) {
                 double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int b = 0; b < NC; ++b) {
-                    const double ev = e_at(sE, c8, (unsigned)(cb0 + b * cs) << 3);
+                column_factors<NC, REC>(sEa, c8, cb0, cs, kappa, [&](const int b, const double ev) {
                     if constexpr (KEEP_E) e[b] = ev;
                     if (b & 1) s1 += ev * gv[b];
                     else s0 += ev * gv[b];
-                }
-                y = recip0_d(s0 + s1, eps);
+                });
+                // inplaceReciprocal (src/filter.cpp:42-54): 1 / s, 0 where |s| < eps; recip0_d's arithmetic
+                const double sm = s0 + s1;
+                double r = __builtin_amdgcn_rcp(sm);
+                r = fma(fma(-sm, r, 1.0), r, r);
+                r = fma(fma(-sm, r, 1.0), r, r);
+                y = r;
+                keep = on && fabs(sm) >= eps;
             } else {
-                if constexpr (KEEP_E) {
-#pragma unroll
-                    for (int b = 0; b < NC; ++b) e[b] = e_at(sE, c8, (unsigned)(cb0 + b * cs) << 3);
-                }
-                if (mode == ROWPASS_XVEC) y = yx;  // apply: y_i = c_i x_i
+                if (xmode) y = cv_row[c8 >> 3] * (double)xv_row[c8 >> 3];  // apply: y_i = c_i x_i
+                if constexpr (KEEP_E) column_factors<NC, REC>(sEa, c8, cb0, cs, kappa, [&](const int b, const double ev) { e[b] = ev; });
             }
-            if (ybuf != nullptr) ybuf[(size_t)lrow * W + (c8 >> 3)] = y;
+            y = keep ? y : 0.0;  // the padding of the slot adds exact zeros
+            if (yb_row != nullptr && on) yb_row[c8 >> 3] = y;
+            if constexpr (KEEP_E) {
 #pragma unroll
-            for (int b = 0; b < NC; ++b) {
-                if constexpr (KEEP_E) acc[b] += e[b] * y;
-                else acc[b] += e_at(sE, c8, (unsigned)(cb0 + b * cs) << 3) * y;
+                for (int b = 0; b < NC; ++b) acc[b] += e[b] * y;
+            } else {
+                column_factors<NC, REC>(sEa, c8, cb0, cs, kappa, [&](const int b, const double ev) { acc[b] += ev * y; });
             }
-            c8 = c8n;
-            c8n = c8nn;
-            yx = yxn;
+        };
+        int wlen = len;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wlen = max(wlen, __shfl_xor(wlen, off));
+        wlen = __builtin_amdgcn_readfirstlane(wlen);
+#ifdef NLE_ABL_NOLOOP
+        wlen = 0;
+#endif
+#pragma unroll
+        for (int b = 0; b < kMaxBlocks; ++b) {
+            if (4 * b >= wlen) break;
+            pixel(idx[b].x & 0xffffu, 4 * b < len);
+            NLE_PIXEL_FENCE();
+            if (4 * b + 1 < wlen) {
+                pixel(idx[b].x >> 16, 4 * b + 1 < len);
+                NLE_PIXEL_FENCE();
+            }
+            if (4 * b + 2 < wlen) {
+                pixel(idx[b].y & 0xffffu, 4 * b + 2 < len);
+                NLE_PIXEL_FENCE();
+            }
+            if (4 * b + 3 < wlen) {
+                pixel(idx[b].y >> 16, 4 * b + 3 < len);
+                NLE_PIXEL_FENCE();
+            }
         }
-        const int steps = sfirst[kLevels + 1], j = tid - sfirst[x], m = stride;
+        int steps = dsc_steps(dsc), j = dsc_j(dsc), m = dsc_m(dsc);
+        asm volatile("" : "+v"(steps), "+v"(j), "+v"(m));  // decoded before the loads below are issued, not after
+        // the next row's table row: in flight under the combine.  (Requested before the pixel loop -- registers
+        // permitting -- the kernel gets SLOWER, as it does with an L2 prefetch: profiles/r2_pass_ablation.txt.)
+        if (has_next && recip) {
+#pragma unroll
+            for (int b = 0; b < NC; ++b) gv[b] = g[(size_t)nrow * n + b * kLevels + dsc_level(dsc_n)];
+        }
         double* hrow = hout + (size_t)lrow * n;
+#ifdef NLE_ABL_NOTREE
+        if (acc[0] == 12345.678) hrow[tid] = acc[0] + acc[NC - 1];
+        steps = 0;
+#endif
 #pragma unroll
         for (int s0 = 0; s0 < NC; s0 += SL) {
             double v[SL];
 #pragma unroll
             for (int i = 0; i < SL; ++i) v[i] = (s0 + i < NC) ? acc[s0 + i] : 0.0;
             combine_chunks<SL, PS>(v, sP, tid, len > 0, j, m, steps);
+            if (s0 == 0) {
+                // Were the loads above still pending behind the table stores below, the next row's first pixel would
+                // wait for those stores to be acknowledged.  Take them in here (all lanes: a divergent use would leave
+                // a load pending for the others), after the tree has given them time to arrive.
+                asm volatile("" ::"v"(sf_n), "v"(dsc_nn.x), "v"(dsc_nn.y));
+#pragma unroll
+                for (int b = 0; b < kMaxBlocks; ++b) asm volatile("" ::"v"(idx_n[b].x), "v"(idx_n[b].y));
+#pragma unroll
+                for (int b = 0; b < NC; ++b) asm volatile("" ::"v"(gv[b]));
+                // next row's first-chunk table (its last readers left before the previous row's end barrier; its next
+                // readers come after the barriers of the next combine)
+                if (has_next && tid < 258) sfirst[(par ^ 1) * 260 + tid] = sf_n;
+            }
             const int ns = (NC - s0 < SL) ? NC - s0 : SL;
+#ifndef NLE_ABL_NOTREE
             for (int i = tid; i < ns * kLevels; i += kT) {
                 const int bb = i / kLevels, xx = i & (kLevels - 1);
-                const int f0 = sfirst[xx];
-                hrow[(size_t)(s0 + bb) * kLevels + xx] = sfirst[xx + 1] > f0 ? sP[f0 * PS + bb] : 0.0;
+                const int f0 = sfc[xx];
+                hrow[(size_t)(s0 + bb) * kLevels + xx] = sfc[xx + 1] > f0 ? sP[f0 * PS + bb] : 0.0;
             }
+#endif
             __syncthreads();  // before the next slice / row overwrites sP and sfirst
         }
+        if (!has_next) break;
+        lrow = nrow;
+        nrow = nnrow;
+        dsc = dsc_n;
+        dsc_n = dsc_nn;
+#pragma unroll
+        for (int b = 0; b < kMaxBlocks; ++b) idx[b] = idx_n[b];
     }
 }
 
@@ -342,24 +513,49 @@ static int sorted_grid(int nrows) {
     return std::max(1, std::min(nrows, 2 * ncu));  // two 512-thread workgroups per CU, each walks its rows
 }
 
+// Where the recurrence of column_factors stays inside the normal range of fp64 (with a wide margin): every e_b =
+// exp(-(u - b cs)^2 / hx^2) and every ratio rho_b = exp((2 cs u - (2 b + 1) cs^2) / hx^2), u = c - cb0, c = 0 .. W-1.
+// Narrow kernels (W / hx beyond ~20) keep the table form.  *kappa = exp(-2 cs^2 / hx^2).
+bool sorted_recurrence(GridSpec gs, double hx, double* kappa) {
+    const double cs = gs.colStep, umax = std::max<double>(gs.colOff, gs.W - 1 - gs.colOff), nC = gs.nSelCols;
+    const double span = umax + nC * cs;  // |u - b cs| <= span
+    const double m_e = span * span / (hx * hx);
+    const double m_rho = (2.0 * cs * umax + (2.0 * nC + 1.0) * cs * cs) / (hx * hx);
+    *kappa = std::exp(-2.0 * cs * cs / (hx * hx));
+    const bool off = std::getenv("NLE_SORTED_TABLE") != nullptr;  // every column factor from the table
+    // up to 12 columns the factors of a pixel stay in registers between its two uses (10 table reads per pixel at cfg4:
+    // measured no slower than the recurrence, and bit-identical to the ecT table of the other kernels); beyond, the table
+    // form reads every factor twice and the LDS pipe bounds it (cfg5, 30 columns: 1212 -> 861 us per pass)
+    return !off && gs.nSelCols > 12 && m_e < 500.0 && m_rho < 500.0;
+}
+
 hipError_t sorted_pass(hipStream_t s, int mode, GridSpec gs, int row0, int nrows_local, const unsigned short* d_scol,
                        const uint2* d_desc, const unsigned short* d_first, const double* d_E, const double* d_g, double eps,
-                       double* d_ybuf, double* d_h, const double* d_cvec, const float* d_xvec) {
+                       double* d_ybuf, double* d_h, const double* d_cvec, const float* d_xvec, bool rec, double kappa) {
     const int nC = gs.nSelCols;
     if (nC < 1 || nC > 36 || gs.W > sorted_max_width()) return hipErrorInvalidValue;
     if (nrows_local <= 0) return hipSuccess;
     const size_t shm = sorted_lds_bytes(gs.W, (nC < 11 ? nC : 11) | 1);
     const int grid = sorted_grid(nrows_local);
-#define NLE_SP(NCV)                                                                                                       \
-    case NCV: {                                                                                                           \
+#define NLE_SP1(NCV, RECV)                                                                                                \
+    {                                                                                                                     \
         if (shm > 48 * 1024) {                                                                                            \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sorted_pass<NCV>),                        \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sorted_pass<NCV, RECV>),                  \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                    \
             if (ea != hipSuccess) return ea;                                                                              \
         }                                                                                                                 \
-        hipLaunchKernelGGL((k_sorted_pass<NCV>), dim3((unsigned)grid), dim3(kT), shm, s, mode, d_scol, d_desc, d_first, gs, \
-                           row0, nrows_local, d_E, d_g, eps, d_ybuf, d_h, d_cvec, d_xvec);                                \
-    } break;
+        hipLaunchKernelGGL((k_sorted_pass<NCV, RECV>), dim3((unsigned)grid), dim3(kT), shm, s, mode, d_scol, d_desc,       \
+                           d_first, gs, row0, nrows_local, d_E, d_g, eps, d_ybuf, d_h, d_cvec, d_xvec, kappa);            \
+    }
+#define NLE_SP(NCV)                                                                                                       \
+    case NCV:                                                                                                             \
+        if constexpr ((NCV) > 12) {                                                                                       \
+            if (rec) NLE_SP1(NCV, true) else NLE_SP1(NCV, false)                                                          \
+        } else {                                                                                                          \
+            if (rec) return hipErrorInvalidValue;                                                                         \
+            NLE_SP1(NCV, false)                                                                                           \
+        }                                                                                                                 \
+        break;
     switch (nC) {
         NLE_SP(1) NLE_SP(2) NLE_SP(3) NLE_SP(4) NLE_SP(5) NLE_SP(6) NLE_SP(7) NLE_SP(8) NLE_SP(9) NLE_SP(10) NLE_SP(11)
         NLE_SP(12) NLE_SP(13) NLE_SP(14) NLE_SP(15) NLE_SP(16) NLE_SP(17) NLE_SP(18) NLE_SP(19) NLE_SP(20)
@@ -368,17 +564,18 @@ hipError_t sorted_pass(hipStream_t s, int mode, GridSpec gs, int row0, int nrows
         default: return hipErrorInvalidValue;
     }
 #undef NLE_SP
+#undef NLE_SP1
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ Gram, per-row pair tables (nC <= 11)
 // A_r[(b, b')][x] = sum_{i in row r, x_i = x} c_i^2 ec[c_i][b] ec[c_i][b'],  b <= b': what k_ghist_rows computes with
 // nC (nC + 1) / 2 LDS atomics per pixel.  Output layout [row][pair][level], as k_ghist_gemm / k_ghist_final expect.
-template <int NC>
+template <int NC, bool REC>
 __global__ __launch_bounds__(kT) void k_sorted_gram(const unsigned short* __restrict__ scol, const uint2* __restrict__ desc,
                                                     const unsigned short* __restrict__ first, GridSpec gs, int nrows,
                                                     const double* __restrict__ Etab, const double* __restrict__ cvec,
-                                                    double* __restrict__ Aout) {
+                                                    double* __restrict__ Aout, double kappa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NP = NC * (NC + 1) / 2;
     constexpr int SL = 11, PS = SL;  // the tree combines 11 sums at a time (odd stride)
@@ -389,35 +586,39 @@ __global__ __launch_bounds__(kT) void k_sorted_gram(const unsigned short* __rest
     const int tid = threadIdx.x;
     for (int i = tid; i <= W; i += kT) sE[i] = Etab[i];
     const int cb0 = gs.colOff, cs = gs.colStep;
+    const unsigned sEa = lds_addr(sE);
+    const size_t pitch = sorted_row_pitch(W);
     for (int lrow = blockIdx.x; lrow < nrows; lrow += gridDim.x) {
         if (tid < 258) sfirst[tid] = first[(size_t)lrow * 258 + tid];
         const uint2 dsc = desc[(size_t)lrow * kT + tid];
-        const int start = (int)(dsc.x & 0xffffu), stride = (int)(dsc.x >> 16), len = (int)(dsc.y & 0xffffu),
-                  x = (int)(dsc.y >> 16);
+        const int len = dsc_len(dsc);
         double acc[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc[i] = 0.0;
         __syncthreads();
-        const unsigned short* sc = scol + (size_t)lrow * W + start;
+        const uint2* slot = reinterpret_cast<const uint2*>(scol + (size_t)lrow * pitch + (size_t)tid * dsc_chp(dsc));
         const double* cv_row = cvec + (size_t)lrow * W;
-        unsigned c8 = sc[0], c8n = sc[stride];
-        double cf = cv_row[c8 >> 3];
-        for (int t = 0; t < len; ++t) {  // loads of pixel t + 1 (and the index of t + 2) in flight under pixel t
-            const unsigned c8nn = sc[(t + 2) * stride];
-            const double cfn = cv_row[c8n >> 3];
-            double q[NC];
+        uint2 cur = slot[0];
+        for (int t0 = 0; t0 < len; t0 += 4) {  // four pixels per step, indices fetched one step ahead (zero padded slots)
+            const uint2 nxt = slot[(t0 >> 2) + 1];
+            const unsigned c8v[4] = {cur.x & 0xffffu, cur.x >> 16, cur.y & 0xffffu, cur.y >> 16};
+            double cfv[4];
 #pragma unroll
-            for (int b = 0; b < NC; ++b) q[b] = cf * e_at(sE, c8, (unsigned)(cb0 + b * cs) << 3);
-            int idx = 0;
+            for (int k = 0; k < 4; ++k) cfv[k] = cv_row[c8v[k] >> 3];
 #pragma unroll
-            for (int b = 0; b < NC; ++b)
+            for (int k = 0; k < 4; ++k) {
+                const double cf = (t0 + k < len) ? cfv[k] : 0.0;  // padding adds exact zeros
+                double q[NC];
+                column_factors<NC, REC>(sEa, c8v[k], cb0, cs, kappa, [&](const int b, const double ev) { q[b] = cf * ev; });
+                int idx = 0;
 #pragma unroll
-                for (int b2 = b; b2 < NC; ++b2) acc[idx++] += q[b] * q[b2];
-            c8 = c8n;
-            c8n = c8nn;
-            cf = cfn;
+                for (int b = 0; b < NC; ++b)
+#pragma unroll
+                    for (int b2 = b; b2 < NC; ++b2) acc[idx++] += q[b] * q[b2];
+            }
+            cur = nxt;
         }
-        const int steps = sfirst[kLevels + 1], j = tid - sfirst[x], m = stride;
+        const int steps = dsc_steps(dsc), j = dsc_j(dsc), m = dsc_m(dsc);
         double* out = Aout + (size_t)lrow * kLevels * NP;
 #pragma unroll
         for (int s0 = 0; s0 < NP; s0 += SL) {
@@ -439,27 +640,34 @@ __global__ __launch_bounds__(kT) void k_sorted_gram(const unsigned short* __rest
 int sorted_gram_max_cols() { return 11; }
 
 hipError_t sorted_gram_rows(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
-                            const unsigned short* d_first, const double* d_E, const double* d_cvec, double* d_Aout) {
+                            const unsigned short* d_first, const double* d_E, const double* d_cvec, double* d_Aout, bool rec,
+                            double kappa) {
     const int nC = gs.nSelCols;
     if (nC < 1 || nC > sorted_gram_max_cols() || gs.W > sorted_max_width()) return hipErrorInvalidValue;
     if (nrows_local <= 0) return hipSuccess;
     const size_t shm = sorted_lds_bytes(gs.W, 11);
     const int grid = sorted_grid(nrows_local);
-#define NLE_SG(NCV)                                                                                                     \
-    case NCV: {                                                                                                         \
+#define NLE_SG1(NCV, RECV)                                                                                              \
+    {                                                                                                                   \
         if (shm > 48 * 1024) {                                                                                          \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sorted_gram<NCV>),                      \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sorted_gram<NCV, RECV>),                \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                  \
             if (ea != hipSuccess) return ea;                                                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL((k_sorted_gram<NCV>), dim3((unsigned)grid), dim3(kT), shm, s, d_scol, d_desc, d_first, gs,   \
-                           nrows_local, d_E, d_cvec, d_Aout);                                                           \
-    } break;
+        hipLaunchKernelGGL((k_sorted_gram<NCV, RECV>), dim3((unsigned)grid), dim3(kT), shm, s, d_scol, d_desc, d_first,  \
+                           gs, nrows_local, d_E, d_cvec, d_Aout, kappa);                                                \
+    }
+#define NLE_SG(NCV)                                                                                                     \
+    case NCV:                                                                                                           \
+        if (rec) return hipErrorInvalidValue; /* sorted Gram: nC <= 11, table form only */                              \
+        NLE_SG1(NCV, false)                                                                                             \
+        break;
     switch (nC) {
         NLE_SG(1) NLE_SG(2) NLE_SG(3) NLE_SG(4) NLE_SG(5) NLE_SG(6) NLE_SG(7) NLE_SG(8) NLE_SG(9) NLE_SG(10) NLE_SG(11)
         default: return hipErrorInvalidValue;
     }
 #undef NLE_SG
+#undef NLE_SG1
     return hipGetLastError();
 }
 

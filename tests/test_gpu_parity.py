@@ -369,7 +369,7 @@ def test_host_buffer_entry_points_match_the_device_ones(nle, oracle, ctx, pinned
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["noise", "flat", "two-level", "tiny"])
+@pytest.mark.parametrize("kind", ["noise", "flat", "two-level", "tiny", "wide20"])
 def test_level_sorted_rows_agree_with_the_histogram_kernels_and_are_bitwise_reproducible(nle, oracle, kind):
     """sorted.hip (level-sorted rows, register accumulation, fixed combine tree) against the LDS-atomic histogram
     kernels it replaces (NLE_NO_SORTED_ROWS=1), on images that stress the chunking: noise, one flat level (every
@@ -378,9 +378,11 @@ def test_level_sorted_rows_agree_with_the_histogram_kernels_and_are_bitwise_repr
     rng = np.random.default_rng(5)
     if kind == "tiny":
         H, W, nr, nc = 40, 37, 4, 5
+    elif kind == "wide20":           # more than 12 sample columns: column factors by recurrence (sorted.hip)
+        H, W, nr, nc = 150, 700, 6, 20
     else:
         H, W, nr, nc = 150, 700, 6, 10
-    if kind == "noise" or kind == "tiny":
+    if kind in ("noise", "tiny", "wide20"):
         x = rng.integers(0, 256, (H, W)).astype(np.float32)
     elif kind == "flat":
         x = np.full((H, W), 97.0, dtype=np.float32)
@@ -403,7 +405,10 @@ def test_level_sorted_rows_agree_with_the_histogram_kernels_and_are_bitwise_repr
 
     ev1, Y1 = run()
     ev2, Y2 = run()
-    assert np.array_equal(ev1, ev2) and np.array_equal(Y1, Y2)          # bitwise reproducible
+    if kind == "wide20":   # beyond 11 sample columns the Gram stage still uses the LDS-atomic histogram (k_ghist_rows)
+        assert rel_l2(ev1, ev2) < 1e-12 and rel_l2(Y1, Y2) < 1e-9
+    else:
+        assert np.array_equal(ev1, ev2) and np.array_equal(Y1, Y2)          # bitwise reproducible
     os.environ["NLE_NO_SORTED_ROWS"] = "1"
     try:
         ev0, Y0 = run()
@@ -412,6 +417,16 @@ def test_level_sorted_rows_agree_with_the_histogram_kernels_and_are_bitwise_repr
     assert rel_l2(ev1, ev0) < 1e-9
     for j in range(L):
         assert rel_l2(Y1[j], Y0[j]) < 1e-6, (kind, j)
+    # column factors by recurrence (two table reads per pixel: the default for more than 12 sample columns, where it is
+    # safe) against all of them read from the table (NLE_SORTED_TABLE=1): O(nC^2) ulp apart
+    os.environ["NLE_SORTED_TABLE"] = "1"
+    try:
+        ev3, Y3 = run()
+    finally:
+        del os.environ["NLE_SORTED_TABLE"]
+    assert rel_l2(ev1, ev3) < 1e-11, rel_l2(ev1, ev3)
+    for j in range(L):
+        assert rel_l2(Y1[j], Y3[j]) < 1e-7, (kind, j, rel_l2(Y1[j], Y3[j]))
 
 
 @pytest.mark.gpu
