@@ -140,6 +140,7 @@ def main():
                     help="N > 1: 'rccl' = the library's own ncclAllReduce on its stream (communicator bootstrapped over "
                          "torch.distributed); 'torch' = torch.distributed.all_reduce through the callback ABI")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the replica-throughput leg")
+    ap.add_argument("--no-pipelined", action="store_true", help="N = 1: skip the images-in-flight throughput leg")
     ap.add_argument("--full-plane-input", action="store_true",
                     help="N > 1: every rank holds the whole plane (default: slab input, a rank holds and uploads its rows only)")
     ap.add_argument("--same-device", action="store_true",
@@ -305,6 +306,47 @@ def main():
         f_r.close()
         c_r.close()
 
+    # ---- throughput with several images in flight (N = 1): each image on its own ctx / stream / host thread, so that one
+    # image's p-sized host algebra (W_A root, eig(Q): ~2.7 ms of the 7.5) runs under another image's kernels.  Reported
+    # beside `value`, which stays the one-image-at-a-time figure.
+    pipelined = None
+    if world == 1 and args.simulate_world <= 1 and args.inflight == 1 and not args.no_pipelined:
+        import threading
+        pipelined = []
+        for M in (2, 3):
+            pl = []
+            for _ in range(M):
+                c2 = nle.Context(local_rank)
+                c2.set_mode(args.mode)
+                pl.append((c2, nle.NLEFilter(c2), torch.empty_like(out)))
+
+            def work(i, n, pl=pl, M=M):
+                torch.cuda.set_device(local_rank)
+                _, f_i, o_i = pl[i]
+                for _ in range(i, n, M):
+                    f_i.train_filter(lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"])
+                    f_i.apply_layers(lum, L, out=o_i)
+
+            def run(n):
+                th = [threading.Thread(target=work, args=(i, n)) for i in range(M)]
+                for t_ in th:
+                    t_.start()
+                for t_ in th:
+                    t_.join()
+            nimg = max(3 * args.steps, 12)   # enough images for the pipeline's start-up and drain to wash out
+            run(2 * M)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run(nimg)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            same = bool(torch.equal(pl[0][2], out))
+            pipelined.append({"images_in_flight": M, "value": (H * W / 1e6) * nimg / el, "unit": "MP/s",
+                              "ms_per_image": el * 1e3 / nimg, "images": nimg, "matches_single_image_output": same})
+            for c2, f2_, _ in pl:
+                f2_.close()
+                c2.close()
+
     # ---- SURVEY.md section 8d's metric: host plane -> host layers, median of >= 5 runs after 2 warm-ups.  N > 1 (slab
     # input): every rank uploads its own rows and downloads its own rows of the layers, max over ranks per run
     h2h = None
@@ -460,6 +502,7 @@ def main():
                                    "fp64 reductions and Gram/projection MFMA; fp32 affinities, V and outputs")},
             "host_to_host": h2h,
             "slab_input": bool(slab_input),
+            "pipelined": pipelined,
             "replicas": replicas,
             "comm": comm_kind,
             "roofline": roofline,

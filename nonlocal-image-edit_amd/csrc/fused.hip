@@ -958,10 +958,16 @@ hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, i
 __global__ __launch_bounds__(256) void k_hist_g(GridSpec gs, int p, int nrows, int tiles_per_wave,
                                                 const double* __restrict__ er, const double* __restrict__ Ep,
                                                 const double* __restrict__ w, double* __restrict__ g) {
+    // the er rows of this workgroup's row range, staged once (coalesced) -- a per-tile global load of the A operand put
+    // one memory latency on every 16-row tile, which is what bounded the kernel (25 us for an 84 MB stream at cfg4)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* sEr = reinterpret_cast<double*>(smem_raw);  // [tiles_per_wave * 16][nR]
     const int nC = gs.nSelCols, nR = gs.nSelRows, n = kLevels * nC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int t0 = blockIdx.y * tiles_per_wave, ntiles = (nrows + 15) >> 4;
+    const int rbase = t0 * 16, rcount = min(nrows - rbase, tiles_per_wave * 16);
+    for (int i = tid; i < rcount * nR; i += 256) sEr[i] = er[(size_t)rbase * nR + i];
     const int n0 = (blockIdx.x * 4 + wave) * 16;
-    if (n0 >= n) return;  // wave-uniform
     const int col = n0 + l15;
     const bool col_ok = col < n;
     const int b = col_ok ? col / kLevels : 0, x = col & (kLevels - 1);  // table columns are b-major: col = b*256 + x
@@ -971,15 +977,16 @@ __global__ __launch_bounds__(256) void k_hist_g(GridSpec gs, int p, int nrows, i
         const int a = ks * 4 + kq;
         bop[ks] = (col_ok && a < nR) ? w[a * nC + b] * Ep[(size_t)x * p + a * nC + b] : 0.0;
     }
+    __syncthreads();
+    if (n0 >= n) return;  // wave-uniform (after the barrier)
     const int ksteps = (nR + 3) >> 2;
-    const int t0 = blockIdx.y * tiles_per_wave, ntiles = (nrows + 15) >> 4;
     for (int t = t0; t < min(ntiles, t0 + tiles_per_wave); ++t) {
-        const int r = t * 16 + l15;
+        const int rl = (t - t0) * 16 + l15;  // row within the staged range
         double aop[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const int a = ks * 4 + kq;
-            aop[ks] = (ks < ksteps && r < nrows && a < nR) ? er[(size_t)r * nR + a] : 0.0;
+            aop[ks] = (ks < ksteps && rl < rcount && a < nR) ? sEr[rl * nR + a] : 0.0;
         }
         f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -999,10 +1006,17 @@ static hipError_t launch_hist_g(hipStream_t s, GridSpec gs, int p, int nrows_loc
                                 const double* d_w, double* d_g) {
     const int n = kLevels * gs.nSelCols, ntiles = (nrows_local + 15) / 16;
     const int gx = (n / 16 + 3) / 4;
-    // ~2560 waves on the chip (or one row tile per wave if the slab is short)
-    const int chunks = std::max(1, std::min(ntiles, (640 + gx - 1) / gx));
+    // ~2560 waves on the chip (or one row tile per wave if the slab is short); at most 16 tiles (256 rows x nR <= 32
+    // doubles = 64 KB of LDS) per workgroup
+    const int chunks = std::max(1, std::min(ntiles, std::max((640 + gx - 1) / gx, (ntiles + 15) / 16)));
     const int tpw = (ntiles + chunks - 1) / chunks;
-    hipLaunchKernelGGL(k_hist_g, dim3((unsigned)gx, (unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), 0, s, gs, p,
+    const size_t shm = (size_t)tpw * 16 * gs.nSelRows * sizeof(double);
+    if (shm > 48 * 1024) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_g), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)shm);
+        if (ea != hipSuccess) return ea;
+    }
+    hipLaunchKernelGGL(k_hist_g, dim3((unsigned)gx, (unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), shm, s, gs, p,
                        nrows_local, tpw, d_er, d_Ep, d_w, d_g);
     return hipGetLastError();
 }
@@ -1194,30 +1208,36 @@ __global__ void k_scatter_samples(int p, int L, const long long* __restrict__ lo
 __global__ __launch_bounds__(256) void k_hist_hh(int nC, int nR, int nrows, int slab_rows, const double* __restrict__ er,
                                                  const double* __restrict__ h, const double* __restrict__ Ep, int p, int ldp,
                                                  double* __restrict__ zpart) {
+    // the slab's er rows, staged once for the four waves (they were re-read from global memory inside the MFMA loop: a
+    // second dependent latency per 32 rows), and all of a lane's h loads of a 64-row half slab in flight together
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* sEr = reinterpret_cast<double*>(smem_raw);  // [slab_rows][nR]
     const int n = kLevels * nC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int r0 = blockIdx.y * slab_rows, rcount = min(nrows - r0, slab_rows);
+    for (int i = tid; i < rcount * nR; i += 256) sEr[i] = er[(size_t)r0 * nR + i];
     const int n0 = (blockIdx.x * 4 + wave) * 16;
-    if (n0 >= n) return;  // wave-uniform
     const int col = n0 + l15;
     const bool col_ok = col < n;
-    const int r0 = blockIdx.y * slab_rows;
     const bool two = nR > 16;
     f64x4 acc0 = f64x4{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
-    for (int k0 = 0; k0 < slab_rows; k0 += 32) {
-        double bop[8];
+    __syncthreads();
+    if (n0 >= n) return;  // wave-uniform (after the barrier)
+    for (int k0 = 0; k0 < slab_rows; k0 += 64) {
+        double bop[16];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int r = r0 + k0 + ks * 4 + kq;
-            bop[ks] = (col_ok && r < nrows) ? h[(size_t)r * n + col] : 0.0;
+        for (int ks = 0; ks < 16; ++ks) {
+            const int rl = k0 + ks * 4 + kq;
+            bop[ks] = (col_ok && rl < rcount) ? h[(size_t)(r0 + rl) * n + col] : 0.0;
         }
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int r = r0 + k0 + ks * 4 + kq;
-            const bool rok = r < nrows;
-            const double a0 = (rok && l15 < nR) ? er[(size_t)r * nR + l15] : 0.0;
+        for (int ks = 0; ks < 16; ++ks) {
+            const int rl = k0 + ks * 4 + kq;
+            const bool rok = rl < rcount;
+            const double a0 = (rok && l15 < nR) ? sEr[rl * nR + l15] : 0.0;
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bop[ks], acc0, 0, 0, 0);
             if (two) {
-                const double a1 = (rok && 16 + l15 < nR) ? er[(size_t)r * nR + 16 + l15] : 0.0;
+                const double a1 = (rok && 16 + l15 < nR) ? sEr[rl * nR + 16 + l15] : 0.0;
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bop[ks], acc1, 0, 0, 0);
             }
         }
@@ -1274,7 +1294,8 @@ static int hist_slab_rows(GridSpec gs, int nrows_local) {
     const int want = std::max(1, (4096 + ncoltiles - 1) / ncoltiles);   // slabs wanted
     int rows = (nrows_local + want - 1) / want;
     rows = std::max(64, ((rows + 31) / 32) * 32);
-    return rows;
+    const int lds_rows = ((8192 / std::max(gs.nSelRows, 1)) / 32) * 32;  // k_hist_hh stages the slab's er rows: <= 64 KB
+    return std::min(rows, std::max(64, lds_rows));
 }
 size_t hist_tiled_workspace_elems(GridSpec gs, int nrows_local) {
     const size_t n = (size_t)kLevels * gs.nSelCols;
@@ -1341,8 +1362,16 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
 #undef NLE_HP
     }
     Scope sc(obs, SUB_HIST_HH);
-    hipLaunchKernelGGL(k_hist_hh, dim3((unsigned)((n / 16 + 3) / 4), (unsigned)nslabs), dim3(256), 0, s, nC, nR,
-                       nrows_local, slab_rows, d_er, d_h, d_Ep, p, ldp, d_HH);
+    {
+        const size_t shm_hh = (size_t)slab_rows * nR * sizeof(double);  // slab_rows <= 1024 in practice; nR <= 32
+        if (shm_hh > 48 * 1024) {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist_hh),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_hh);
+            if (ea != hipSuccess) return ea;
+        }
+        hipLaunchKernelGGL(k_hist_hh, dim3((unsigned)((n / 16 + 3) / 4), (unsigned)nslabs), dim3(256), shm_hh, s, nC, nR,
+                           nrows_local, slab_rows, d_er, d_h, d_Ep, p, ldp, d_HH);
+    }
     hipLaunchKernelGGL(k_z_reduce, dim3((unsigned)((ldp + 7) / 8)), dim3(256), 0, s, d_HH, nslabs * (kLevels / 16), p, ldp, d_z);
     return hipGetLastError();
 }

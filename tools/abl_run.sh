@@ -5,7 +5,7 @@ L=$ROOT/nonlocal-image-edit_amd/lib
 cp $L/libnle_hip.so /tmp/libnle_hip.keep
 for v in "$@"; do
   cp $L/abl_$v.so $L/libnle_hip.so
-  timeout -k 10 120 python $ROOT/bench.py --no-cpu-baseline --h2h-runs 0 --steps 10 --warmup 3 > /tmp/abl_$v.json 2> /tmp/abl_$v.err
+  timeout -k 10 120 python $ROOT/bench.py --no-cpu-baseline --no-pipelined --h2h-runs 0 --steps 10 --warmup 3 > /tmp/abl_$v.json 2> /tmp/abl_$v.err
   python - <<PY
 import json
 try:

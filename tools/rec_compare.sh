@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 for cfg in cfg4 cfg3 cfg5 cfg2; do
   for t in rec table; do
     if [ $t = table ]; then export NLE_SORTED_TABLE=1; else unset NLE_SORTED_TABLE; fi
-    timeout -k 10 200 python $ROOT/bench.py --config $cfg --no-cpu-baseline --h2h-runs 0 --steps 5 --warmup 2 > /tmp/rc.json 2> /tmp/rc.err
+    timeout -k 10 200 python $ROOT/bench.py --config $cfg --no-cpu-baseline --no-pipelined --h2h-runs 0 --steps 5 --warmup 2 > /tmp/rc.json 2> /tmp/rc.err
     python - <<PY
 import json
 try:
