@@ -208,6 +208,12 @@ private:
     std::shared_ptr<nle_filter> fh_;  // nle_filter_destroy when the last copy goes
     nle_filter* f_ = nullptr;         // == fh_.get()
     int rows_ = 0, cols_ = 0;
+    // NLE_DEVICES=<dev>,<dev>,...: trainForEnhancement / enhance shard the image by row slabs over one context (and
+    // one host thread per call) per listed device; rank r's filter is group_[r] and f_ == group_[0].get()
+    std::vector<std::shared_ptr<nle_filter>> group_;
+    void trainForEnhancementGroup(const Image& image, int nRowSamples, int nColSamples, DType hx, DType hy,
+                                  int nSinkhornIter, int nEigenVectors);
+    Image enhanceGroup(const Image& image, const std::vector<DType>& weights) const;
 };
 
 }  // namespace nle

@@ -7,7 +7,12 @@
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
+#include <algorithm>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "nle.h"
 
@@ -31,6 +36,147 @@ nle_ctx* shared_ctx() {
 
 void check(int status, nle_ctx* ctx) {
     if (status != NLE_OK) throw std::runtime_error(nle_last_error(ctx));
+}
+
+// ---- NLE_DEVICES=<dev>,<dev>,...  (SURVEY.md section 8e through the reference's own surface) ----
+// One context per listed device, created once per process; rank r owns image rows nle_slab_rows(H, r, G) and hands the
+// library only those (nle_ctx_set_slab_input).  All-reduces: the library's own RCCL communicator when the devices are
+// distinct (ncclCommInitRank from G threads), otherwise -- the same device listed more than once, a rehearsal on one
+// GPU -- a host-mediated sum in rank order behind a thread barrier, so that every rank sees bitwise the same sums.
+struct DeviceGroup {
+    std::vector<int> devs;
+    std::vector<nle_ctx*> ctx;
+    bool native = false;
+    // host-mediated all-reduce
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    long long generation = 0;
+    bool failed = false;
+    std::vector<std::vector<double>> slot;  // one per rank
+    std::vector<void*> d_comm;
+    struct Rank { DeviceGroup* g; int r; };
+    std::vector<Rank> ranks;
+
+    int size() const { return (int)devs.size(); }
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed) throw std::runtime_error("nle: another rank of the device group failed");
+        const long long gen = generation;
+        if (++arrived == size()) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen || failed; });
+            if (failed) throw std::runtime_error("nle: another rank of the device group failed");
+        }
+    }
+    void fail() {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        cv.notify_all();
+    }
+    static int allreduce_cb(void* user, void* d_buf, size_t count) {
+        Rank* me = static_cast<Rank*>(user);
+        DeviceGroup* g = me->g;
+        try {
+            std::vector<double>& mine = g->slot[me->r];
+            mine.resize(count);
+            if (nle_dev_download(g->ctx[me->r], mine.data(), d_buf, count * sizeof(double)) != NLE_OK) return 1;
+            g->barrier();  // every slot is filled
+            std::vector<double> sum(count, 0.0);
+            for (int r = 0; r < g->size(); ++r)  // rank order: identical on every rank
+                for (size_t i = 0; i < count; ++i) sum[i] += g->slot[r][i];
+            g->barrier();  // every rank has read every slot
+            return nle_dev_upload(g->ctx[me->r], d_buf, sum.data(), count * sizeof(double)) == NLE_OK ? 0 : 1;
+        } catch (...) {
+            return 1;
+        }
+    }
+    // fn(rank) on one thread per rank; the first exception is rethrown after all threads have ended
+    template <typename Fn>
+    void run(Fn&& fn) {
+        std::vector<std::thread> th;
+        std::vector<std::exception_ptr> err(size());
+        for (int r = 0; r < size(); ++r)
+            th.emplace_back([&, r] {
+                try {
+                    fn(r);
+                } catch (...) {
+                    err[r] = std::current_exception();
+                    fail();
+                }
+            });
+        for (auto& t : th) t.join();
+        for (auto& e : err)
+            if (e) std::rethrow_exception(e);
+    }
+};
+
+// nullptr unless NLE_DEVICES lists at least two devices
+DeviceGroup* device_group(int p_samples) {
+    static DeviceGroup* g = nullptr;
+    static bool looked = false;
+    if (!looked) {
+        looked = true;
+        const char* e = std::getenv("NLE_DEVICES");
+        std::vector<int> devs;
+        if (e) {
+            std::string s(e);
+            size_t pos = 0;
+            while (pos <= s.size()) {
+                const size_t c = s.find(',', pos);
+                const std::string tok = s.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+                if (!tok.empty()) devs.push_back(std::stoi(tok));
+                if (c == std::string::npos) break;
+                pos = c + 1;
+            }
+        }
+        if (devs.size() >= 2) {
+            g = new DeviceGroup;
+            g->devs = devs;
+            std::vector<int> sorted(devs);
+            std::sort(sorted.begin(), sorted.end());
+            g->native = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
+            const int G = g->size();
+            g->ctx.resize(G, nullptr);
+            g->slot.resize(G);
+            g->d_comm.resize(G, nullptr);
+            g->ranks.resize(G);
+            for (int r = 0; r < G; ++r) {
+                if (nle_ctx_create(devs[r], nullptr, &g->ctx[r]) != NLE_OK)
+                    throw std::runtime_error(std::string("nle: cannot create GPU context: ") + nle_last_error(nullptr));
+                if (const char* m = std::getenv("NLE_MODE")) nle_ctx_set_mode(g->ctx[r], std::atoi(m));
+                g->ranks[r] = DeviceGroup::Rank{g, r};
+            }
+        }
+    }
+    if (g && p_samples > 0) {
+        // (re)bind the communicator for this sample count: the callback form needs a comm buffer of nle_comm_len(p)
+        static int bound_p = -1;
+        if (bound_p != p_samples) {
+            const int G = g->size();
+            if (g->native) {
+                if (bound_p < 0) {
+                    unsigned char id[NLE_RCCL_UNIQUE_ID_BYTES];
+                    check(nle_rccl_unique_id(id, sizeof id), nullptr);
+                    g->run([&](int r) { check(nle_ctx_init_rccl(g->ctx[r], r, G, id, sizeof id), g->ctx[r]); });
+                }
+            } else {
+                const size_t len = nle_comm_len(p_samples);
+                for (int r = 0; r < G; ++r) {
+                    if (g->d_comm[r]) nle_dev_free(g->ctx[r], g->d_comm[r]);
+                    check(nle_dev_alloc(g->ctx[r], len * sizeof(double), &g->d_comm[r]), g->ctx[r]);
+                    check(nle_ctx_set_shard(g->ctx[r], r, G, &DeviceGroup::allreduce_cb, &g->ranks[r],
+                                            static_cast<double*>(g->d_comm[r]), len), g->ctx[r]);
+                }
+            }
+            for (int r = 0; r < G; ++r) check(nle_ctx_set_slab_input(g->ctx[r], 1), g->ctx[r]);
+            bound_p = p_samples;
+        }
+    }
+    return g;
 }
 
 // RAII device buffer through the ABI helpers
@@ -409,6 +555,7 @@ void NLEFilter::trainOnDevice(const float* d_lum, int rows, int cols, int nRowSa
     ctx_ = shared_ctx();
     fh_.reset();
     f_ = nullptr;
+    group_.clear();
     if (verbose) {
         // the four stages run as one fused GPU pipeline; the banners keep the reference's stdout (:483-498)
         std::cout << "Computing kernel" << std::endl;
@@ -436,6 +583,14 @@ void NLEFilter::trainForEnhancement(const Image& image, int nRowSamples, int nCo
     if (image.channels() != 3 || image.depth() != NLE_8U) throw std::runtime_error("Can only enhance RGB image.");
     if (nRowSamples > image.rows || nColSamples > image.cols)
         throw std::runtime_error("Number of samples per row and col must be <= that of image.");
+    if (std::getenv("NLE_DEVICES") != nullptr) {
+        int rs, ro, nr, cs, co, nc;
+        if (nle_sample_grid(image.rows, image.cols, nRowSamples, nColSamples, &rs, &ro, &nr, &cs, &co, &nc) == NLE_OK &&
+            device_group(nr * nc) != nullptr) {
+            trainForEnhancementGroup(image, nRowSamples, nColSamples, hx, hy, nSinkhornIter, nEigenVectors);
+            return;
+        }
+    }
     // getLuminanceChannel (:460-469) on the device: BGR -> Lab (8 bit) -> L as float
     ctx_ = shared_ctx();
     const size_t n = image.total();
@@ -586,8 +741,87 @@ std::vector<Image> NLEFilter::applyLayers(const Image& channel, int nLayers) con
     return out;
 }
 
+// ---- NLE_DEVICES: the two calls of the `enhance` CLI over a device group (row slabs, slab input) ----
+void NLEFilter::trainForEnhancementGroup(const Image& image, int nRowSamples, int nColSamples, DType hx, DType hy,
+                                         int nSinkhornIter, int nEigenVectors) {
+    int rs, ro, nr, cs, co, nc;
+    check(nle_sample_grid(image.rows, image.cols, nRowSamples, nColSamples, &rs, &ro, &nr, &cs, &co, &nc), nullptr);
+    DeviceGroup* g = device_group(nr * nc);
+    const int G = g->size(), H = image.rows, W = image.cols;
+    if (G > H) throw std::runtime_error("more devices than image rows");
+    fh_.reset();
+    f_ = nullptr;
+    group_.assign(G, nullptr);
+    if (verbose) {
+        std::cout << "Computing kernel" << std::endl;
+        std::cout << "Nystrom approximation" << std::endl;
+        std::cout << "Sinkhorn" << std::endl;
+        std::cout << "Orthogonalize" << std::endl;
+    }
+    std::vector<nle_filter*> fs(G, nullptr);
+    g->run([&](int r) {
+        nle_ctx* c = g->ctx[r];
+        int r0 = 0, r1 = 0;
+        check(nle_slab_rows(H, r, G, &r0, &r1), c);
+        const size_t nl = (size_t)(r1 - r0) * W;
+        Dev d_bgr(c, nl * 3), d_L(c, nl * 4);
+        check(nle_dev_upload(c, d_bgr.p, image.ptr<unsigned char>() + (size_t)r0 * W * 3, nl * 3), c);
+        check(nle_bgr2lab8(c, static_cast<unsigned char*>(d_bgr.p), (long long)nl, nullptr, d_L.f()), c);
+        check(nle_train(c, d_L.f(), H, W, nRowSamples, nColSamples, hx, hy, nSinkhornIter, nEigenVectors, &fs[r]), c);
+    });
+    for (int r = 0; r < G; ++r) group_[r].reset(fs[r], [](nle_filter* f) { nle_filter_destroy(f); });
+    ctx_ = g->ctx[0];
+    fh_ = group_[0];
+    f_ = fh_.get();
+    rows_ = H;
+    cols_ = W;
+    if (verbose) {
+        Vec ev = eigvals();
+        const int nshow = std::min(std::min(nEigenVectors, 5), ev.size());
+        double mn[5], mx[5];
+        for (int i = 0; i < nshow; ++i) mn[i] = 1e300, mx[i] = -1e300;
+        for (int r = 0; r < G && nshow > 0; ++r) {  // min / max over the ranks' slabs
+            double a[5], b[5];
+            check(nle_filter_eigvec_range(group_[r].get(), nshow, a, b), g->ctx[r]);
+            for (int i = 0; i < nshow; ++i) mn[i] = std::min(mn[i], a[i]), mx[i] = std::max(mx[i], b[i]);
+        }
+        for (int i = 0; i < nshow; i++)
+            std::cout << "Eigvec " << i << " eigval: " << ev(i) << " minCoeff: " << mn[i] << " maxCoeff: " << mx[i]
+                      << std::endl;
+    }
+}
+
+Image NLEFilter::enhanceGroup(const Image& image, const std::vector<DType>& weights) const {
+    DeviceGroup* g = device_group(-1);
+    const int G = (int)group_.size(), H = image.rows, W = image.cols;
+    if (!g || G != g->size() || H != rows_ || W != cols_)
+        throw std::runtime_error(
+            "Cannot apply filter on image with different size from the image filter was trained on.");
+    const Vec fS = transformEigenValues(eigvals(), weights);
+    Image out(H, W, NLE_8U, 3);
+    g->run([&](int r) {
+        nle_ctx* c = g->ctx[r];
+        int r0 = 0, r1 = 0;
+        check(nle_slab_rows(H, r, G, &r0, &r1), c);
+        const size_t nl = (size_t)(r1 - r0) * W;
+        Dev d_bgr(c, nl * 3), d_lab(c, nl * 3), d_L(c, nl * 4), d_y(c, nl * 4);
+        check(nle_dev_upload(c, d_bgr.p, image.ptr<unsigned char>() + (size_t)r0 * W * 3, nl * 3), c);
+        check(nle_bgr2lab8(c, static_cast<unsigned char*>(d_bgr.p), (long long)nl, static_cast<unsigned char*>(d_lab.p),
+                           d_L.f()), c);
+        check(nle_apply(group_[r].get(), d_L.f(), H, W, fS.data(), d_y.f()), c);
+        check(nle_lab2bgr8(c, static_cast<unsigned char*>(d_lab.p), d_y.f(), (long long)nl,
+                           static_cast<unsigned char*>(d_bgr.p)), c);
+        check(nle_dev_download(c, out.ptr<unsigned char>() + (size_t)r0 * W * 3, d_bgr.p, nl * 3), c);
+    });
+    return out;
+}
+
 Image NLEFilter::enhance(const Image& image, const std::vector<DType>& weights) const {  // :412-443
     if (image.channels() != 3) throw std::runtime_error("Can only enhance RGB image.");
+    if (!group_.empty()) {
+        if (image.depth() != NLE_8U) throw std::runtime_error("Can only enhance RGB image.");
+        return enhanceGroup(image, weights);
+    }
     long long n = 0;
     if (f_) nle_filter_info(f_, &n, nullptr, nullptr, nullptr, nullptr, nullptr);
     if (!f_ || (long long)image.total() != n)

@@ -117,3 +117,31 @@ def test_enhance_cli_on_a_large_ppm_matches_the_python_pipeline(nle, oracle, ctx
     print("CLI vs python pipeline: max", d.max(), "mismatching values", (d > 0).mean())
     assert d.max() <= 3 and (d > 0).mean() < 5e-3     # rounding ties in the 8-bit conversions only
     f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_enhance_cli_over_a_device_group_matches_one_device(tmp_path, devices):
+    """NLE_DEVICES: `bin/enhance` shards the image by row slabs over one context and host thread per listed device
+    (slab input).  With the same device listed several times the all-reduces go through a
+    host-mediated sum in rank order (distinct devices use the library's RCCL communicator: needs more than one GPU);
+    the written image must be the single-device one up to isolated 8-bit rounding ties, the banners identical."""
+    from PIL import Image
+    src = os.path.join(GOLDEN, "flower-50.bmp")
+    args = ["10", "20", "100", "30", "50", "30", "2", "3", "4", "1"]
+    outs, texts = [], []
+    for tag, env in (("one", {}), ("group", {"NLE_DEVICES": devices})):
+        out = tmp_path / f"{tag}.png"
+        e = dict(os.environ)
+        e.pop("NLE_DEVICES", None)
+        e.update(env)
+        r = subprocess.run([ENHANCE, src, str(out)] + args, capture_output=True, text=True, timeout=300, env=e)
+        assert r.returncode == 0, r.stderr
+        outs.append(np.asarray(Image.open(out).convert("RGB")).astype(int))
+        texts.append(r.stdout.splitlines())
+    assert texts[0][:4] == texts[1][:4] and texts[0][-1] == texts[1][-1]
+    ev = [[float(l.split()[3]) for l in t if l.startswith("Eigvec ")] for t in texts]
+    assert len(ev[0]) == len(ev[1]) == 5 and np.allclose(ev[0], ev[1], rtol=1e-5)   # the banner prints 6 digits
+    d = np.abs(outs[0] - outs[1])
+    print("device group", devices, "vs one device: max", d.max(), "differing values", (d > 0).mean())
+    assert d.max() <= 2 and (d > 0).mean() < 1e-3
