@@ -146,6 +146,11 @@ int nle_eigen_decomposition(const double* h_M, int n, double eps, double* h_U, d
  * h_D receives ALL n eigenvalues (descending), h_U (n x min(kmax, n)) the first min(kmax, n) eigenvectors, *r the length
  * of the leading run >= eps.  For kmax <= n / 2 the eigenvectors come from inverse iteration on the tridiagonal form. */
 int nle_eigen_decomposition_top(const double* h_M, int n, double eps, int kmax, double* h_U, double* h_D, int* r);
+/* the same with the Householder reduction to tridiagonal form on the GPU (one workgroup, the matrix in registers; n <= 224)
+ * and the O(n^2) rest on the host -- what nle_train* uses for Q when K <= q / 2 and q <= 224 (NLE_HOST_TRIDIAG=1 keeps
+ * the whole solve on the host).  Same conventions; results agree with the host form to rounding. */
+int nle_eigen_decomposition_top_device(nle_ctx* ctx, const double* h_M, int n, double eps, int kmax, double* h_U, double* h_D,
+                                       int* r);
 /* topkEigenDecomposition, src/filter.cpp:170-199 (the USE_SPECTRA build's solver for Q): the min(n_largest, n - 1)
  * eigenpairs of largest magnitude of the FULL n x n matrix by Lanczos (tolerance 1e-10, <= 1000 restarts), algebraic
  * value descending, leading run >= eps kept.  h_U: n x min(n_largest, n - 1) col-major, h_D likewise; *r valid pairs. */

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "nle_slab_rows": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_int)] * 2),
     "nle_eigen_decomposition": (C.c_int, [_P, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),
     "nle_eigen_decomposition_top": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, _P, _P, C.POINTER(C.c_int)]),
+    "nle_eigen_decomposition_top_device": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_int, _P, _P, C.POINTER(C.c_int)]),
     "nle_topk_eigen_decomposition": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),
     "nle_transform_eigenvalues": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     "nle_layer_responses": (C.c_int, [_P, C.c_int, C.c_int, _P]),
@@ -323,6 +324,18 @@ class Context:
         buf = (C.c_char * max(n, 1)).from_address(ptr.value)
         self._pinned.append(ptr)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def eigen_decomposition_top_device(self, M, kmax: int, eps: float = EPS):
+        """eigen_decomposition_top with the tridiagonal reduction on the GPU (nle_eigen_decomposition_top_device; n <= 224)"""
+        M = np.asfortranarray(np.asarray(M, dtype=np.float64))
+        n = M.shape[0]
+        k = min(int(kmax), n)
+        U = np.zeros((n, k), dtype=np.float64, order="F")
+        D = np.zeros(n, dtype=np.float64)
+        r = C.c_int()
+        _check(lib().nle_eigen_decomposition_top_device(self._h, _np_ptr(M), n, float(eps), int(kmax), _np_ptr(U), _np_ptr(D),
+                                                        C.byref(r)), self._h)
+        return np.ascontiguousarray(U), D, r.value
 
     def set_slab_input(self, on: bool = True):
         """planes passed to train / apply hold this rank's rows only (nle_ctx_set_slab_input); pass shape=(H, W)"""

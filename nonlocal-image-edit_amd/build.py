@@ -22,7 +22,7 @@ LIBDIR = os.path.join(HERE, "lib")
 BINDIR = os.path.join(HERE, "bin")
 LIB = os.path.join(LIBDIR, "libnle_hip.so")
 
-LIB_SOURCES = ["kernels.hip", "fused.hip", "sorted.hip", "generic64.hip", "colour.hip", "pipeline.hip", "eigen_sym.cpp"]
+LIB_SOURCES = ["kernels.hip", "fused.hip", "sorted.hip", "generic64.hip", "tridiag.hip", "colour.hip", "pipeline.hip", "eigen_sym.cpp"]
 ARCH = "gfx950"
 
 

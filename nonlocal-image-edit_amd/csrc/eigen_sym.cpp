@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <chrono>
+#include <cstdio>
 #include <thread>
 #include <vector>
 #if defined(__x86_64__)
@@ -265,7 +267,10 @@ struct Sweep {
     size_t first;  // index of the i = m-1 rotation in the (c, s) lists
 };
 
-bool ql_record(int n, double* d, double* e, std::vector<Sweep>& sweeps, std::vector<double>& cs, std::vector<double>& sn) {
+// RECORD == false: the same iteration (bit-identical eigenvalues) without keeping the rotations -- for callers that take
+// their eigenvectors from inverse iteration
+template <bool RECORD>
+bool ql_iterate(int n, double* d, double* e, std::vector<Sweep>& sweeps, std::vector<double>& cs, std::vector<double>& sn) {
     for (int i = 1; i < n; ++i) e[i - 1] = e[i];
     e[n - 1] = 0.0;
     double f = 0.0, tst1 = 0.0;
@@ -295,7 +300,7 @@ bool ql_record(int n, double* d, double* e, std::vector<Sweep>& sweeps, std::vec
                 double c = 1.0, c2 = c, c3 = c;
                 const double el1 = e[l + 1];
                 double s = 0.0, s2 = 0.0;
-                sweeps.push_back(Sweep{l, m, cs.size()});
+                if (RECORD) sweeps.push_back(Sweep{l, m, cs.size()});
                 for (int i = m - 1; i >= l; --i) {
                     c3 = c2;
                     c2 = c;
@@ -308,8 +313,10 @@ bool ql_record(int n, double* d, double* e, std::vector<Sweep>& sweeps, std::vec
                     c = p / r;
                     p = c * d[i] - s * g;
                     d[i + 1] = h + s * (c * g + s * d[i]);
-                    cs.push_back(c);
-                    sn.push_back(s);
+                    if (RECORD) {
+                        cs.push_back(c);
+                        sn.push_back(s);
+                    }
                 }
                 p = -s * s2 * c3 * el1 * e[l] / dl1;
                 e[l] = s * p;
@@ -320,6 +327,15 @@ bool ql_record(int n, double* d, double* e, std::vector<Sweep>& sweeps, std::vec
         e[l] = 0.0;
     }
     return true;
+}
+
+bool ql_record(int n, double* d, double* e, std::vector<Sweep>& sweeps, std::vector<double>& cs, std::vector<double>& sn) {
+    return ql_iterate<true>(n, d, e, sweeps, cs, sn);
+}
+bool ql_values(int n, double* d, double* e) {
+    std::vector<Sweep> sweeps;
+    std::vector<double> cs, sn;
+    return ql_iterate<false>(n, d, e, sweeps, cs, sn);
 }
 
 // Rows [k0, k0 + 8 NV) of Z (column-major, leading dimension ldz, a multiple of 8): every sweep's rotations,
@@ -673,7 +689,7 @@ bool tridiag_inverse_iteration(int n, const double* d, const double* e, const do
         onenrm = std::max(onenrm, std::fabs(d[i]) + (i > 0 ? std::fabs(e[i]) : 0.0) + (i + 1 < n ? std::fabs(e[i + 1]) : 0.0));
     if (onenrm == 0.0) onenrm = 1.0;
     const double ortol = 1e-3 * onenrm, tiny = eps * onenrm;
-    std::vector<double> a(n), b(n), c(n), dd(n), x(n), y(n);
+    std::vector<double> a(n), ra(n), b(n), c(n), dd(n), x(n), y(n);
     std::vector<char> piv(n);
     int gp = 0;  // first vector of the current cluster
     double prev = 0.0;
@@ -715,6 +731,7 @@ bool tridiag_inverse_iteration(int n, const double* d, const double* e, const do
             }
         }
         if (std::fabs(a[n - 1]) < tiny) a[n - 1] = std::copysign(tiny, a[n - 1] == 0.0 ? 1.0 : a[n - 1]);
+        for (int i = 0; i < n; ++i) ra[i] = 1.0 / a[i];  // the back substitution is a dependent chain: multiply, not divide
         for (int i = 0; i < n; ++i) {
             seed ^= seed << 13, seed ^= seed >> 7, seed ^= seed << 17;
             x[i] = (double)(seed >> 11) * (1.0 / 9007199254740992.0) - 0.5;
@@ -735,7 +752,7 @@ bool tridiag_inverse_iteration(int n, const double* d, const double* e, const do
                 double t = y[i];
                 if (i + 1 < n) t -= b[i] * x[i + 1];
                 if (i + 2 < n) t -= dd[i] * x[i + 2];
-                x[i] = t / a[i];
+                x[i] = t * ra[i];
             }
             for (int pass = 0; pass < 2; ++pass)  // the cluster's earlier vectors
                 for (int q = gp; q < j; ++q) {
@@ -766,25 +783,29 @@ bool tridiag_inverse_iteration(int n, const double* d, const double* e, const do
     return true;
 }
 
-bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, double* D) {
-    if (n <= 0) return true;
-    ncols = std::max(0, std::min(ncols, n));
-    if (n == 1) {
-        D[0] = M[0];
-        if (ncols) U[0] = 1.0;
-        return true;
-    }
+// The part of sym_eigen_top after the reduction: V (n x n, u_i in column i rows 0..i-1), hs, and the tridiagonal (d, e) as
+// tridiag_reduce -- or the device kernel k_tridiag (tridiag.hip), same conventions -- leaves them.
+bool sym_eigen_top_reduced(int n, const double* V, const double* d_in, const double* e_in, const double* hs, int ncols,
+                           int nthreads, double* U, double* D) {
     if (nthreads <= 0) nthreads = default_threads(n, ncols);
-    std::vector<double> V((size_t)n * n), d(n), e(n), hs(n);
-    for (int c = 0; c < n; ++c)  // mirror the lower triangle (SelfAdjointEigenSolver reads only the lower one)
-        for (int r = 0; r < n; ++r) V[(size_t)c * n + r] = (r >= c) ? M[(size_t)c * n + r] : M[(size_t)r * n + c];
-    tridiag_reduce(n, V.data(), d.data(), e.data(), hs.data());
+    static const bool trace = std::getenv("NLE_EIG_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = trace ? now() : 0.0;
+    std::vector<double> d(d_in, d_in + n), e(e_in, e_in + n);
     const std::vector<double> d0(d), e0(e);  // T itself (the QL iteration overwrites d and e)
     std::vector<Sweep> sweeps;
     std::vector<double> cs, sn;
-    cs.reserve((size_t)n * n);
-    sn.reserve((size_t)n * n);
-    if (!ql_record(n, d.data(), e.data(), sweeps, cs, sn)) return false;
+    // a leading part of the spectrum: the eigenvectors come from inverse iteration, the rotations are not needed (should
+    // the inverse iteration give up, the iteration is repeated with recording below)
+    const bool invit = ncols > 0 && 2 * ncols <= n && std::getenv("NLE_EIG_NO_INVIT") == nullptr;
+    if (invit || ncols == 0) {
+        if (!ql_values(n, d.data(), e.data())) return false;
+    } else {
+        cs.reserve((size_t)n * n);
+        sn.reserve((size_t)n * n);
+        if (!ql_record(n, d.data(), e.data(), sweeps, cs, sn)) return false;
+    }
+    const double t1 = trace ? now() : 0.0;
     // descending order (stable on the ascending sort the classic path uses, reversed)
     std::vector<int> idx(n);
     std::iota(idx.begin(), idx.end(), 0);
@@ -792,16 +813,26 @@ bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, d
     std::reverse(idx.begin(), idx.end());
     for (int j = 0; j < n; ++j) D[j] = d[idx[j]];
     if (ncols == 0) return true;
-    if (2 * ncols <= n && std::getenv("NLE_EIG_NO_INVIT") == nullptr) {
+    if (invit) {
         // a leading part of the spectrum only: inverse iteration on T for those eigenvalues, then the back-transformation
         if (tridiag_inverse_iteration(n, d0.data(), e0.data(), D, ncols, U)) {
+            const double t2 = trace ? now() : 0.0;
             const int cparts0 = std::max(1, std::min(nthreads, (ncols + 3) / 4));
             run_split(cparts0, nthreads, [&](int q) {
                 const int j0 = (int)((long long)ncols * q / cparts0), j1 = (int)((long long)ncols * (q + 1) / cparts0);
-                back_transform_cols(n, V.data(), hs.data(), U, j0, j1);
+                back_transform_cols(n, V, hs, U, j0, j1);
             });
+            if (trace)
+                std::fprintf(stderr, "[nle eig] n = %d, %d vectors: QL %.3f ms, inverse iteration %.3f ms, back-transformation %.3f ms\n",
+                             n, ncols, t1 - t0, t2 - t1, now() - t2);
             return true;
         }
+        // inverse iteration gave up: the rotations after all (same iteration, same eigenvalues)
+        d = d0;
+        e = e0;
+        cs.reserve((size_t)n * n);
+        sn.reserve((size_t)n * n);
+        if (!ql_record(n, d.data(), e.data(), sweeps, cs, sn)) return false;
     }
     const int ldz = (n + 7) & ~7;  // rows padded to whole 8-row vectors (the padding stays zero)
     // (64-byte aligned: the 64-row blocks of different threads then never share a cache line)
@@ -817,8 +848,35 @@ bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, d
     const int cparts = std::max(1, std::min(nthreads, (ncols + 3) / 4));
     run_split(cparts, nthreads, [&](int q) {
         const int j0 = (int)((long long)ncols * q / cparts), j1 = (int)((long long)ncols * (q + 1) / cparts);
-        back_transform_cols(n, V.data(), hs.data(), U, j0, j1);
+        back_transform_cols(n, V, hs, U, j0, j1);
     });
+    return true;
+}
+
+bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, double* D) {
+    if (n <= 0) return true;
+    ncols = std::max(0, std::min(ncols, n));
+    if (n == 1) {
+        D[0] = M[0];
+        if (ncols) U[0] = 1.0;
+        return true;
+    }
+    std::vector<double> V((size_t)n * n), d(n), e(n), hs(n);
+    for (int c = 0; c < n; ++c)  // mirror the lower triangle (SelfAdjointEigenSolver reads only the lower one)
+        for (int r = 0; r < n; ++r) V[(size_t)c * n + r] = (r >= c) ? M[(size_t)c * n + r] : M[(size_t)r * n + c];
+    tridiag_reduce(n, V.data(), d.data(), e.data(), hs.data());
+    return sym_eigen_top_reduced(n, V.data(), d.data(), e.data(), hs.data(), ncols, nthreads, U, D);
+}
+
+// eigen_decomposition_top for a matrix already reduced (n >= 2, kmax <= n): all eigenvalues descending in D, the first kmax
+// eigenvectors in U, *r_out = length of the leading run >= eps (reference src/filter.cpp:209-216)
+bool eigen_decomposition_top_reduced(int n, double eps, int kmax, const double* V, const double* d, const double* e,
+                                     const double* hs, double* U, double* D, int* r_out) {
+    kmax = std::max(0, std::min(kmax, n));
+    if (!sym_eigen_top_reduced(n, V, d, e, hs, kmax, 0, U, D)) return false;
+    int r = 0;
+    while (r < n && D[r] >= eps) ++r;
+    *r_out = r;
     return true;
 }
 
@@ -838,11 +896,7 @@ bool sym_eigen_select(const double* M, int n, double* D, int first, int count, d
         for (int r = 0; r < n; ++r) V[(size_t)c * n + r] = (r >= c) ? M[(size_t)c * n + r] : M[(size_t)r * n + c];
     tridiag_reduce(n, V.data(), d.data(), e.data(), hs.data());
     const std::vector<double> d0(d), e0(e);
-    std::vector<Sweep> sweeps;
-    std::vector<double> cs, sn;
-    cs.reserve((size_t)n * n);
-    sn.reserve((size_t)n * n);
-    if (!ql_record(n, d.data(), e.data(), sweeps, cs, sn)) return false;
+    if (!ql_values(n, d.data(), e.data())) return false;
     std::sort(d.begin(), d.end(), [](double a, double b) { return a > b; });
     std::copy(d.begin(), d.end(), D);
     if (kept_out) {  // select the eigenvalues after the leading run >= below_eps, if there are at most max_below of them

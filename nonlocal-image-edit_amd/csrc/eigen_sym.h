@@ -26,6 +26,12 @@ bool eigen_decomposition_top(const double* M, int n, double eps, int kmax, doubl
 // default (1; NLE_EIG_THREADS overrides).  The rotation and back-transformation phases need no barriers and
 // can run on short-lived threads.
 bool sym_eigen_top(const double* M, int n, int ncols, int nthreads, double* U, double* D);
+// the same for a matrix already reduced to tridiagonal form (V, hs: the Householder vectors and scales; d, e: T), e.g.
+// by the device kernel of tridiag.hip; and eigen_decomposition_top on top of it
+bool sym_eigen_top_reduced(int n, const double* V, const double* d, const double* e, const double* hs, int ncols,
+                           int nthreads, double* U, double* D);
+bool eigen_decomposition_top_reduced(int n, double eps, int kmax, const double* V, const double* d, const double* e,
+                                     const double* hs, double* U, double* D, int* r);
 
 // All n eigenvalues DESCENDING in D and the eigenvectors of D[first .. first + count) in U (n x count), the latter by
 // inverse iteration on the tridiagonal form (cheap when count << n).  false: no convergence.

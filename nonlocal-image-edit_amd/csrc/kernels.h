@@ -157,6 +157,12 @@ hipError_t scatter_rows64(hipStream_t s, const double* d_src, const long long* d
 hipError_t to_f32(hipStream_t s, const double* d_X, long long n, float* d_out);
 hipError_t scale_rows64(hipStream_t s, double* d_X, int m, int n, const double* d_dl);  // X (m x n col-major) <- diag(dl) X
 
+// ---- one-workgroup Householder tridiagonalisation (tridiag.hip): Q n x n col-major (lower triangle read), n <= tridiag_max_n();
+// outputs in the conventions of nleh::tridiag_reduce (V: u_i in column i rows 0..i-1; hs; d, e)
+int tridiag_max_n();
+hipError_t tridiag(hipStream_t s, int n, const double* d_Q, const double* d_diag_add, double* d_V, double* d_d, double* d_e,
+                   double* d_hs);
+
 // ---- level-sorted rows (sorted.hip): the pixel halves of the table passes without LDS atomics
 constexpr int kSortedThreads = 512;
 struct SortedRows {

@@ -510,7 +510,9 @@ static int sorted_grid(int nrows) {
     int ncu = 256;
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    return std::max(1, std::min(nrows, 2 * ncu));  // two 512-thread workgroups per CU, each walks its rows
+    int mult = 2;  // two 512-thread workgroups per CU, each walks its rows
+    if (const char* e = std::getenv("NLE_SORTED_WGS_PER_CU")) mult = std::max(1, std::atoi(e));  // measurement hook
+    return std::max(1, std::min(nrows, mult * ncu));
 }
 
 // Where the recurrence of column_factors stays inside the normal range of fp64 (with a wide margin): every e_b =

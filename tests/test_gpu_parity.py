@@ -484,3 +484,32 @@ def test_lanczos_topk_solver_for_Q_is_opt_in_and_agrees(nle, oracle, ctx, case):
             assert rel_l2(Y1[j], Y0[j]) < 1e-6, j
     f0.close()
     f1.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(16, 4), (57, 20), (196, 50), (200, 100), (224, 7)])
+def test_device_tridiagonalisation_gives_the_host_solver_s_eigenpairs(nle, ctx, n, k):
+    """k_tridiag (one workgroup, the matrix in registers) + the host's QL / inverse iteration / back-transformation against
+    numpy and against the all-host solver: eigenvalues of a matrix with a spectrum decaying to 1e-12 like Q's, a leading
+    block of eigenvectors, only the lower triangle read; also a matrix with zero rows (the scale == 0 branch)."""
+    rng = np.random.default_rng(n * 31 + k)
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.sort(np.concatenate([1.0 - 0.5 * rng.random(n // 3), 10.0 ** (-12 * rng.random(n - n // 3))]))[::-1]
+    M = (Qo * lam) @ Qo.T
+    M = 0.5 * (M + M.T)
+    Mlow = np.tril(M) + 7.0 * np.triu(rng.standard_normal((n, n)), 1)      # garbage above the diagonal must be ignored
+    U, D, r = ctx.eigen_decomposition_top_device(Mlow, k)
+    Uh, Dh, rh = nle.eigen_decomposition_top(Mlow, k)
+    w = np.linalg.eigvalsh(M)[::-1]
+    assert np.abs(D - w).max() < 1e-13 and np.abs(D - Dh).max() < 1e-13 and r == rh
+    assert np.abs(U.T @ U - np.eye(k)).max() < 1e-10
+    assert np.abs(M @ U - U * D[:k]).max() < 1e-12
+    # decoupled matrix: a zero row / column in the middle and a diagonal tail
+    M2 = M.copy()
+    M2[n // 2, :] = 0.0
+    M2[:, n // 2] = 0.0
+    M2[: n // 4, n // 4:] = 0.0
+    M2[n // 4:, : n // 4] = 0.0
+    U2, D2, _ = ctx.eigen_decomposition_top_device(M2, k)
+    assert np.abs(D2 - np.linalg.eigvalsh(M2)[::-1]).max() < 1e-13
+    assert np.abs(M2 @ U2 - U2 * D2[:k]).max() < 1e-12
