@@ -332,10 +332,89 @@ bool ql_iterate(int n, double* d, double* e, std::vector<Sweep>& sweeps, std::ve
 bool ql_record(int n, double* d, double* e, std::vector<Sweep>& sweeps, std::vector<double>& cs, std::vector<double>& sn) {
     return ql_iterate<true>(n, d, e, sweeps, cs, sn);
 }
-bool ql_values(int n, double* d, double* e) {
-    std::vector<Sweep> sweeps;
-    std::vector<double> cs, sn;
-    return ql_iterate<false>(n, d, e, sweeps, cs, sn);
+// Eigenvalues only, by the square-root-free QL variant of Pal, Walker and Kahan as LAPACK's dsterf organises it (implicit
+// Wilkinson shift; deflation where e_m^2 <= eps^2 |d_m d_{m+1}|; 2 x 2 blocks in closed form, dlae2): one reciprocal
+// and a handful of multiplications per rotation instead of tql2's two hypot calls -- 0.22 -> ~0.1 ms at n = 196.
+// d: diagonal, e[1..n): sub-diagonal (e[i] couples i-1 and i) on entry; d holds the eigenvalues (unsorted) on return.
+bool ql_values(int n, double* d, double* e2) {
+    if (n <= 1) return true;
+    if (std::getenv("NLE_EIG_TQL") != nullptr) {  // the rotation-based iteration (what ql_record runs)
+        std::vector<Sweep> sweeps;
+        std::vector<double> cs, sn;
+        return ql_iterate<false>(n, d, e2, sweeps, cs, sn);
+    }
+    const double eps = std::ldexp(1.0, -53), eps2 = eps * eps, safmin = 2.2250738585072014e-308;
+    double anorm = 0.0;
+    for (int i = 0; i < n; ++i) anorm = std::max(anorm, std::fabs(d[i]) + (i + 1 < n ? std::fabs(e2[i + 1]) : 0.0) + std::fabs(e2[i]));
+    if (anorm == 0.0) return true;
+    // scale to norm 1 (squares of tiny off-diagonals must not underflow), e2[i] := (e[i+1] / anorm)^2 couples i and i+1
+    const double scl = 1.0 / anorm;
+    for (int i = 0; i < n; ++i) d[i] *= scl;
+    for (int i = 0; i + 1 < n; ++i) {
+        const double t = e2[i + 1] * scl;
+        e2[i] = t * t;
+    }
+    e2[n - 1] = 0.0;
+    int iter_left = 60 * n;
+    for (int l = 0; l < n; ++l) {
+        for (;;) {
+            int m = l;
+            while (m + 1 < n) {
+                if (e2[m] <= eps2 * std::fabs(d[m] * d[m + 1]) + safmin) break;
+                ++m;
+            }
+            if (m + 1 < n) e2[m] = 0.0;  // the block [l, m] is decoupled from the rest
+            if (m == l) break;           // d[l] is an eigenvalue
+            if (m == l + 1) {   // 2 x 2 block [[a, b], [b, c]]: dlae2
+                const double a = d[l], c = d[l + 1], b = std::sqrt(e2[l]);
+                const double sm = a + c, df = a - c, adf = std::fabs(df), tb = b + b, ab = std::fabs(tb);
+                const double acmx = std::fabs(a) > std::fabs(c) ? a : c, acmn = std::fabs(a) > std::fabs(c) ? c : a;
+                double rt;
+                if (adf > ab) rt = adf * std::sqrt(1.0 + (ab / adf) * (ab / adf));
+                else if (adf < ab) rt = ab * std::sqrt(1.0 + (adf / ab) * (adf / ab));
+                else rt = ab * std::sqrt(2.0);
+                double rt1, rt2;
+                if (sm < 0.0) {
+                    rt1 = 0.5 * (sm - rt);
+                    rt2 = (acmx / rt1) * acmn - (b / rt1) * b;
+                } else if (sm > 0.0) {
+                    rt1 = 0.5 * (sm + rt);
+                    rt2 = (acmx / rt1) * acmn - (b / rt1) * b;
+                } else {
+                    rt1 = 0.5 * rt;
+                    rt2 = -0.5 * rt;
+                }
+                d[l] = rt1;
+                d[l + 1] = rt2;
+                e2[l] = 0.0;
+                ++l;  // both are done
+                break;
+            }
+            if (--iter_left < 0) return false;
+            // Wilkinson shift from the leading 2 x 2 block of [l, m]
+            const double rte = std::sqrt(e2[l]);
+            const double p0 = d[l];
+            double sigma = (d[l + 1] - p0) / (2.0 * rte);
+            const double r0 = hyp(sigma, 1.0);
+            sigma = p0 - rte / (sigma + (sigma >= 0.0 ? r0 : -r0));
+            double c = 1.0, sn = 0.0, gamma = d[m] - sigma, p = gamma * gamma;
+            for (int i = m - 1; i >= l; --i) {
+                const double bb = e2[i], r = p + bb;
+                if (i != m - 1) e2[i + 1] = sn * r;
+                const double oldc = c, rinv = 1.0 / r;
+                c = p * rinv;
+                sn = bb * rinv;
+                const double oldgam = gamma, alpha = d[i];
+                gamma = c * (alpha - sigma) - sn * oldgam;
+                d[i + 1] = oldgam + (alpha - gamma);
+                p = (c != 0.0) ? (gamma * gamma) / c : oldc * bb;
+            }
+            e2[l] = sn * p;
+            d[l] = sigma + gamma;
+        }
+    }
+    for (int i = 0; i < n; ++i) d[i] *= anorm;
+    return true;
 }
 
 // Rows [k0, k0 + 8 NV) of Z (column-major, leading dimension ldz, a multiple of 8): every sweep's rotations,
