@@ -570,7 +570,7 @@ hipError_t sorted_pass(hipStream_t s, int mode, GridSpec gs, int row0, int nrows
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------ Gram, per-row pair tables (nC <= 11)
+// ------------------------------------------------------------------ Gram, per-row pair tables (nC <= 11: one launch)
 // A_r[(b, b')][x] = sum_{i in row r, x_i = x} c_i^2 ec[c_i][b] ec[c_i][b'],  b <= b': what k_ghist_rows computes with
 // nC (nC + 1) / 2 LDS atomics per pixel.  Output layout [row][pair][level], as k_ghist_gemm / k_ghist_final expect.
 template <int NC, bool REC>
@@ -639,7 +639,96 @@ __global__ __launch_bounds__(kT) void k_sorted_gram(const unsigned short* __rest
     }
 }
 
-int sorted_gram_max_cols() { return 11; }
+// ------------------------------------------------------------------ Gram pair tables for wider grids (12 <= nC <= 36)
+// nC (nC + 1) / 2 accumulators do not fit in registers any more, so a launch takes BB = 64 / nC rows b0 .. b0 + nb - 1 of
+// the pair triangle: acc[i][b'] += q_{b0+i} q_{b'} for ALL b' (the b' < b half is computed and dropped: the row index b0 is
+// a run-time value and register arrays need static indices), the column factors by recurrence where the host allows it.
+// ceil(nC / BB) launches, each a pass over the sorted pixels; still no atomics: the pair tables of a 10 x 20 grid (most of
+// the reference's README runs) are bitwise reproducible like the rest.
+__host__ __device__ constexpr int gram_wide_bb(int nc) { return 64 / nc > 0 ? 64 / nc : 1; }
+
+template <int NC>
+__global__ __launch_bounds__(kT) void k_sorted_gram_wide(const unsigned short* __restrict__ scol, const uint2* __restrict__ desc,
+                                                         const unsigned short* __restrict__ first, GridSpec gs, int nrows,
+                                                         const double* __restrict__ Etab, const double* __restrict__ cvec,
+                                                         double* __restrict__ Aout, int rec, double kappa, int b0, int nb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NP = NC * (NC + 1) / 2;
+    constexpr int BB = gram_wide_bb(NC), NV = BB * NC;
+    constexpr int SL = 11, PS = SL;
+    const int W = gs.W;
+    double* sE = reinterpret_cast<double*>(smem_raw);
+    double* sP = sE + ((W + 2) & ~1);
+    unsigned short* sfirst = reinterpret_cast<unsigned short*>(sP + (size_t)kT * PS);
+    const int tid = threadIdx.x;
+    for (int i = tid; i <= W; i += kT) sE[i] = Etab[i];
+    const int cb0 = gs.colOff, cs = gs.colStep;
+    const unsigned sEa = lds_addr(sE);
+    const size_t pitch = sorted_row_pitch(W);
+    for (int lrow = blockIdx.x; lrow < nrows; lrow += gridDim.x) {
+        if (tid < 258) sfirst[tid] = first[(size_t)lrow * 258 + tid];
+        const uint2 dsc = desc[(size_t)lrow * kT + tid];
+        const int len = dsc_len(dsc);
+        double acc[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+        __syncthreads();
+        const uint2* slot = reinterpret_cast<const uint2*>(scol + (size_t)lrow * pitch + (size_t)tid * dsc_chp(dsc));
+        const double* cv_row = cvec + (size_t)lrow * W;
+        uint2 cur = slot[0];
+        for (int t0 = 0; t0 < len; t0 += 4) {  // four pixels per step, indices fetched one step ahead (zero padded slots)
+            const uint2 nxt = slot[(t0 >> 2) + 1];
+            double cfv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cfv[k] = cv_row[((((k & 2) ? cur.y : cur.x) >> ((k & 1) << 4)) & 0xffffu) >> 3];
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                const unsigned c8 = (((k & 2) ? cur.y : cur.x) >> ((k & 1) << 4)) & 0xffffu;
+                double cf = (k == 0) ? cfv[0] : (k == 1) ? cfv[1] : (k == 2) ? cfv[2] : cfv[3];
+                if (t0 + k >= len) cf = 0.0;  // padding adds exact zeros
+                double q[NC], qs[BB];
+#pragma unroll
+                for (int i = 0; i < BB; ++i) qs[i] = 0.0;
+                auto take = [&](const int b, const double ev) {
+                    q[b] = cf * ev;
+#pragma unroll
+                    for (int i = 0; i < BB; ++i)
+                        if (b == b0 + i) qs[i] = q[b];  // uniform
+                };
+                if (rec) column_factors<NC, true>(sEa, c8, cb0, cs, kappa, take);
+                else column_factors<NC, false>(sEa, c8, cb0, cs, kappa, take);
+#pragma unroll
+                for (int i = 0; i < BB; ++i)
+#pragma unroll
+                    for (int b2 = 0; b2 < NC; ++b2) acc[i * NC + b2] += qs[i] * q[b2];
+            }
+            cur = nxt;
+        }
+        const int steps = dsc_steps(dsc), j = dsc_j(dsc), m = dsc_m(dsc);
+        double* out = Aout + (size_t)lrow * kLevels * NP;
+#pragma unroll
+        for (int s0 = 0; s0 < NV; s0 += SL) {
+            double v[SL];
+#pragma unroll
+            for (int i = 0; i < SL; ++i) v[i] = (s0 + i < NV) ? acc[s0 + i] : 0.0;
+            combine_chunks<SL, PS>(v, sP, tid, len > 0, j, m, steps);
+            const int ns = (NV - s0 < SL) ? NV - s0 : SL;
+            for (int i = tid; i < ns * kLevels; i += kT) {
+                const int jj = i / kLevels, xx = i & (kLevels - 1);
+                const int f = s0 + jj, bi = f / NC, b2 = f - bi * NC, b = b0 + bi;
+                if (bi < nb && b2 >= b) {  // pair (b, b2), b <= b2, at its place in the triangle
+                    const int pair = b * NC - (b * (b - 1)) / 2 + (b2 - b);
+                    const int f0 = sfirst[xx];
+                    out[(size_t)pair * kLevels + xx] = sfirst[xx + 1] > f0 ? sP[f0 * PS + jj] : 0.0;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+int sorted_gram_max_cols() { return 36; }
+
 
 hipError_t sorted_gram_rows(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
                             const unsigned short* d_first, const double* d_E, const double* d_cvec, double* d_Aout, bool rec,
@@ -649,6 +738,29 @@ hipError_t sorted_gram_rows(hipStream_t s, GridSpec gs, int nrows_local, const u
     if (nrows_local <= 0) return hipSuccess;
     const size_t shm = sorted_lds_bytes(gs.W, 11);
     const int grid = sorted_grid(nrows_local);
+    if (nC > 11) {
+        const int bb = gram_wide_bb(nC);
+#define NLE_SGW(NCV)                                                                                                    \
+    case NCV: {                                                                                                         \
+        if (shm > 48 * 1024) {                                                                                          \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sorted_gram_wide<NCV>),                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                  \
+            if (ea != hipSuccess) return ea;                                                                            \
+        }                                                                                                               \
+        for (int b0 = 0; b0 < nC; b0 += bb)                                                                             \
+            hipLaunchKernelGGL((k_sorted_gram_wide<NCV>), dim3((unsigned)grid), dim3(kT), shm, s, d_scol, d_desc,       \
+                               d_first, gs, nrows_local, d_E, d_cvec, d_Aout, rec ? 1 : 0, kappa, b0,                    \
+                               std::min(bb, nC - b0));                                                                  \
+    } break;
+        switch (nC) {
+            NLE_SGW(12) NLE_SGW(13) NLE_SGW(14) NLE_SGW(15) NLE_SGW(16) NLE_SGW(17) NLE_SGW(18) NLE_SGW(19) NLE_SGW(20)
+            NLE_SGW(21) NLE_SGW(22) NLE_SGW(23) NLE_SGW(24) NLE_SGW(25) NLE_SGW(26) NLE_SGW(27) NLE_SGW(28) NLE_SGW(29)
+            NLE_SGW(30) NLE_SGW(31) NLE_SGW(32) NLE_SGW(33) NLE_SGW(34) NLE_SGW(35) NLE_SGW(36)
+            default: return hipErrorInvalidValue;
+        }
+#undef NLE_SGW
+        return hipGetLastError();
+    }
 #define NLE_SG1(NCV, RECV)                                                                                              \
     {                                                                                                                   \
         if (shm > 48 * 1024) {                                                                                          \
@@ -661,7 +773,7 @@ hipError_t sorted_gram_rows(hipStream_t s, GridSpec gs, int nrows_local, const u
     }
 #define NLE_SG(NCV)                                                                                                     \
     case NCV:                                                                                                           \
-        if (rec) return hipErrorInvalidValue; /* sorted Gram: nC <= 11, table form only */                              \
+        if (rec) return hipErrorInvalidValue; /* up to 11 columns: table form only */                                    \
         NLE_SG1(NCV, false)                                                                                             \
         break;
     switch (nC) {
