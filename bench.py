@@ -91,8 +91,10 @@ def roofline_models(info, L, form, grid, lazy=False):
             m["gram_gemm"] = ("mfma", 2.0 * ldm * 256.0 * npair * rows, FP64_MFMA_PEAK_TF)
             if lazy:  # V stays implicit: apply runs on the tables too (bytes the two kernels really move)
                 m["apply_reduce"] = ("hbm", srt + n * (8.0 + s) + tab, HBM_PEAK_GBS)      # sorted row, c, x in; h out
-                lb = max(1, min(L, 4, (144 * 1024) // (256 * (nC | 1) * 8)))             # layers per k_hist_dot launch
-                m["apply_expand"] = ("hbm", n * (s + 8.0) + lb * (tab + n * s), HBM_PEAK_GBS)  # luminance, c; per layer g in, y out
+                lb = max(1, min(L, 4, (144 * 1024) // (256 * (nC | 1) * 8)))             # layers per expand launch
+                W_img = n / max(rows, 1)
+                px_in = srt if (nC <= 12 and W_img <= 4096) else n * s   # k_sorted_expand reads the sorted row, k_hist_dot the luminance
+                m["apply_expand"] = ("hbm", px_in + n * 8.0 + lb * (tab + n * s), HBM_PEAK_GBS)  # pixels, c; per layer g in, y out
     return m
 
 
@@ -124,7 +126,7 @@ def kernel_symbols(form, lazy):
         sym.update({"sinkhorn_pass": ("k_sorted_pass", "k_hist_pix"), "sink_tables": ("k_hist_g",),
                     "gram_rows": ("k_sorted_gram", "k_ghist_rows"), "gram_gemm": ("k_ghist_gemm",)})
         if lazy:  # the apply's reduce half is the pass kernel in its XVEC mode: same symbol as the Sinkhorn pass
-            sym.update({"apply_expand": ("k_hist_dot",), "apply_reduce": ("k_sorted_pass", "k_hist_pix")})
+            sym.update({"apply_expand": ("k_sorted_expand", "k_hist_dot"), "apply_reduce": ("k_sorted_pass", "k_hist_pix")})
     return sym
 
 

@@ -1388,7 +1388,7 @@ int apply_layers_per_launch(GridSpec gs) {
 hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
                              const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_wl, int ldw,
                              int nl, const double* d_c, double* d_ws, float* d_out, long long ostride,
-                             LaunchObserver* obs) {
+                             LaunchObserver* obs, const SortedRows* sorted) {
     const int nC = gs.nSelCols, nR = gs.nSelRows;
     if (nC > 36 || nR > 32 || nrows_local <= 0) return nrows_local <= 0 ? hipSuccess : hipErrorInvalidValue;
     if (nl < 1 || nl > apply_layers_per_launch(gs)) return hipErrorInvalidValue;
@@ -1399,6 +1399,13 @@ hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int
         if (eg != hipSuccess) return eg;
     }
     if (obs) obs->end(), obs->begin(SUB_HIST_PIX);
+    if (sorted != nullptr && nC <= sorted_expand_max_cols() && gs.W <= sorted_expand_max_width() &&
+        nl <= sorted_expand_layers() && std::getenv("NLE_NO_SORTED_EXPAND") == nullptr) {
+        hipError_t ex = sorted_expand(s, gs, nrows_local, sorted->scol, sorted->desc, sorted->E, d_ws, gstride, nl, d_c, d_out,
+                                      ostride);
+        if (obs) obs->end();
+        return ex;
+    }
 #define NLE_HD(NCV)                                                                                                  \
     case NCV: {                                                                                                      \
         const size_t shm_d = (size_t)nl * kLevels * ((NCV) | 1) * sizeof(double);                                    \

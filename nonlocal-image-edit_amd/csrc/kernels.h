@@ -177,6 +177,13 @@ bool sorted_recurrence(GridSpec gs, double hx, double* kappa);
 int sorted_max_width();
 size_t sorted_scol_elems(int W, int nrows_local);  // allocation size of SortedRows::scol
 int sorted_gram_max_cols();
+// expand half of the sample-space apply on the sorted rows (nl <= sorted_expand_layers() layers per launch)
+int sorted_expand_max_cols();
+int sorted_expand_max_width();
+int sorted_expand_layers();
+hipError_t sorted_expand(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
+                         const double* d_E, const double* d_g, size_t gstride, int nl, const double* d_cvec, float* d_out,
+                         long long ostride);
 hipError_t dist_table(hipStream_t s, int W, double hx, double* d_E);
 hipError_t sort_rows(hipStream_t s, const float* d_lum, GridSpec gs, int row0, int nrows_local, unsigned short* d_scol,
                      uint2* d_desc, unsigned short* d_first);
@@ -197,10 +204,11 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
                            const SortedRows* sorted = nullptr);  // given: the pixel kernel runs on the level-sorted rows
 // sample-space apply (tables): expand half for one layer, the p/K-sized middle, and the sample-pixel outputs
 int apply_layers_per_launch(GridSpec gs);
+// (sorted given, nC <= 12, W <= 4096: the pixel kernel runs on the level-sorted rows, sorted_expand)
 hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
                              const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_wl, int ldw,
                              int nl, const double* d_c, double* d_ws, float* d_out, long long ostride,
-                             LaunchObserver* obs);
+                             LaunchObserver* obs, const SortedRows* sorted = nullptr);
 hipError_t apply_small(hipStream_t s, int p, int K, int ldk, int L, int ldw, const double* d_m, const double* d_D,
                        const double* d_Vrows, const double* d_xA /* x at the p sample pixels */, const double* d_resp,
                        double* d_t, double* d_Wp, double* d_YA);

@@ -1786,7 +1786,7 @@ void apply_sample_space(nle_filter* f, const float* d_x, const double* h_g /* L 
                 ProfObserver obs(c, emap);
                 HIP_OK(nlek::apply_hist_layers(c->stream, lum, f->gs, p, f->row0, nrows_local, f->d_er, f->d_ecT, f->d_Ep,
                                                d_Wp.p + (size_t)l * P64, P64, nl, f->d_c, d_gws.p, d_y + (size_t)l * M, M,
-                                               &obs));
+                                               &obs, f->has_sorted ? &f->sorted : nullptr));
             }
             PROFILED(c, NLE_K_SMALL, nlek::scatter_samples(c->stream, p, nl, f->d_sample_loc, d_YA.p + (size_t)l * p,
                                                            d_y + (size_t)l * M, M));

@@ -570,6 +570,130 @@ hipError_t sorted_pass(hipStream_t s, int mode, GridSpec gs, int row0, int nrows
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ apply, expand half, on the sorted rows
+// out_l[i] = (float)(c_i sum_b ec[c_i][b] g_l[r][x_i][b]) for the nl <= 4 layers of a launch (g_l from w'_l = D (f_l o t),
+// k_hist_g).  k_hist_dot does this pixel by pixel in image order with nl nC random LDS reads of the level-major tables per
+// pixel (LDS-conflict bound: 376 us for four layers at cfg4 against a 160 us stream floor).  Here a thread keeps the nl
+// table rows of ITS level in registers, so a pixel costs nC reads of the E table for all layers together; the results
+// are scattered into the row's output buffer in LDS and leave it coalesced.  Sample pixels are not in the sorted lists:
+// their slots hold whatever the buffer held and are overwritten by k_scatter_samples with the exact sample rows, as before.
+// nC <= 12 (registers), W <= 4096 (LDS: E table + 4 rows of fp32 output).
+constexpr int kExpLayers = 4;
+template <int NC>
+__global__ __launch_bounds__(kT) void k_sorted_expand(const unsigned short* __restrict__ scol, const uint2* __restrict__ desc,
+                                                      GridSpec gs, int nrows, const double* __restrict__ Etab,
+                                                      const double* __restrict__ g, size_t gstride, int nl,
+                                                      const double* __restrict__ cvec, float* __restrict__ out,
+                                                      long long ostride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int n = kLevels * NC;
+    const int W = gs.W;
+    double* sE = reinterpret_cast<double*>(smem_raw);
+    float* sOut = reinterpret_cast<float*>(sE + ((W + 2) & ~1));  // [kExpLayers][W]
+    const int tid = threadIdx.x;
+    for (int i = tid; i <= W; i += kT) sE[i] = Etab[i];
+    const int cb0 = gs.colOff, cs = gs.colStep;
+    const unsigned sEa = lds_addr(sE);
+    const size_t pitch = sorted_row_pitch(W);
+    __syncthreads();
+    for (int lrow = blockIdx.x; lrow < nrows; lrow += gridDim.x) {
+        const uint2 dsc = desc[(size_t)lrow * kT + tid];
+        const int len = dsc_len(dsc), x = dsc_level(dsc);
+        const uint2* slot = reinterpret_cast<const uint2*>(scol + (size_t)lrow * pitch + (size_t)tid * dsc_chp(dsc));
+        uint2 idx[kMaxBlocks];
+#pragma unroll
+        for (int b = 0; b < kMaxBlocks; ++b) {
+            uint2 v = make_uint2(0u, 0u);
+            if (4 * b < len) v = slot[b];
+            idx[b] = v;
+        }
+        double gv[kExpLayers][NC];
+#pragma unroll
+        for (int l = 0; l < kExpLayers; ++l)
+#pragma unroll
+            for (int b = 0; b < NC; ++b) gv[l][b] = (l < nl) ? g[(size_t)l * gstride + (size_t)lrow * n + b * kLevels + x] : 0.0;
+        const double* cv_row = cvec + (size_t)lrow * W;
+        int wlen = len;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wlen = max(wlen, __shfl_xor(wlen, off));
+        wlen = __builtin_amdgcn_readfirstlane(wlen);
+        auto pixel = [&](const unsigned c8, const bool on) {
+            const unsigned c = c8 >> 3;
+            const double cv = cv_row[c];
+            double e[NC];
+            column_factors<NC, false>(sEa, c8, cb0, cs, 0.0, [&](const int b, const double ev) { e[b] = ev; });
+#pragma unroll
+            for (int l = 0; l < kExpLayers; ++l) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int b = 0; b < NC; ++b) {
+                    if (b & 1) s1 += e[b] * gv[l][b];
+                    else s0 += e[b] * gv[l][b];
+                }
+                if (on && l < nl) sOut[l * W + c] = (float)(cv * (s0 + s1));
+            }
+        };
+#pragma unroll
+        for (int b = 0; b < kMaxBlocks; ++b) {
+            if (4 * b >= wlen) break;
+            pixel(idx[b].x & 0xffffu, 4 * b < len);
+            NLE_PIXEL_FENCE();
+            if (4 * b + 1 < wlen) {
+                pixel(idx[b].x >> 16, 4 * b + 1 < len);
+                NLE_PIXEL_FENCE();
+            }
+            if (4 * b + 2 < wlen) {
+                pixel(idx[b].y & 0xffffu, 4 * b + 2 < len);
+                NLE_PIXEL_FENCE();
+            }
+            if (4 * b + 3 < wlen) {
+                pixel(idx[b].y >> 16, 4 * b + 3 < len);
+                NLE_PIXEL_FENCE();
+            }
+        }
+        __syncthreads();  // the row's outputs are in sOut
+        for (int l = 0; l < nl; ++l) {
+            float* orow = out + (size_t)l * ostride + (size_t)lrow * W;
+            for (int c = tid; c < W; c += kT) orow[c] = sOut[l * W + c];
+        }
+        __syncthreads();  // before the next row writes sOut
+    }
+}
+
+int sorted_expand_max_cols() { return 12; }
+int sorted_expand_max_width() { return 4096; }
+int sorted_expand_layers() { return kExpLayers; }
+
+hipError_t sorted_expand(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
+                         const double* d_E, const double* d_g, size_t gstride, int nl, const double* d_cvec, float* d_out,
+                         long long ostride) {
+    const int nC = gs.nSelCols;
+    if (nC < 1 || nC > sorted_expand_max_cols() || gs.W > sorted_expand_max_width() || nl < 1 || nl > kExpLayers)
+        return hipErrorInvalidValue;
+    if (nrows_local <= 0) return hipSuccess;
+    const size_t shm = (size_t)((gs.W + 2) & ~1) * sizeof(double) + (size_t)kExpLayers * gs.W * sizeof(float);
+    int ncu = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = std::max(1, std::min(nrows_local, ncu));  // one 512-thread workgroup per CU (registers, LDS)
+#define NLE_SX(NCV)                                                                                                    \
+    case NCV: {                                                                                                        \
+        if (shm > 48 * 1024) {                                                                                         \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sorted_expand<NCV>),                   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                 \
+            if (ea != hipSuccess) return ea;                                                                           \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_sorted_expand<NCV>), dim3((unsigned)grid), dim3(kT), shm, s, d_scol, d_desc, gs,         \
+                           nrows_local, d_E, d_g, gstride, nl, d_cvec, d_out, ostride);                                \
+    } break;
+    switch (nC) {
+        NLE_SX(1) NLE_SX(2) NLE_SX(3) NLE_SX(4) NLE_SX(5) NLE_SX(6) NLE_SX(7) NLE_SX(8) NLE_SX(9) NLE_SX(10) NLE_SX(11)
+        NLE_SX(12)
+        default: return hipErrorInvalidValue;
+    }
+#undef NLE_SX
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ Gram, per-row pair tables (nC <= 11: one launch)
 // A_r[(b, b')][x] = sum_{i in row r, x_i = x} c_i^2 ec[c_i][b] ec[c_i][b'],  b <= b': what k_ghist_rows computes with
 // nC (nC + 1) / 2 LDS atomics per pixel.  Output layout [row][pair][level], as k_ghist_gemm / k_ghist_final expect.
