@@ -783,24 +783,43 @@ Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_
         const double s = std::sqrt(recip0(l2[k]));
         for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * s;
     }
-    mm_nt(Us.data(), U2.data(), S.data(), q, r2, q);
     o.r_wa = r2;
-    // Q = Wa + S * WW * S  (:296)
-    std::vector<double> T1((size_t)q * q), Qm((size_t)q * q);
-    mm(S.data(), WW.data(), T1.data(), q, q, q);
-    mm(T1.data(), S.data(), Qm.data(), q, q, q);
-    for (size_t i = 0; i < Qm.size(); ++i) Qm[i] += o.Wa[i];
-    std::vector<double> Vq, Sq;
-    int rq = 0;
-    top_eigenpairs(Qm, q, n_eig, topk_solver, &Vq, &Sq, &rq);
-    const int K = std::min(n_eig, rq);  // :314
-    if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
+    if (r2 <= 0) throw Fail{NLE_ERR_NUMERIC, "Wa has no eigenvalue >= 1e-10"};
+    std::vector<double> Vq, Sq, T2;
+    int rq = 0, K = 0;
+    if (topk_solver == 0) {
+        // Q = Wa + S (Wab Wab^T) S  (:296) on the subspace the Wa cut kept: with F = U2 L2^-1/2 (q x r2), S = F U2^T and
+        // Q = U2 (L2 + F^T WW F) U2^T + U1 L1 U1^T, so the eigenpairs of Q are those of Qt = L2 + F^T WW F (order r2)
+        // mapped by U2, plus the dropped (U1, L1 < 1e-10) -- which the literal S (.) S product, with entries of S up to
+        // 1e5, can lift back over the cut by its rounding alone (tools/parity_fuzz.py, seed 12 "big", case 59: 9.5e-11
+        // became 1.11e-10 here and 9.97e-11 in numpy).  S Vq = F Vt.
+        std::vector<double> WF((size_t)q * r2), Qt((size_t)r2 * r2);
+        mm(WW.data(), Us.data(), WF.data(), q, q, r2);
+        mm_tn(Us.data(), WF.data(), Qt.data(), q, r2, r2);
+        for (int k = 0; k < r2; ++k) Qt[(size_t)k * r2 + k] += l2[k];
+        std::vector<double> Vt;
+        top_eigenpairs(Qt, r2, n_eig, topk_solver, &Vt, &Sq, &rq);
+        K = std::min(n_eig, rq);  // :314
+        if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
+        T2.resize((size_t)q * K);
+        mm(Us.data(), Vt.data(), T2.data(), q, r2, K);
+    } else {
+        // the USE_SPECTRA build's solver works on the literal Q (full matrix, :170-199)
+        mm_nt(Us.data(), U2.data(), S.data(), q, r2, q);
+        std::vector<double> T1((size_t)q * q), Qm((size_t)q * q);
+        mm(S.data(), WW.data(), T1.data(), q, q, q);
+        mm(T1.data(), S.data(), Qm.data(), q, q, q);
+        for (size_t i = 0; i < Qm.size(); ++i) Qm[i] += o.Wa[i];
+        top_eigenpairs(Qm, q, n_eig, topk_solver, &Vq, &Sq, &rq);
+        K = std::min(n_eig, rq);  // :314
+        if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
+        T2.resize((size_t)q * K);
+        mm(S.data(), Vq.data(), T2.data(), q, q, K);
+    }
     o.K = K;
     o.r_q = rq;
     o.Sq.assign(Sq.begin(), Sq.begin() + K);
     // T2 = S * Vq * diag(Sq^-1/2)  (q x K)
-    std::vector<double> T2((size_t)q * K);
-    mm(S.data(), Vq.data(), T2.data(), q, q, K);
     for (int k = 0; k < K; ++k) {
         const double s = std::sqrt(recip0(Sq[k]));
         for (int i = 0; i < q; ++i) T2[(size_t)k * q + i] *= s;
