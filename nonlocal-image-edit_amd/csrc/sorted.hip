@@ -668,28 +668,6 @@ __global__ __launch_bounds__(kT) void k_sorted_expand(const unsigned short* __re
                 if (on && l < nl) sOut[l * W + c] = (float)(cv * (s0 + s1));
             }
         };
-#ifdef NLE_ABL_PAIR
-#pragma unroll
-        for (int b = 0; b < kMaxBlocks; ++b) {  // two pixels between fences: two independent dependency chains in flight
-            if (4 * b >= wlen) break;
-            if (4 * b + 1 < wlen) {
-                pixel(idx[b].x & 0xffffu, 4 * b < len);
-                pixel(idx[b].x >> 16, 4 * b + 1 < len);
-            } else {
-                pixel(idx[b].x & 0xffffu, 4 * b < len);
-            }
-            NLE_PIXEL_FENCE();
-            if (4 * b + 2 < wlen) {
-                if (4 * b + 3 < wlen) {
-                    pixel(idx[b].y & 0xffffu, 4 * b + 2 < len);
-                    pixel(idx[b].y >> 16, 4 * b + 3 < len);
-                } else {
-                    pixel(idx[b].y & 0xffffu, 4 * b + 2 < len);
-                }
-                NLE_PIXEL_FENCE();
-            }
-        }
-#else
 #pragma unroll
         for (int b = 0; b < kMaxBlocks; ++b) {
             if (4 * b >= wlen) break;
@@ -708,7 +686,6 @@ __global__ __launch_bounds__(kT) void k_sorted_expand(const unsigned short* __re
                 NLE_PIXEL_FENCE();
             }
         }
-#endif
         __syncthreads();  // the row's outputs are in sOut
         for (int l = 0; l < nl; ++l) {
             float* orow = out + (size_t)l * ostride + (size_t)lrow * W;
