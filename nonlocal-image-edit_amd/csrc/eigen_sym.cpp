@@ -579,10 +579,13 @@ void run_split(int nparts, int nthreads, F&& body) {  // body(part) for part in 
 }
 
 // right-looking Cholesky on the lower triangle, column-major (all inner loops unit stride)
-NLE_SIMD_CLONES bool cholesky_lower(int n, double* A) {
+// min_pivot: give up as soon as a pivot L_jj^2 falls below it (L_jj^2 >= lambda_min of the leading block >= lambda_min(A),
+// so a pivot below tau proves trace(A^-1) > 1 / tau: callers that would reject the factor for that anyway stop here
+// instead of finishing the factorisation and inverting it)
+NLE_SIMD_CLONES bool cholesky_lower(int n, double* A, double min_pivot) {
     for (int j = 0; j < n; ++j) {
         const double djj = at(A, n, j, j);
-        if (!(djj > 0.0)) return false;
+        if (!(djj > min_pivot)) return false;
         const double d = std::sqrt(djj), inv = 1.0 / d;
         double* cj = &at(A, n, 0, j);
         cj[j] = d;
@@ -700,10 +703,10 @@ NLE_SIMD_CLONES void gemm_tn_cols(const double* A, const double* B, double* C, i
         }
 }
 
-bool cholesky_with_inverse(const double* M, int n, double* L, double* Linv, double* inv_trace) {
+bool cholesky_with_inverse(const double* M, int n, double* L, double* Linv, double* inv_trace, double max_inv_trace) {
     for (int c = 0; c < n; ++c)
         for (int r = 0; r < n; ++r) L[(size_t)c * n + r] = (r >= c) ? M[(size_t)c * n + r] : 0.0;
-    if (!cholesky_lower(n, L)) return false;
+    if (!cholesky_lower(n, L, max_inv_trace > 0.0 ? 1.0 / max_inv_trace : 0.0)) return false;
     lower_inverse(n, L, Linv);
     double t = 0.0;
     for (size_t i = 0; i < (size_t)n * n; ++i) t += Linv[i] * Linv[i];

@@ -50,7 +50,9 @@ int lanczos_topk(const double* A, int n, int nev_in, double tol, int max_restart
 // column-major lower triangular (zeros above the diagonal), Linv = L^-1 likewise.  Returns false if
 // a pivot is not positive.  *inv_trace = trace(M^-1) = ||Linv||_F^2, so every eigenvalue of M is at
 // least 1 / *inv_trace: the caller's proof that the reference's eigenvalue cut at eps removes nothing.
-bool cholesky_with_inverse(const double* M, int n, double* L, double* Linv, double* inv_trace);
+// max_inv_trace > 0: the caller will reject the factor if trace(M^-1) exceeds it -- the factorisation then stops at the
+// first pivot that already proves that (returns false)
+bool cholesky_with_inverse(const double* M, int n, double* L, double* Linv, double* inv_trace, double max_inv_trace = 0.0);
 
 // Column ranges [j0, j1) of small column-major products (the caller splits columns over threads):
 //   nn: C (m x n) = A (m x k) B (k x n);  nt: C (m x n) = A (m x k) B^T (B n x k);  tn: C (k x n) = A^T B (A m x k, B m x n)

@@ -469,7 +469,7 @@ Nystrom solve_Ka(const std::vector<double>& Ka, int p, bool allow_chol) {
     if (allow_chol && std::getenv("NLE_FORCE_EIG") == nullptr) {
         std::vector<double> L((size_t)p * p), Li((size_t)p * p);
         double inv_trace = 0.0;
-        if (nleh::cholesky_with_inverse(Ka.data(), p, L.data(), Li.data(), &inv_trace) && inv_trace <= kCholMaxInvTrace) {
+        if (nleh::cholesky_with_inverse(Ka.data(), p, L.data(), Li.data(), &inv_trace, kCholMaxInvTrace) && inv_trace <= kCholMaxInvTrace) {
             n.chol = true;
             n.r = p;
             n.ldr = ld4(p);
@@ -891,7 +891,7 @@ void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<do
     if (std::getenv("NLE_FORCE_EIG") == nullptr && inv_diag <= kCholMaxInvTrace) {
         std::vector<double> L((size_t)q * q), Li((size_t)q * q);
         double inv_trace = 0.0;
-        if (nleh::cholesky_with_inverse(o.Wa.data(), q, L.data(), Li.data(), &inv_trace) && inv_trace <= kCholMaxInvTrace) {
+        if (nleh::cholesky_with_inverse(o.Wa.data(), q, L.data(), Li.data(), &inv_trace, kCholMaxInvTrace) && inv_trace <= kCholMaxInvTrace) {
             std::vector<double> Lt((size_t)q * q);
             for (int k = 0; k < q; ++k)
                 for (int a = 0; a < q; ++a) {
@@ -1041,7 +1041,7 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
         L.resize(qq);
         Li.resize(qq);
         double inv_trace = 0.0;
-        chol_wa = nleh::cholesky_with_inverse(o.Wa.data(), q, L.data(), Li.data(), &inv_trace) && inv_trace <= kCholMaxInvTrace;
+        chol_wa = nleh::cholesky_with_inverse(o.Wa.data(), q, L.data(), Li.data(), &inv_trace, kCholMaxInvTrace) && inv_trace <= kCholMaxInvTrace;
     }
     // Few eigenvalues below the cut (the usual case on large images: 4 of 200 at cfg4): deflate them and take the Cholesky
     // route after all.  With Vd, Ld the dropped eigenpairs and s = lambda_max, Ahat = A + Vd (s I - Ld) Vd^T has A's kept
@@ -1058,7 +1058,9 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     if (!chol_wa && std::getenv("NLE_FORCE_EIG") == nullptr && std::getenv("NLE_NO_DEFLATE") == nullptr && q >= 16 && q < 512) {
         std::vector<double> Dall(q), Vd((size_t)q * (max_defl + 1));
         int kept = 0;
+        tr.mark("ss:   Wa built, Cholesky attempt");
         if (nleh::sym_eigen_select(o.Wa.data(), q, Dall.data(), 0, 0, Vd.data(), NLE_EPS, max_defl, &kept)) {
+            tr.mark("ss:   Wa eigenvalues + dropped eigenvectors");
             nd = q - kept;
             if (kept > 0 && nd <= max_defl && Dall[0] > 0.0) {
                 const double sig = Dall[0];
@@ -1078,6 +1080,7 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
                 Li.resize(qq);
                 double inv_trace = 0.0;
                 if (nleh::cholesky_with_inverse(Ah.data(), q, L.data(), Li.data(), &inv_trace)) {
+                    tr.mark("ss:   deflated matrix + its Cholesky factor and inverse");
                     // F = L^-T - Vd (Vd^T L^-T),  G = L^T Vd
                     Fdefl.resize(qq);
                     for (int k = 0; k < q; ++k)
