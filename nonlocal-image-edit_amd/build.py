@@ -48,7 +48,7 @@ def _run(cmd):
 def build_lib(force: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("kernels.h", "eigen_sym.h")] + [
+    deps = srcs + [os.path.join(CSRC, h) for h in ("kernels.h", "eigen_sym.h", "pipeline_internal.h")] + [
         os.path.join(ROOT, "include", "nle.h")]
     if force or _newer(LIB, deps):
         objs = []

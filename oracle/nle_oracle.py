@@ -255,7 +255,7 @@ def _affinity_rows(lum_flat, W, idx, sr, sc, sv, sw, pw):
 
 def train_filter_streaming(channel, n_row_samples, n_col_samples, hx, hy,
                            n_sinkhorn_iter, n_eigen_vectors, tile: int = 1 << 15,
-                           shard=(0, 1), allreduce=None, phi_dtype=np.float64):
+                           shard=(0, 1), allreduce=None, phi_dtype=np.float64, intermediates: dict | None = None):
     """Same math as `train_filter` in NATURAL pixel order, tiled over pixels.
 
     Follows src/filter.cpp:480-502 stage by stage; algebra used to avoid N x p / N x q
@@ -270,7 +270,9 @@ def train_filter_streaming(channel, n_row_samples, n_col_samples, hx, hy,
 
     shard=(g, G): only pixel rows [g*H/G, (g+1)*H/G) are processed; `allreduce(x)` must
     then return the sum of x over all G shards (fp64).  Returns (V_local, S) where
-    V_local covers this shard's pixels (natural order).
+    V_local covers this shard's pixels (natural order).  `intermediates`, when given, receives
+    lam (eigenvalues of K_A kept), c (this shard's Sinkhorn column scalings, natural order), the
+    eigenvalues of W_A and of Q either side of the 1e-10 cut (fixture generation only).
     """
     channel = np.asarray(channel, dtype=np.float64)
     H, W = channel.shape
@@ -339,6 +341,9 @@ def train_filter_streaming(channel, n_row_samples, n_col_samples, hx, hy,
     ownA = (A >= lo) & (A < hi)
     in_A[A[ownA] - lo] = True
     c_loc, _ = inplace_reciprocal(pass_dot(u_c))
+    if intermediates is not None:
+        intermediates["c"] = c_loc.copy()
+        intermediates["lam"] = lam.copy()
     c_loc[in_A] = 0.0
     Gm = np.zeros((r_, r_))
     for s in range(0, nloc, tile):
@@ -346,11 +351,16 @@ def train_filter_streaming(channel, n_row_samples, n_col_samples, hx, hy,
         Gm += z.T @ z
     Gm = allreduce(Gm)
 
-    U2, l2 = eigen_decomposition(Wa)
+    cut_info = [] if intermediates is not None else None
+    U2, l2 = eigen_decomposition(Wa, info=cut_info)
     ir, _ = inplace_reciprocal(l2)
     S = (U2 * np.sqrt(ir)[None, :]) @ U2.T
     Q = Wa + S @ (M.T @ Gm @ M) @ S
-    Vq, Sq = eigen_decomposition(Q)
+    Vq, Sq = eigen_decomposition(Q, info=cut_info)
+    if intermediates is not None:
+        intermediates["cuts"] = cut_info
+        intermediates["wa_eigvals"] = l2.copy()
+        intermediates["q_eigvals"] = Sq.copy()
     k = min(n_eigen_vectors, Vq.shape[1])
     Vq, Sq = Vq[:, :k], Sq[:k]
     irs, _ = inplace_reciprocal(Sq)
