@@ -151,6 +151,16 @@ int nle_eigen_decomposition_top(const double* h_M, int n, double eps, int kmax, 
  * the whole solve on the host).  Same conventions; results agree with the host form to rounding. */
 int nle_eigen_decomposition_top_device(nle_ctx* ctx, const double* h_M, int n, double eps, int kmax, double* h_U, double* h_D,
                                        int* r);
+/* eigenDecomposition (:204-228) with the O(n^3) part on the GPU, 3 <= n <= 1152: Householder reduction in one persistent
+ * multi-workgroup launch, all eigenvalues by Sturm bisection, the eigenvectors of h_D[first .. first + count) by inverse
+ * iteration on the tridiagonal form (host) and their back-transformation (device).  h_D: all n eigenvalues descending;
+ * h_U: n x count col-major (may be NULL when count == 0); *r = length of the leading run >= eps.  What nle_train* uses
+ * for Wa and Q from 288 samples on (NLE_DEV_SOLVER_MIN; NLE_HOST_SOLVER=1 keeps the host solver). */
+int nle_sym_eigen_device(nle_ctx* ctx, const double* h_M, int n, double eps, int first, int count, double* h_U, double* h_D,
+                         int* r);
+/* Cholesky factor of a symmetric matrix (lower triangle read) and its inverse on the GPU (blocked, fp64 MFMA updates):
+ * h_L, h_Linv n x n col-major lower triangular, *inv_trace = trace(M^-1), *ok = 0 if a pivot was not positive. */
+int nle_cholesky_device(nle_ctx* ctx, const double* h_M, int n, double* h_L, double* h_Linv, double* inv_trace, int* ok);
 /* topkEigenDecomposition, src/filter.cpp:170-199 (the USE_SPECTRA build's solver for Q): the min(n_largest, n - 1)
  * eigenpairs of largest magnitude of the FULL n x n matrix by Lanczos (tolerance 1e-10, <= 1000 restarts), algebraic
  * value descending, leading run >= eps kept.  h_U: n x min(n_largest, n - 1) col-major, h_D likewise; *r valid pairs. */

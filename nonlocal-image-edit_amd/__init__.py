@@ -53,6 +53,8 @@ _SIGNATURES = {
     "nle_eigen_decomposition": (C.c_int, [_P, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),
     "nle_eigen_decomposition_top": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, _P, _P, C.POINTER(C.c_int)]),
     "nle_eigen_decomposition_top_device": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_int, _P, _P, C.POINTER(C.c_int)]),
+    "nle_sym_eigen_device": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_int, C.c_int, _P, _P, C.POINTER(C.c_int)]),
+    "nle_cholesky_device": (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "nle_topk_eigen_decomposition": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),
     "nle_transform_eigenvalues": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     "nle_layer_responses": (C.c_int, [_P, C.c_int, C.c_int, _P]),
@@ -336,6 +338,29 @@ class Context:
         _check(lib().nle_eigen_decomposition_top_device(self._h, _np_ptr(M), n, float(eps), int(kmax), _np_ptr(U), _np_ptr(D),
                                                         C.byref(r)), self._h)
         return np.ascontiguousarray(U), D, r.value
+
+    def sym_eigen_device(self, M, first: int = 0, count: int = 0, eps: float = EPS):
+        """all eigenvalues (descending) and the eigenvectors of D[first:first+count] with the reduction, the bisection and the
+        back-transformation on the GPU (nle_sym_eigen_device; 3 <= n <= 1152).  Returns (U n x count, D, r)."""
+        M = np.asfortranarray(np.asarray(M, dtype=np.float64))
+        n = M.shape[0]
+        U = np.zeros((n, max(count, 1)), dtype=np.float64, order="F")
+        D = np.zeros(n, dtype=np.float64)
+        r = C.c_int()
+        _check(lib().nle_sym_eigen_device(self._h, _np_ptr(M), n, float(eps), int(first), int(count), _np_ptr(U), _np_ptr(D),
+                                          C.byref(r)), self._h)
+        return np.ascontiguousarray(U[:, :count]), D, r.value
+
+    def cholesky_device(self, M):
+        """(L, L^-1, trace(M^-1), ok) of a symmetric matrix (lower triangle read) on the GPU (nle_cholesky_device)"""
+        M = np.asfortranarray(np.asarray(M, dtype=np.float64))
+        n = M.shape[0]
+        L = np.zeros((n, n), dtype=np.float64, order="F")
+        Li = np.zeros((n, n), dtype=np.float64, order="F")
+        tr = C.c_double()
+        ok = C.c_int()
+        _check(lib().nle_cholesky_device(self._h, _np_ptr(M), n, _np_ptr(L), _np_ptr(Li), C.byref(tr), C.byref(ok)), self._h)
+        return np.ascontiguousarray(L), np.ascontiguousarray(Li), tr.value, bool(ok.value)
 
     def set_slab_input(self, on: bool = True):
         """planes passed to train / apply hold this rank's rows only (nle_ctx_set_slab_input); pass shape=(H, W)"""

@@ -22,7 +22,7 @@ LIBDIR = os.path.join(HERE, "lib")
 BINDIR = os.path.join(HERE, "bin")
 LIB = os.path.join(LIBDIR, "libnle_hip.so")
 
-LIB_SOURCES = ["kernels.hip", "fused.hip", "sorted.hip", "generic64.hip", "tridiag.hip", "colour.hip", "pipeline.hip", "eigen_sym.cpp"]
+LIB_SOURCES = ["kernels.hip", "fused.hip", "sorted.hip", "generic64.hip", "tridiag.hip", "dense64.hip", "colour.hip", "pipeline.hip", "devsolve.hip", "eigen_sym.cpp"]
 ARCH = "gfx950"
 
 
@@ -45,22 +45,40 @@ def _run(cmd):
     subprocess.run(cmd, check=True)
 
 
+def _includes(path: str, seen=None) -> set:
+    """the quoted headers a source pulls in, transitively (paths relative to the including file)"""
+    import re
+    seen = set() if seen is None else seen
+    try:
+        text = open(path).read()
+    except OSError:
+        return seen
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        h = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+        if h not in seen and os.path.exists(h):
+            seen.add(h)
+            _includes(h, seen)
+    return seen
+
+
 def build_lib(force: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("kernels.h", "eigen_sym.h", "pipeline_internal.h")] + [
-        os.path.join(ROOT, "include", "nle.h")]
-    if force or _newer(LIB, deps):
-        objs = []
-        for s in srcs:
-            o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
-            if force or _newer(o, deps):
-                if s.endswith(".cpp"):  # host-only fp64 algebra: plain g++ (needs function multiversioning)
-                    _run(["g++", "-O3", "-fopenmp-simd", "-std=c++17", "-fPIC", "-pthread", "-Wno-psabi", "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
-                else:
-                    _run([_hipcc(), "-x", "hip", "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC",
-                          "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
-            objs.append(o)
+    jobs, objs = [], []
+    for s in srcs:
+        o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + sorted(_includes(s))):
+            if s.endswith(".cpp"):  # host-only fp64 algebra: plain g++ (needs function multiversioning)
+                jobs.append(["g++", "-O3", "-fopenmp-simd", "-std=c++17", "-fPIC", "-pthread", "-Wno-psabi", "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
+            else:
+                jobs.append([_hipcc(), "-x", "hip", "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC",
+                             "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(os.environ.get("NLE_BUILD_JOBS", "4"))) as ex:
+            list(ex.map(_run, jobs))
+    if jobs or force or _newer(LIB, objs):
         _run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lpthread", "-ldl"])
     return LIB
 

@@ -865,6 +865,22 @@ bool tridiag_inverse_iteration(int n, const double* d, const double* e, const do
     return true;
 }
 
+bool tridiag_eigenvectors(int n, const double* d, const double* e, const double* lam_all, int first, int count, double* Z) {
+    if (count <= 0) return true;
+    if (tridiag_inverse_iteration(n, d, e, lam_all + first, count, Z)) return true;
+    // the classic iteration on T itself: rotations accumulated from the identity
+    std::vector<double> V((size_t)n * n, 0.0), dd(d, d + n), ee(e, e + n);
+    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+    if (!ql_implicit(n, V.data(), dd.data(), ee.data())) return false;
+    std::vector<int> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return dd[a] < dd[b]; });
+    std::reverse(idx.begin(), idx.end());
+    for (int j = 0; j < count; ++j)
+        std::copy(V.begin() + (size_t)idx[first + j] * n, V.begin() + (size_t)idx[first + j] * n + n, Z + (size_t)j * n);
+    return true;
+}
+
 // The part of sym_eigen_top after the reduction: V (n x n, u_i in column i rows 0..i-1), hs, and the tridiagonal (d, e) as
 // tridiag_reduce -- or the device kernel k_tridiag (tridiag.hip), same conventions -- leaves them.
 bool sym_eigen_top_reduced(int n, const double* V, const double* d_in, const double* e_in, const double* hs, int ncols,

@@ -40,6 +40,12 @@ bool eigen_decomposition_top_reduced(int n, double eps, int kmax, const double* 
 bool sym_eigen_select(const double* M, int n, double* D, int first, int count, double* U, double below_eps = 0.0,
                       int max_below = 0, int* kept_out = nullptr);
 
+// Eigenvectors of the symmetric tridiagonal T (d[0..n) diagonal, e[1..n) sub-diagonal) for its eigenvalues
+// lam_all[first .. first + count) (lam_all: all n eigenvalues DESCENDING, accurate to rounding): inverse iteration
+// (dstein's scheme), falling back to the QL iteration with accumulated rotations if a vector does not converge.
+// Z: n x count column-major.  What the device reduction (dense64.hip: sytrd_dist + tridiag_bisect) leaves to the host.
+bool tridiag_eigenvectors(int n, const double* d, const double* e, const double* lam_all, int first, int count, double* Z);
+
 // Opt-in top-K solver with the semantics of the reference's USE_SPECTRA build (src/filter.cpp:170-199; see eigen_sym.cpp):
 // the nev = min(nev_in, n - 1) eigenpairs of LARGEST MAGNITUDE of the FULL n x n matrix A (column-major), Krylov
 // dimension min(2 nev, n), residual tolerance `tol`, at most `max_restarts` restarts.  Returns the number of converged

@@ -163,6 +163,29 @@ int tridiag_max_n();
 hipError_t tridiag(hipStream_t s, int n, const double* d_Q, const double* d_diag_add, double* d_V, double* d_d, double* d_e,
                    double* d_hs);
 
+// ---- dense fp64 algebra of order n <= sytrd_max_n() on the device (dense64.hip)
+// Householder tridiagonalisation in one persistent launch of G workgroups (0: sytrd_groups(n)); d_A n x n column-major, lower
+// triangle read, d_diag_add (n, optional) added to the diagonal; d_pub: sytrd_pub_elems(n) doubles (the Householder vectors
+// and scales stay there for sytrd_back); d_d[i] = T(i,i), d_e[i] = T(i,i-1), d_e[0] = 0; *d_status != 0 afterwards: a
+// hand-off between workgroups timed out (the outputs are then meaningless)
+int sytrd_max_n();
+int sytrd_groups(int n);
+size_t sytrd_pub_elems(int n);
+hipError_t sytrd_dist(hipStream_t s, int n, int G, const double* d_A, const double* d_diag_add, double* d_pub, double* d_d,
+                      double* d_e, int* d_status);
+// all n eigenvalues of the tridiagonal matrix, DESCENDING, by multi-section Sturm counts (absolute accuracy ~ulp ||T||)
+hipError_t tridiag_bisect(hipStream_t s, int n, const double* d_d, const double* d_e, double* d_D);
+// Z (n x K, column stride ldz) <- Q Z with the orthogonal factor of sytrd_dist's reduction
+hipError_t sytrd_back(hipStream_t s, int n, const double* d_pub, int K, double* d_Z, int ldz);
+// Cholesky factor L of d_A (lower triangle read; d_A untouched), L^-1 and d_scal[0] = trace(A^-1); *d_status |= 2 when a pivot
+// is not positive; d_tmp: potrf_tmp_elems(n) doubles of scratch
+size_t potrf_tmp_elems(int n);
+hipError_t potrf_inverse(hipStream_t s, int n, const double* d_A, double* d_L, double* d_Linv, double* d_tmp, double* d_scal,
+                         int* d_status);
+hipError_t transpose64(hipStream_t s, int n, const double* d_src, double* d_dst);   // n x n column-major
+hipError_t symm_lower64(hipStream_t s, int n, const double* d_src, double* d_dst);  // mirror the lower triangle
+hipError_t fill64(hipStream_t s, double* d_p, size_t n, double v);
+
 // ---- level-sorted rows (sorted.hip): the pixel halves of the table passes without LDS atomics
 constexpr int kSortedThreads = 512;
 struct SortedRows {

@@ -2,12 +2,10 @@
 // fused train pipeline (NLEFilter::trainFilter, reference src/filter.cpp:480-502) and
 // apply (:445-458).  Small (p x p, r x r) algebra and the three symmetric eigensolves run
 // on the host in fp64; everything N-sized is a HIP kernel (kernels.hip).
-#include "pipeline_internal.h"
+#include "devsolve.h"
 
 using nlek::GridSpec;
 using namespace nlep;
-
-static thread_local std::string g_create_err;
 
 namespace {
 // ---- sample set + Ka (host) ----
@@ -110,12 +108,34 @@ struct Nystrom {
 // every eigenvalue of an SPD matrix with trace(M^-1) <= kCholMaxInvTrace is >= 1e-9 > NLE_EPS
 constexpr double kCholMaxInvTrace = 1e9;
 
-Nystrom solve_Ka(const std::vector<double>& Ka, int p, bool allow_chol) {
+Nystrom solve_Ka(nle_ctx* c, const std::vector<double>& Ka, int p, bool allow_chol) {
     Nystrom n;
     if (allow_chol && std::getenv("NLE_FORCE_EIG") == nullptr) {
         std::vector<double> L((size_t)p * p), Li((size_t)p * p);
         double inv_trace = 0.0;
-        if (nleh::cholesky_with_inverse(Ka.data(), p, L.data(), Li.data(), &inv_trace, kCholMaxInvTrace) && inv_trace <= kCholMaxInvTrace) {
+        bool ok;
+        if (c && use_dev_solver(p) && !std::getenv("NLE_HOST_KA")) {  // blocked factorisation + inverse on the device (dense64.hip): 22 -> ~5 ms at p = 900
+            const size_t pp = (size_t)p * p;
+            DevBuf<double> d_Ka(pp);
+            HIP_OK(hipMemcpyAsync(d_Ka.p, Ka.data(), pp * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            DevChol ch;
+            ch.factor(c, p, d_Ka.p);
+            ok = ch.finish(c);
+            inv_trace = ch.inv_trace;
+            if (ok && inv_trace <= kCholMaxInvTrace) {
+                // (through the ctx's page-locked block: a device-to-host copy of this size into pageable memory left the
+                // runtime with 10-20 ms of clean-up at a later synchronisation)
+                double* hs = static_cast<double*>(pinned_stage(c, 2 * pp * sizeof(double)));
+                HIP_OK(hipMemcpyAsync(hs, ch.L.p, pp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                HIP_OK(hipMemcpyAsync(hs + pp, ch.Linv.p, pp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                HIP_OK(hipStreamSynchronize(c->stream));
+                std::copy(hs, hs + pp, L.begin());
+                std::copy(hs + pp, hs + 2 * pp, Li.begin());
+            }
+        } else {
+            ok = nleh::cholesky_with_inverse(Ka.data(), p, L.data(), Li.data(), &inv_trace, kCholMaxInvTrace);
+        }
+        if (ok && inv_trace <= kCholMaxInvTrace) {
             n.chol = true;
             n.r = p;
             n.ldr = ld4(p);
@@ -318,24 +338,6 @@ void mm_nt(const double* A, const double* B, double* C, int m, int k, int n) {
 // C (k x n) = A^T (A is m x k) * B (m x n)
 void mm_tn(const double* A, const double* B, double* C, int m, int k, int n) {
     par_cols(n, (long long)m * k, [&](int j0, int j1) { nleh::gemm_tn_cols(A, B, C, m, k, n, j0, j1); });
-}
-
-double now_ms();
-struct Trace {
-    bool on;
-    double t0, last;
-    Trace() : on(std::getenv("NLE_TRACE") != nullptr) { t0 = last = now_ms(); }
-    void mark(const char* what) {
-        if (!on) return;
-        const double t = now_ms();
-        std::fprintf(stderr, "[nle trace] %-28s +%8.3f ms  (t=%8.3f)\n", what, t - last, t - t0);
-        last = t;
-    }
-};
-
-double now_ms() {
-    using namespace std::chrono;
-    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
 }  // namespace
@@ -671,111 +673,199 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
         HIP_OK(hipMemcpyAsync(o.Kr.data(), d_Kr.p, pp * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
     }
-    enqueue_gram();
-    // ---- host: Wa and the factor of its (pseudo-)inverse, under the Gram kernels
+    // ---- Wa and a factor F of its (pseudo-)inverse, beside the Gram kernels: on the host below dev_solver_min_n(), else on
+    // the device on the ctx's second stream (the Gram kernels are on the first)
     double h0 = now_ms();
     o.Wa.resize(qq);
     for (int b = 0; b < q; ++b)
         for (int a = 0; a < q; ++a) o.Wa[(size_t)b * q + a] = o.rA[a] * o.Kr[(size_t)b * p + a] * o.cA[b];  // :249
-    // (see ortho_ss_prepare for why any root of the pseudo-inverse serves and when Cholesky is admissible)
     std::vector<double> L, Li, U2, Us, l2_kept;
     int r2 = 0;
     bool chol_wa = false;
     double inv_diag = 0.0;
     for (int a = 0; a < q; ++a) inv_diag += o.Wa[(size_t)a * q + a] > 0.0 ? 1.0 / o.Wa[(size_t)a * q + a] : 1e300;
-    if (std::getenv("NLE_FORCE_EIG") == nullptr && inv_diag <= kCholMaxInvTrace) {
-        L.resize(qq);
-        Li.resize(qq);
-        double inv_trace = 0.0;
-        chol_wa = nleh::cholesky_with_inverse(o.Wa.data(), q, L.data(), Li.data(), &inv_trace, kCholMaxInvTrace) && inv_trace <= kCholMaxInvTrace;
-    }
-    // Few eigenvalues below the cut (the usual case on large images: 4 of 200 at cfg4): deflate them and take the Cholesky
-    // route after all.  With Vd, Ld the dropped eigenpairs and s = lambda_max, Ahat = A + Vd (s I - Ld) Vd^T has A's kept
-    // eigenpairs and s on span(Vd); Ahat = L L^T, and with Pk = I - Vd Vd^T (which commutes with Ahat)
-    //     F = Pk L^-T  satisfies  F F^T = Pk Ahat^-1 Pk = pinv of the kept part of A,    F^T A^2 F = L^T Pk L
-    // -- the two things the device half needs.  Only the d dropped eigenvectors are formed (inverse iteration), not all q:
-    // reduction + QL values + Cholesky with inverse, ~1.0 ms at q = 200 against 1.5 ms for the full eigensolve.
     bool deflated = false;
     std::vector<double> Fdefl, Gdefl;  // F (q x q) and G = L^T Vd (q x d):  F^T A^2 F = L^T L - G G^T
     int nd = 0;
-    // (tried only where it pays: below q = 512, where the eigensolver is single threaded -- at q = 900 with 100 dropped
-    // eigenvalues it lost 40 ms to the threaded full solve -- and for at most q / 8 dropped eigenvalues)
     const int max_defl = q / 8;
-    if (!chol_wa && std::getenv("NLE_FORCE_EIG") == nullptr && std::getenv("NLE_NO_DEFLATE") == nullptr && q >= 16 && q < 512) {
-        std::vector<double> Dall(q), Vd((size_t)q * (max_defl + 1));
-        int kept = 0;
-        tr.mark("ss:   Wa built, Cholesky attempt");
-        if (nleh::sym_eigen_select(o.Wa.data(), q, Dall.data(), 0, 0, Vd.data(), NLE_EPS, max_defl, &kept)) {
-            tr.mark("ss:   Wa eigenvalues + dropped eigenvectors");
+    const bool force_eig = std::getenv("NLE_FORCE_EIG") != nullptr;
+    // device form: the same three routes (Cholesky when the cut provably removes nothing; deflated Cholesky when it removes
+    // at most q / 8 eigenvalues; else all kept eigenvectors -- that last one stays on the host)
+    const bool dev_wa = use_dev_solver(q) && !std::getenv("NLE_HOST_WA");
+    DevBuf<double> d_Wa(qq), d_F, d_L, d_G;
+    DevSymEig esw;
+    DevChol chw;
+    DevBuf<double> d_Ah, d_Vd, d_wgt, d_W, d_neg1;
+    bool dev_done = false;
+    if (dev_wa) {
+        hipStream_t sa = aux_stream(c);
+        // (workspace taken from the ctx cache now, while the first stream is idle: blocks of the cache are only ordered on it)
+        esw.prepare(c, q, sa);
+        chw.prepare(c, q, sa);
+        d_Ah.alloc(qq);
+        d_F.alloc(qq);
+        d_Vd.alloc((size_t)q * (max_defl + 1));
+        d_wgt.alloc(max_defl + 1);
+        d_W.alloc((size_t)(max_defl + 1) * q);
+        d_G.alloc((size_t)q * (max_defl + 1));
+        d_neg1.alloc(max_defl + 1);
+        HIP_OK(hipStreamSynchronize(st));
+        const bool wa_serial = std::getenv("NLE_WA_SERIAL") != nullptr;  // measurement: the Gram kernels after the root
+        if (!wa_serial) enqueue_gram();
+        HIP_OK(hipMemcpyAsync(d_Wa.p, o.Wa.data(), qq * sizeof(double), hipMemcpyHostToDevice, sa));
+        HIP_OK(nlek::symm_lower64(sa, q, d_Wa.p, d_Ah.p));
+        if (!force_eig && inv_diag <= kCholMaxInvTrace) {
+            chw.factor(c, q, d_Ah.p);
+            chol_wa = chw.finish(c) && chw.inv_trace <= kCholMaxInvTrace;
+            tr.mark("ss:   Wa: Cholesky attempt (device)");
+        }
+        if (chol_wa) {
+            HIP_OK(nlek::transpose64(sa, q, chw.Linv.p, d_F.p));  // F = L^-T
+            dev_done = true;
+        } else if (!force_eig && std::getenv("NLE_NO_DEFLATE") == nullptr) {
+            esw.reduce(c, q, d_Ah.p, nullptr);
+            tr.mark("ss:   Wa: tridiagonal form + eigenvalues (device)");
+            int kept = 0;
+            while (kept < q && esw.D[kept] >= NLE_EPS) ++kept;  // :213-216
             nd = q - kept;
-            if (kept > 0 && nd <= max_defl && Dall[0] > 0.0) {
-                const double sig = Dall[0];
-                std::vector<double> Ah(qq);
-                for (int cidx = 0; cidx < q; ++cidx)  // the symmetric matrix the reference's solver sees: lower triangle
-                    for (int ridx = 0; ridx < q; ++ridx)
-                        Ah[(size_t)cidx * q + ridx] = ridx >= cidx ? o.Wa[(size_t)cidx * q + ridx] : o.Wa[(size_t)ridx * q + cidx];
-                for (int t = 0; t < nd; ++t) {
-                    const double wgt = sig - Dall[kept + t];
-                    const double* v = Vd.data() + (size_t)t * q;
-                    for (int cidx = 0; cidx < q; ++cidx) {
-                        const double vc = wgt * v[cidx];
-                        for (int ridx = 0; ridx < q; ++ridx) Ah[(size_t)cidx * q + ridx] += v[ridx] * vc;
-                    }
+            if (kept > 0 && nd <= max_defl && esw.D[0] > 0.0) {
+                const double sig = esw.D[0];
+                if (nd > 0) {
+                    esw.vectors(c, kept, nd, d_Vd.p);
+                    tr.mark("ss:   Wa: dropped eigenvectors (host inverse iteration)");
+                    std::vector<double> wgt(nd);
+                    for (int t = 0; t < nd; ++t) wgt[t] = sig - esw.D[kept + t];
+                    HIP_OK(hipMemcpyAsync(d_wgt.p, wgt.data(), nd * sizeof(double), hipMemcpyHostToDevice, sa));
+                    // Ahat = A + Vd (sig I - Ld) Vd^T
+                    HIP_OK(nlek::gemm64s(sa, q, q, nd, d_Vd.p, 1, q, d_Vd.p, q, 1, d_Ah.p, 1, q, nullptr, d_wgt.p, nullptr, d_Ah.p, 1, q));
+                    HIP_OK(hipStreamSynchronize(sa));  // `wgt` (host) is consumed
                 }
-                L.resize(qq);
-                Li.resize(qq);
-                double inv_trace = 0.0;
-                if (nleh::cholesky_with_inverse(Ah.data(), q, L.data(), Li.data(), &inv_trace)) {
-                    tr.mark("ss:   deflated matrix + its Cholesky factor and inverse");
+                chw.factor(c, q, d_Ah.p);
+                const bool fact_ok = chw.finish(c);
+                if (!fact_ok && std::getenv("NLE_TRACE"))
+                    fprintf(stderr, "[nle trace] Wa: the deflated matrix did not factor (trace of the inverse %.3e, %d dropped, sigma %.3e)\n",
+                            chw.inv_trace, nd, sig);
+                if (fact_ok) {
                     // F = L^-T - Vd (Vd^T L^-T),  G = L^T Vd
-                    Fdefl.resize(qq);
-                    for (int k = 0; k < q; ++k)
-                        for (int a = 0; a < q; ++a) Fdefl[(size_t)k * q + a] = Li[(size_t)a * q + k];
-                    Gdefl.assign((size_t)q * std::max(nd, 1), 0.0);
-                    std::vector<double> wv(q);
-                    for (int t = 0; t < nd; ++t) {
-                        const double* v = Vd.data() + (size_t)t * q;
-                        for (int k = 0; k < q; ++k) {  // w = (Vd^T L^-T)[t, k] = sum_a v[a] L^-T(a, k) = sum_a v[a] Li(k, a)
-                            double acc = 0.0, g = 0.0;
-                            for (int a = 0; a < q; ++a) {
-                                acc += v[a] * Li[(size_t)a * q + k];
-                                g += L[(size_t)k * q + a] * v[a];  // (L^T v)[k] = sum_a L(a, k) v[a]
-                            }
-                            wv[k] = acc;
-                            Gdefl[(size_t)t * q + k] = g;
-                        }
-                        for (int k = 0; k < q; ++k)
-                            for (int a = 0; a < q; ++a) Fdefl[(size_t)k * q + a] -= v[a] * wv[k];
+                    HIP_OK(nlek::transpose64(sa, q, chw.Linv.p, d_F.p));
+                    if (nd > 0) {
+                        HIP_OK(nlek::fill64(sa, d_neg1.p, nd, -1.0));
+                        HIP_OK(nlek::gemm64s(sa, nd, q, q, d_Vd.p, q, 1, chw.Linv.p, q, 1, d_W.p, 1, nd));
+                        HIP_OK(nlek::gemm64s(sa, q, q, nd, d_Vd.p, 1, q, d_W.p, 1, nd, d_F.p, 1, q, nullptr, d_neg1.p, nullptr, d_F.p, 1, q));
+                        HIP_OK(nlek::gemm64s(sa, q, nd, q, chw.L.p, q, 1, d_Vd.p, 1, q, d_G.p, 1, q));
                     }
                     deflated = true;
+                    dev_done = true;
                     r2 = kept;
                     if (std::getenv("NLE_TRACE"))
-                        fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e), %d deflated\n",
-                                kept, q, Dall[0], Dall[kept - 1], nd);
+                        fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e), %d deflated (device)\n",
+                                kept, q, esw.D[0], esw.D[kept - 1], nd);
                 }
             }
         }
-    }
-    if (!chol_wa && !deflated) {
-        std::vector<double> Uf(qq), l2(q);
-        if (!nleh::eigen_decomposition(o.Wa.data(), q, NLE_EPS, Uf.data(), l2.data(), &r2))
-            throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Wa"};
-        U2.assign(Uf.begin(), Uf.begin() + (size_t)q * std::max(r2, 1));
-        l2_kept.assign(l2.begin(), l2.begin() + r2);
-        Us.resize((size_t)q * std::max(r2, 1));
-        for (int k = 0; k < r2; ++k) {
-            const double sv = std::sqrt(recip0(l2[k]));
-            for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * sv;
+        if (dev_done) {
+            d_L.alloc(qq);
+            HIP_OK(hipMemcpyAsync(d_L.p, chw.L.p, qq * sizeof(double), hipMemcpyDeviceToDevice, sa));
         }
-        if (std::getenv("NLE_TRACE"))
-            fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e)\n", r2, q, l2[0],
-                    r2 > 0 ? l2[r2 - 1] : 0.0);
+        HIP_OK(hipEventRecord(c->aux_ev, sa));
+        HIP_OK(hipStreamWaitEvent(st, c->aux_ev, 0));  // the first stream's later kernels see F, L, G, Wa
+        if (wa_serial) enqueue_gram();
+    } else {
+        enqueue_gram();
+    }
+    if (!dev_done) {
+        // (see ortho_ss_prepare for why any root of the pseudo-inverse serves and when Cholesky is admissible)
+        nd = 0;
+        if (!dev_wa && !force_eig && inv_diag <= kCholMaxInvTrace) {
+            L.resize(qq);
+            Li.resize(qq);
+            double inv_trace = 0.0;
+            chol_wa = nleh::cholesky_with_inverse(o.Wa.data(), q, L.data(), Li.data(), &inv_trace, kCholMaxInvTrace) && inv_trace <= kCholMaxInvTrace;
+        }
+        // Few eigenvalues below the cut (the usual case on large images: 4 of 200 at cfg4): deflate them and take the Cholesky
+        // route after all.  With Vd, Ld the dropped eigenpairs and s = lambda_max, Ahat = A + Vd (s I - Ld) Vd^T has A's kept
+        // eigenpairs and s on span(Vd); Ahat = L L^T, and with Pk = I - Vd Vd^T (which commutes with Ahat)
+        //     F = Pk L^-T  satisfies  F F^T = Pk Ahat^-1 Pk = pinv of the kept part of A,    F^T A^2 F = L^T Pk L
+        // -- the two things the device half needs.  Only the d dropped eigenvectors are formed (inverse iteration), not all q:
+        // reduction + QL values + Cholesky with inverse, ~1.0 ms at q = 200 against 1.5 ms for the full eigensolve.
+        // (on the host tried only where it pays: below q = 512, where the eigensolver is single threaded -- at q = 900 with 100
+        // dropped eigenvalues it lost 40 ms to the threaded full solve -- and for at most q / 8 dropped eigenvalues)
+        if (!dev_wa && !chol_wa && std::getenv("NLE_FORCE_EIG") == nullptr && std::getenv("NLE_NO_DEFLATE") == nullptr && q >= 16 && q < 512) {
+            std::vector<double> Dall(q), Vd((size_t)q * (max_defl + 1));
+            int kept = 0;
+            tr.mark("ss:   Wa built, Cholesky attempt");
+            if (nleh::sym_eigen_select(o.Wa.data(), q, Dall.data(), 0, 0, Vd.data(), NLE_EPS, max_defl, &kept)) {
+                tr.mark("ss:   Wa eigenvalues + dropped eigenvectors");
+                nd = q - kept;
+                if (kept > 0 && nd <= max_defl && Dall[0] > 0.0) {
+                    const double sig = Dall[0];
+                    std::vector<double> Ah(qq);
+                    for (int cidx = 0; cidx < q; ++cidx)  // the symmetric matrix the reference's solver sees: lower triangle
+                        for (int ridx = 0; ridx < q; ++ridx)
+                            Ah[(size_t)cidx * q + ridx] = ridx >= cidx ? o.Wa[(size_t)cidx * q + ridx] : o.Wa[(size_t)ridx * q + cidx];
+                    for (int t = 0; t < nd; ++t) {
+                        const double wgt = sig - Dall[kept + t];
+                        const double* v = Vd.data() + (size_t)t * q;
+                        for (int cidx = 0; cidx < q; ++cidx) {
+                            const double vc = wgt * v[cidx];
+                            for (int ridx = 0; ridx < q; ++ridx) Ah[(size_t)cidx * q + ridx] += v[ridx] * vc;
+                        }
+                    }
+                    L.resize(qq);
+                    Li.resize(qq);
+                    double inv_trace = 0.0;
+                    if (nleh::cholesky_with_inverse(Ah.data(), q, L.data(), Li.data(), &inv_trace)) {
+                        tr.mark("ss:   deflated matrix + its Cholesky factor and inverse");
+                        // F = L^-T - Vd (Vd^T L^-T),  G = L^T Vd
+                        Fdefl.resize(qq);
+                        for (int k = 0; k < q; ++k)
+                            for (int a = 0; a < q; ++a) Fdefl[(size_t)k * q + a] = Li[(size_t)a * q + k];
+                        Gdefl.assign((size_t)q * std::max(nd, 1), 0.0);
+                        std::vector<double> wv(q);
+                        for (int t = 0; t < nd; ++t) {
+                            const double* v = Vd.data() + (size_t)t * q;
+                            for (int k = 0; k < q; ++k) {  // w = (Vd^T L^-T)[t, k] = sum_a v[a] L^-T(a, k) = sum_a v[a] Li(k, a)
+                                double acc = 0.0, g = 0.0;
+                                for (int a = 0; a < q; ++a) {
+                                    acc += v[a] * Li[(size_t)a * q + k];
+                                    g += L[(size_t)k * q + a] * v[a];  // (L^T v)[k] = sum_a L(a, k) v[a]
+                                }
+                                wv[k] = acc;
+                                Gdefl[(size_t)t * q + k] = g;
+                            }
+                            for (int k = 0; k < q; ++k)
+                                for (int a = 0; a < q; ++a) Fdefl[(size_t)k * q + a] -= v[a] * wv[k];
+                        }
+                        deflated = true;
+                        r2 = kept;
+                        if (std::getenv("NLE_TRACE"))
+                            fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e), %d deflated\n",
+                                    kept, q, Dall[0], Dall[kept - 1], nd);
+                    }
+                }
+            }
+        }
+        if (!chol_wa && !deflated) {
+            std::vector<double> Uf(qq), l2(q);
+            if (!nleh::eigen_decomposition(o.Wa.data(), q, NLE_EPS, Uf.data(), l2.data(), &r2))
+                throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Wa"};
+            U2.assign(Uf.begin(), Uf.begin() + (size_t)q * std::max(r2, 1));
+            l2_kept.assign(l2.begin(), l2.begin() + r2);
+            Us.resize((size_t)q * std::max(r2, 1));
+            for (int k = 0; k < r2; ++k) {
+                const double sv = std::sqrt(recip0(l2[k]));
+                for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * sv;
+            }
+            if (std::getenv("NLE_TRACE"))
+                fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e)\n", r2, q, l2[0],
+                        r2 > 0 ? l2[r2 - 1] : 0.0);
+        }
     }
     o.r_wa = chol_wa ? q : r2;
     o.chol_wa = chol_wa;
     const bool chol_form = chol_wa || deflated;  // F is q x q and F^T A^2 F = L^T L (- G G^T)
     *host_overlapped_ms += now_ms() - h0;
-    tr.mark("ss: Wa root (host, under the Gram kernels)");
+    tr.mark(dev_done ? "ss: Wa root (device, second stream, beside the Gram kernels)" : "ss: Wa root (host, under the Gram kernels)");
     // ---- device: with a factor F of the (pseudo-)inverse of A = sym-lower(Wa), F F^T = A^+, the matrix the reference
     // diagonalises, Q = Wa + S (Wab Wab^T) S with S = A^+1/2 (:296), is similar on range(A) to
     //     Qt = F^T A^2 F + F^T WW F          (m x m, m = number of eigenvalues of Wa kept by the cut, :287)
@@ -786,23 +876,31 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     const int m = chol_form ? q : std::max(r2, 0);
     if (m <= 0) throw Fail{NLE_ERR_NUMERIC, "Wa has no eigenvalue >= 1e-10"};
     const size_t mm_ = (size_t)m * m;
-    DevBuf<double> d_Wa(qq), d_F((size_t)q * m), d_L, d_T(pp), d_T1((size_t)m * q), d_Qm(mm_);
-    HIP_OK(hipMemcpyAsync(d_Wa.p, o.Wa.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));
-    std::vector<double> F;  // q x m column-major
-    if (chol_form) {
-        if (deflated) {
-            F = Fdefl;
+    DevBuf<double> d_T(pp), d_T1((size_t)m * q), d_Qm(mm_);
+    if (!dev_wa) HIP_OK(hipMemcpyAsync(d_Wa.p, o.Wa.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));
+    if (!dev_done) {
+        std::vector<double> F;  // q x m column-major
+        if (chol_form) {
+            if (deflated) {
+                F = Fdefl;
+            } else {
+                F.resize(qq);
+                for (int k = 0; k < q; ++k)
+                    for (int a = 0; a < q; ++a) F[(size_t)k * q + a] = Li[(size_t)a * q + k];  // L^-T
+            }
+            d_L.alloc(qq);
+            HIP_OK(hipMemcpyAsync(d_L.p, L.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));
         } else {
-            F.resize(qq);
-            for (int k = 0; k < q; ++k)
-                for (int a = 0; a < q; ++a) F[(size_t)k * q + a] = Li[(size_t)a * q + k];  // L^-T
+            F = Us;
         }
-        d_L.alloc(qq);
-        HIP_OK(hipMemcpyAsync(d_L.p, L.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));
-    } else {
-        F = Us;
+        d_F.alloc((size_t)q * m);
+        HIP_OK(hipMemcpyAsync(d_F.p, F.data(), (size_t)q * m * sizeof(double), hipMemcpyHostToDevice, st));
+        if (deflated && nd > 0) {
+            d_G.alloc((size_t)q * nd);
+            HIP_OK(hipMemcpyAsync(d_G.p, Gdefl.data(), (size_t)q * nd * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+        HIP_OK(hipStreamSynchronize(st));  // the staging vectors go out of scope
     }
-    HIP_OK(hipMemcpyAsync(d_F.p, F.data(), (size_t)q * m * sizeof(double), hipMemcpyHostToDevice, st));
     reduce_gram();
     if (q < p) {  // samples that fall in the B block: Gk += Kr[:, q:] diag(cA[q:]^2) Kr[:, q:]^T
         std::vector<double> c2(p - q);
@@ -823,12 +921,9 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
         DevBuf<double> d_A2(qq);
         HIP_OK(nlek::gemm64s(st, q, q, q, d_L.p, q, 1, d_L.p, 1, q, d_A2.p, 1, q));
         if (deflated && nd > 0) {  // - G G^T
-            DevBuf<double> d_G((size_t)q * nd), d_neg(nd);
-            const std::vector<double> neg(nd, -1.0);
-            HIP_OK(hipMemcpyAsync(d_G.p, Gdefl.data(), (size_t)q * nd * sizeof(double), hipMemcpyHostToDevice, st));
-            HIP_OK(hipMemcpyAsync(d_neg.p, neg.data(), nd * sizeof(double), hipMemcpyHostToDevice, st));
+            DevBuf<double> d_neg(nd);
+            HIP_OK(nlek::fill64(st, d_neg.p, nd, -1.0));
             HIP_OK(nlek::gemm64s(st, q, q, nd, d_G.p, 1, q, d_G.p, q, 1, d_A2.p, 1, q, nullptr, d_neg.p, nullptr, d_A2.p, 1, q));
-            HIP_OK(hipStreamSynchronize(st));  // `neg` (host) is consumed
         }
         HIP_OK(nlek::gemm64s(st, m, m, q, d_T1.p, 1, m, d_F.p, 1, q, d_Qm.p, 1, m, nullptr, d_rA.p, nullptr, d_A2.p, 1, q));
     } else {
@@ -836,13 +931,34 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     }
     std::vector<double> Vq, Sq;
     int rq = 0;
-    // Top eigenpairs of Qt: on the host.  NLE_DEVICE_TRIDIAG=1 (opt-in; default solver, K <= m / 2, m <= 224) runs the
-    // Householder reduction on the device instead, where Qt already is (k_tridiag, one workgroup) -- measured at m = 196:
-    // 0.66 ms on the device against 0.43 ms of the 1.26 ms host solve, so it is not the default (tridiag.hip says why).
+    // Top eigenpairs of Qt.  From dev_solver_min_n() on: reduction, eigenvalues and back-transformation on the device
+    // (dense64.hip), only the inverse iteration for the K kept vectors on the host.  Below it: on the host
+    // (NLE_DEVICE_TRIDIAG=1, opt-in, K <= m / 2, m <= 224: the one-workgroup reduction of tridiag.hip -- measured at m = 196:
+    // 0.66 ms on the device against 0.43 ms of the 1.26 ms host solve, so it is not the default).
     const int kq = std::min(std::max(n_eig, 1), m);
-    const bool dev_tridiag = c->topk_solver == 0 && m >= 16 && m <= nlek::tridiag_max_n() && 2 * kq <= m &&
+    const bool dev_eig = c->topk_solver == 0 && use_dev_solver(m) && !std::getenv("NLE_HOST_Q");
+    const bool dev_tridiag = !dev_eig && c->topk_solver == 0 && m >= 16 && m <= nlek::tridiag_max_n() && 2 * kq <= m &&
                              std::getenv("NLE_DEVICE_TRIDIAG") != nullptr;
-    if (dev_tridiag) {
+    DevSymEig es;  // (its staging buffer must outlive the upload it enqueues: function scope)
+    DevBuf<double> d_Vq, d_l2q;
+    if (dev_eig) {
+        const double* d_add = nullptr;
+        if (!chol_form) {
+            d_l2q.alloc(m);
+            HIP_OK(hipMemcpyAsync(d_l2q.p, l2_kept.data(), m * sizeof(double), hipMemcpyHostToDevice, st));
+            d_add = d_l2q.p;
+        }
+        es.reduce(c, m, d_Qm.p, d_add);
+        tr.mark("ss: Q, its tridiagonal form and eigenvalues (device)");
+        h0 = now_ms();
+        Sq = es.D;
+        while (rq < m && Sq[rq] >= NLE_EPS) ++rq;  // :213-216
+        const int Kd = std::min(n_eig, rq);
+        if (Kd > 0) {
+            d_Vq.alloc((size_t)m * Kd);
+            es.vectors(c, 0, Kd, d_Vq.p);
+        }
+    } else if (dev_tridiag) {
         DevBuf<double> d_tv(mm_), d_td((size_t)3 * m), d_l2;
         const double* d_add = nullptr;
         if (!chol_form) {
@@ -881,10 +997,13 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     std::vector<double> sv(K);
     for (int k = 0; k < K; ++k) sv[k] = std::sqrt(recip0(Sq[k]));  // :319-321
     *host_ms += now_ms() - h0;
-    tr.mark("ss: eig(Q) (host)");
+    tr.mark(dev_eig ? "ss: eigenvectors of Q (inverse iteration on the host, back-transformation enqueued)" : "ss: eig(Q) (host)");
     // ---- device: T2 = F Vt Sq^-1/2, D = P[:, :q] diag(rA) T2, Vrows = [Wa T2; diag(cA_B) Kr_B D]
-    DevBuf<double> d_Vq((size_t)m * K), d_sv(K), d_T2((size_t)q * K), d_D((size_t)p * K), d_Vr((size_t)p * K);
-    HIP_OK(hipMemcpyAsync(d_Vq.p, Vq.data(), (size_t)m * K * sizeof(double), hipMemcpyHostToDevice, st));
+    DevBuf<double> d_sv(K), d_T2((size_t)q * K), d_D((size_t)p * K), d_Vr((size_t)p * K);
+    if (!dev_eig) {
+        d_Vq.alloc((size_t)m * K);
+        HIP_OK(hipMemcpyAsync(d_Vq.p, Vq.data(), (size_t)m * K * sizeof(double), hipMemcpyHostToDevice, st));
+    }
     HIP_OK(hipMemcpyAsync(d_sv.p, sv.data(), K * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_OK(nlek::gemm64s(st, q, K, m, d_F.p, 1, q, d_Vq.p, 1, m, d_T2.p, 1, q, nullptr, nullptr, d_sv.p));
     if (r < p) {
@@ -1530,7 +1649,7 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum_in, int H, int W, int nRow
         sm.host += now_ms() - h0;
         auto solve = [&](bool allow_chol) {
             const double t0 = now_ms();
-            Nystrom ny = solve_Ka(Ka, ss.p, allow_chol);
+            Nystrom ny = solve_Ka(c, Ka, ss.p, allow_chol);
             tr.mark(ny.chol ? "chol(Ka)" : "eig(Ka)");
             sm.host += now_ms() - t0;
             return ny;
@@ -1615,21 +1734,6 @@ void layer_resp(const double* ev, int K, int L, double* out) {
         }
 }
 
-template <typename Fn>
-int guard(nle_ctx* c, Fn&& fn) {
-    CurCtx scope(c);
-    try {
-        fn();
-        return NLE_OK;
-    } catch (const Fail& e) {
-        if (c) c->err = e.msg; else g_create_err = e.msg;
-        return e.code;
-    } catch (const std::exception& e) {
-        if (c) c->err = e.what(); else g_create_err = e.what();
-        return NLE_ERR_INVALID;
-    }
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------ C ABI
@@ -1683,6 +1787,12 @@ void nle_ctx_destroy(nle_ctx* ctx) {
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     for (auto e : ctx->copy_ev)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->aux_stream) {
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+        if (ctx->aux_ev) (void)hipEventDestroy(ctx->aux_ev);
+    }
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
@@ -2046,7 +2156,7 @@ int nle_nystrom(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_sample
         HIP_OK(hipSetDevice(ctx->device));
         SampleSet ss = fetch_samples(ctx, d_lum, gs);
         std::vector<double> Ka = build_Ka(ss, hx, hy);
-        Nystrom ny = solve_Ka(Ka, ss.p, false);
+        Nystrom ny = solve_Ka(nullptr, Ka, ss.p, false);
         int row0, row1;
         slab(H, ctx->rank, ctx->world, &row0, &row1);
         build_phi(ctx, d_lum, ss, ny, hx, hy, (long long)row0 * W, (long long)(row1 - row0) * W, d_phi);

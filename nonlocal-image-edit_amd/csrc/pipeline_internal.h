@@ -48,6 +48,10 @@ struct nle_ctx {
     size_t arena_bytes = 0;
     double* d_lut = nullptr;        // sRGB decode table of the colour wrapper
     std::set<nle_filter*> filters;  // live filters trained on this ctx (orphaned if the ctx dies first)
+    hipEvent_t aux_ev = nullptr;
+    void* h_stage = nullptr;  // page-locked staging block for the solvers' larger transfers (grow-only; pinned_stage())
+    size_t h_stage_bytes = 0;
+    hipStream_t aux_stream = nullptr;   // second compute stream (devsolve.hip: the root of Wa beside the Gram kernels)
     hipStream_t copy_stream = nullptr;  // device-to-host copies of finished output layers (host-buffer entry points)
     hipEvent_t copy_ev[2] = {nullptr, nullptr};
     int mode = 0;  // nle_ctx_set_mode: 0 auto, 1 materialised Phi, 2 Phi-free, 3 Phi-free without look-up tables
@@ -361,6 +365,55 @@ inline void all_reduce(nle_ctx* c, double* d, size_t n) {
     HIP_OK(hipMemcpyAsync(c->d_comm, d, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     if (c->allreduce(c->ar_user, c->d_comm, n) != 0) throw Fail{NLE_ERR_COMM, "all-reduce callback failed"};
     HIP_OK(hipMemcpyAsync(d, c->d_comm, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+}
+
+
+// page-locked host block of at least `bytes` owned by the ctx (contents undefined; valid until the next call)
+inline void* pinned_stage(nle_ctx* c, size_t bytes) {
+    if (c->h_stage_bytes < bytes) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr;
+        c->h_stage_bytes = 0;
+        HIP_OK(hipHostMalloc(&c->h_stage, bytes, hipHostMallocDefault));
+        c->h_stage_bytes = bytes;
+    }
+    return c->h_stage;
+}
+
+inline double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+// NLE_TRACE=1: stage marks of a train call on stderr
+struct Trace {
+    bool on;
+    double t0, last;
+    Trace() : on(std::getenv("NLE_TRACE") != nullptr) { t0 = last = now_ms(); }
+    void mark(const char* what) {
+        if (!on) return;
+        const double t = now_ms();
+        std::fprintf(stderr, "[nle trace] %-28s +%8.3f ms  (t=%8.3f)\n", what, t - last, t - t0);
+        last = t;
+    }
+};
+
+// error text of the last failed call without a ctx (nle_ctx_create)
+inline thread_local std::string g_create_err;
+
+// body of every C ABI entry point: exceptions become status codes, the ctx's workspace cache serves the DevBufs
+template <typename Fn>
+int guard(nle_ctx* c, Fn&& fn) {
+    CurCtx scope(c);
+    try {
+        fn();
+        return NLE_OK;
+    } catch (const Fail& e) {
+        if (c) c->err = e.msg; else g_create_err = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        if (c) c->err = e.what(); else g_create_err = e.what();
+        return NLE_ERR_INVALID;
+    }
 }
 
 }  // namespace nlep

@@ -9,8 +9,13 @@ H, W, L = cfg["H"], cfg["W"], cfg["L"]
 ctx = nle.Context(0)
 lum = torch.from_numpy(np.ascontiguousarray(synth.synthetic_luminance(H, W), dtype=np.float32)).cuda()
 f = nle.NLEFilter(ctx)
-for it in range(4):
-    if it == 3: os.environ["NLE_TRACE"] = "1"
+import time
+for it in range(5):
+    if it == 4: os.environ["NLE_TRACE"] = "1"
+    t0 = time.perf_counter()
     f.train_filter(lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"])
-    f.apply_layers(lum, L)
+    t1 = time.perf_counter()
+    Y = f.apply_layers(lum, L)
     torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"[step {it}] train {1e3 * (t1 - t0):.2f} ms, apply {1e3 * (t2 - t1):.2f} ms", file=sys.stderr)
