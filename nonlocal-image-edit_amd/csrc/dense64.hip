@@ -500,14 +500,15 @@ __global__ __launch_bounds__(1024) void k_sumsq(const double* __restrict__ x, si
     }
 }
 
-__global__ void k_transpose64(int n, const double* __restrict__ src, double* __restrict__ dst) {
+// dst (n x n, column stride ldd) = transpose of src (n x n, column stride lds)
+__global__ void k_transpose64(int n, const double* __restrict__ src, int lds, double* __restrict__ dst, int ldd) {
     __shared__ double tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 threads
     for (int r = ty; r < 32; r += 8)
-        if (bx + tx < n && by + r < n) tile[r][tx] = src[(size_t)(by + r) * n + bx + tx];  // element (row bx+tx, col by+r)
+        if (bx + tx < n && by + r < n) tile[r][tx] = src[(size_t)(by + r) * lds + bx + tx];  // element (row bx+tx, col by+r)
     __syncthreads();
     for (int r = ty; r < 32; r += 8)
-        if (by + tx < n && bx + r < n) dst[(size_t)(bx + r) * n + by + tx] = tile[tx][r];  // dst(row by+tx, col bx+r)
+        if (by + tx < n && bx + r < n) dst[(size_t)(bx + r) * ldd + by + tx] = tile[tx][r];  // dst(row by+tx, col bx+r)
 }
 // dst = the symmetric matrix whose lower triangle is src's (what SelfAdjointEigenSolver sees, src/filter.cpp:207)
 __global__ void k_symm_lower64(int n, const double* __restrict__ src, double* __restrict__ dst) {
@@ -516,8 +517,9 @@ __global__ void k_symm_lower64(int n, const double* __restrict__ src, double* __
         dst[t] = r >= c ? src[t] : src[(size_t)r * n + c];
     }
 }
-hipError_t transpose64(hipStream_t s, int n, const double* d_src, double* d_dst) {
-    hipLaunchKernelGGL(k_transpose64, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, s, n, d_src, d_dst);
+hipError_t transpose64(hipStream_t s, int n, const double* d_src, double* d_dst, int lds, int ldd) {
+    hipLaunchKernelGGL(k_transpose64, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, s, n, d_src, lds > 0 ? lds : n, d_dst,
+                       ldd > 0 ? ldd : n);
     return hipGetLastError();
 }
 hipError_t symm_lower64(hipStream_t s, int n, const double* d_src, double* d_dst) {

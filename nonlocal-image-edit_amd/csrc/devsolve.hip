@@ -75,13 +75,18 @@ void DevSymEig::reduce(nle_ctx* c, int n_, const double* d_M, const double* d_di
         CuLease lease(G);
         HIP_OK(nlek::sytrd_dist(st, n, G, d_M, d_diag_add, pub.p, tde.p, tde.p + n, status.p));
         HIP_OK(nlek::tridiag_bisect(st, n, tde.p, tde.p + n, tde.p + 2 * n));
-        std::vector<double> h((size_t)3 * n);
-        HIP_OK(hipMemcpyAsync(h.data(), tde.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        std::vector<double> hv;
+        double* h = static_cast<double*>(pinned_take(c, (size_t)3 * n * sizeof(double)));
+        if (!h) {
+            hv.resize((size_t)3 * n);
+            h = hv.data();
+        }
+        HIP_OK(hipMemcpyAsync(h, tde.p, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(&h_status, status.p, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
-        std::copy(h.begin(), h.begin() + n, d.begin());
-        std::copy(h.begin() + n, h.begin() + 2 * n, e.begin());
-        std::copy(h.begin() + 2 * n, h.end(), D.begin());
+        std::copy(h, h + n, d.begin());
+        std::copy(h + n, h + 2 * n, e.begin());
+        std::copy(h + 2 * n, h + 3 * n, D.begin());
     }
     if (h_status != 0) throw Fail{NLE_ERR_NUMERIC, "device eigensolver: a hand-off between workgroups timed out"};
     for (int i = 0; i < n; ++i)
@@ -93,11 +98,15 @@ void DevSymEig::vectors(nle_ctx* c, int first, int count, double* d_Z) {
     if (first < 0 || first + count > n) throw Fail{NLE_ERR_INVALID, "device eigensolver: eigenvector range"};
     static const bool trace = std::getenv("NLE_EIG_TRACE") != nullptr;
     const double t0 = trace ? now_ms() : 0.0;
-    hZ.resize((size_t)n * count);
-    if (!nleh::tridiag_eigenvectors(n, d.data(), e.data(), D.data(), first, count, hZ.data()))
+    double* hz = static_cast<double*>(pinned_take(c, (size_t)n * count * sizeof(double)));
+    if (!hz) {
+        hZ.resize((size_t)n * count);
+        hz = hZ.data();
+    }
+    if (!nleh::tridiag_eigenvectors(n, d.data(), e.data(), D.data(), first, count, hz))
         throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge (tridiagonal eigenvectors)"};
     if (trace) std::fprintf(stderr, "[nle eig] device path n = %d: %d vectors by inverse iteration %.3f ms\n", n, count, now_ms() - t0);
-    HIP_OK(hipMemcpyAsync(d_Z, hZ.data(), hZ.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_Z, hz, (size_t)n * count * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_OK(nlek::sytrd_back(st, n, pub.p, count, d_Z, n));
 }
 

@@ -182,7 +182,8 @@ hipError_t sytrd_back(hipStream_t s, int n, const double* d_pub, int K, double* 
 size_t potrf_tmp_elems(int n);
 hipError_t potrf_inverse(hipStream_t s, int n, const double* d_A, double* d_L, double* d_Linv, double* d_tmp, double* d_scal,
                          int* d_status);
-hipError_t transpose64(hipStream_t s, int n, const double* d_src, double* d_dst);   // n x n column-major
+// d_dst = d_src^T, n x n column-major with column strides lds / ldd (0: n)
+hipError_t transpose64(hipStream_t s, int n, const double* d_src, double* d_dst, int lds = 0, int ldd = 0);
 hipError_t symm_lower64(hipStream_t s, int n, const double* d_src, double* d_dst);  // mirror the lower triangle
 hipError_t fill64(hipStream_t s, double* d_p, size_t n, double v);
 

@@ -96,9 +96,16 @@ std::vector<double> build_Ka(const SampleSet& s, double hx, double hy) {
 // so when Ka is provably full rank at the reference's threshold (every eigenvalue >= 1e-10, certified
 // by 1 / trace(Ka^-1)) the Cholesky factor serves as well: VA = L, lam = 1, B = L^-T (P = I) -- a
 // p^3/3 factorisation instead of a p x p eigensolve.  The materialised path keeps the eigenpairs.
+// Ka and its Cholesky factors left on the device by solve_Ka's device route (then VA and B stay empty on the host)
+struct KaDevice {
+    DevBuf<double> Ka;
+    DevChol ch;
+};
+
 struct Nystrom {
     int r = 0, ldr = 0;
     bool chol = false;
+    std::shared_ptr<KaDevice> dev;  // set: L = dev->ch.L, L^-1 = dev->ch.Linv (p x p column-major, device)
     std::vector<double> VA;   // p x r col-major
     std::vector<double> lam;  // r
     std::vector<double> B;    // p x r col-major
@@ -111,41 +118,39 @@ constexpr double kCholMaxInvTrace = 1e9;
 Nystrom solve_Ka(nle_ctx* c, const std::vector<double>& Ka, int p, bool allow_chol) {
     Nystrom n;
     if (allow_chol && std::getenv("NLE_FORCE_EIG") == nullptr) {
-        std::vector<double> L((size_t)p * p), Li((size_t)p * p);
-        double inv_trace = 0.0;
-        bool ok;
-        if (c && use_dev_solver(p) && !std::getenv("NLE_HOST_KA")) {  // blocked factorisation + inverse on the device (dense64.hip): 22 -> ~5 ms at p = 900
+        if (c && use_dev_solver(p) && !std::getenv("NLE_HOST_KA")) {  // blocked factorisation + inverse on the device (dense64.hip)
             const size_t pp = (size_t)p * p;
-            DevBuf<double> d_Ka(pp);
-            HIP_OK(hipMemcpyAsync(d_Ka.p, Ka.data(), pp * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            DevChol ch;
-            ch.factor(c, p, d_Ka.p);
-            ok = ch.finish(c);
-            inv_trace = ch.inv_trace;
-            if (ok && inv_trace <= kCholMaxInvTrace) {
-                // (through the ctx's page-locked block: a device-to-host copy of this size into pageable memory left the
-                // runtime with 10-20 ms of clean-up at a later synchronisation)
-                double* hs = static_cast<double*>(pinned_stage(c, 2 * pp * sizeof(double)));
-                HIP_OK(hipMemcpyAsync(hs, ch.L.p, pp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-                HIP_OK(hipMemcpyAsync(hs + pp, ch.Linv.p, pp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-                HIP_OK(hipStreamSynchronize(c->stream));
-                std::copy(hs, hs + pp, L.begin());
-                std::copy(hs + pp, hs + 2 * pp, Li.begin());
+            auto kd = std::make_shared<KaDevice>();
+            kd->Ka.alloc(pp);
+            upload_staged(c, kd->Ka.p, Ka.data(), pp, c->stream);
+            kd->ch.factor(c, p, kd->Ka.p);
+            if (kd->ch.finish(c) && kd->ch.inv_trace <= kCholMaxInvTrace) {
+                // the factors stay on the device: the table path builds the Sinkhorn update's operands from them there
+                // (22 ms of host factorisation and ~28 ms of host transposes and uploads at p = 900 become ~6 ms)
+                n.chol = true;
+                n.r = p;
+                n.ldr = ld4(p);
+                n.lam.assign(p, 1.0);
+                n.Ka = Ka;
+                n.dev = std::move(kd);
+                return n;
             }
         } else {
-            ok = nleh::cholesky_with_inverse(Ka.data(), p, L.data(), Li.data(), &inv_trace, kCholMaxInvTrace);
-        }
-        if (ok && inv_trace <= kCholMaxInvTrace) {
-            n.chol = true;
-            n.r = p;
-            n.ldr = ld4(p);
-            n.VA = std::move(L);
-            n.lam.assign(p, 1.0);
-            n.B.resize((size_t)p * p);
-            for (int k = 0; k < p; ++k)
-                for (int a = 0; a < p; ++a) n.B[(size_t)k * p + a] = Li[(size_t)a * p + k];  // L^-T
-            n.Ka = Ka;
-            return n;
+            std::vector<double> L((size_t)p * p), Li((size_t)p * p);
+            double inv_trace = 0.0;
+            if (nleh::cholesky_with_inverse(Ka.data(), p, L.data(), Li.data(), &inv_trace, kCholMaxInvTrace) &&
+                inv_trace <= kCholMaxInvTrace) {
+                n.chol = true;
+                n.r = p;
+                n.ldr = ld4(p);
+                n.VA = std::move(L);
+                n.lam.assign(p, 1.0);
+                n.B.resize((size_t)p * p);
+                for (int k = 0; k < p; ++k)
+                    for (int a = 0; a < p; ++a) n.B[(size_t)k * p + a] = Li[(size_t)a * p + k];  // L^-T
+                n.Ka = Ka;
+                return n;
+            }
         }
     }
     // nystromApproximation, reference src/filter.cpp:262-271
@@ -712,7 +717,7 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
         HIP_OK(hipStreamSynchronize(st));
         const bool wa_serial = std::getenv("NLE_WA_SERIAL") != nullptr;  // measurement: the Gram kernels after the root
         if (!wa_serial) enqueue_gram();
-        HIP_OK(hipMemcpyAsync(d_Wa.p, o.Wa.data(), qq * sizeof(double), hipMemcpyHostToDevice, sa));
+        upload_staged(c, d_Wa.p, o.Wa.data(), qq, sa);
         HIP_OK(nlek::symm_lower64(sa, q, d_Wa.p, d_Ah.p));
         if (!force_eig && inv_diag <= kCholMaxInvTrace) {
             chw.factor(c, q, d_Ah.p);
@@ -1327,9 +1332,21 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     f->r = r;
     f->chol_ka = ny.chol ? 1 : 0;
     f->formulation = hist ? NLE_MODE_PHI_FREE : NLE_MODE_PHI_FREE_EXP;
-    {
+    if (ny.dev) {
+        // Cholesky form with the factors on the device: X1 = [L^-T; 0] (2p x p column-major), X2 = [L^-T; Ka] row-major --
+        // row a of L^-T is column a of L^-1 and Ka is symmetric, so X2 is two plain copies and X1 one transpose
+        const size_t n2 = (size_t)2 * p, pp = (size_t)p * p;
+        d_X1.alloc(n2 * p);
+        d_X2.alloc(n2 * p);
+        d_lam.alloc(p);
+        HIP_OK(hipMemsetAsync(d_X1.p, 0, n2 * p * sizeof(double), c->stream));
+        HIP_OK(nlek::transpose64(c->stream, p, ny.dev->ch.Linv.p, d_X1.p, p, 2 * p));
+        HIP_OK(hipMemcpyAsync(d_X2.p, ny.dev->ch.Linv.p, pp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_X2.p + pp, ny.dev->Ka.p, pp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIP_OK(nlek::fill64(c->stream, d_lam.p, p, 1.0));
+    } else {
         // X1 (2p x r column-major) and X2 (2p x r row-major) = [B; V_A]; Cholesky form: X1 = [L^-T; 0], the lower
-        // half of X2 = the rows of Ka (exact projector / exact V_A diag(lambda) V_A^T, see k_sink_update_b)
+        // half of X2 = the rows of Ka itself (exact projector / exact V_A diag(lambda) V_A^T, see k_sink_update_b)
         const size_t n2 = (size_t)2 * p;
         std::vector<double> X1(n2 * r, 0.0), X2(n2 * r);
         for (int k = 0; k < r; ++k)
@@ -1631,6 +1648,7 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum_in, int H, int W, int nRow
         const long long M = (long long)(f->row1 - f->row0) * W;
         f->n_local = M;
         const double t_begin = now_ms();
+        pinned_reset(c);
         Trace tr;
         StageMs sm;
         // --- sample set, Ka and its eigenpairs (:486-491, host fp64)

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <thread>
@@ -49,8 +50,8 @@ struct nle_ctx {
     double* d_lut = nullptr;        // sRGB decode table of the colour wrapper
     std::set<nle_filter*> filters;  // live filters trained on this ctx (orphaned if the ctx dies first)
     hipEvent_t aux_ev = nullptr;
-    void* h_stage = nullptr;  // page-locked staging block for the solvers' larger transfers (grow-only; pinned_stage())
-    size_t h_stage_bytes = 0;
+    void* h_stage = nullptr;  // page-locked staging block for the solvers' larger transfers (pinned_take())
+    size_t h_stage_bytes = 0, h_stage_used = 0, h_stage_want = 0;
     hipStream_t aux_stream = nullptr;   // second compute stream (devsolve.hip: the root of Wa beside the Gram kernels)
     hipStream_t copy_stream = nullptr;  // device-to-host copies of finished output layers (host-buffer entry points)
     hipEvent_t copy_ev[2] = {nullptr, nullptr};
@@ -368,16 +369,37 @@ inline void all_reduce(nle_ctx* c, double* d, size_t n) {
 }
 
 
-// page-locked host block of at least `bytes` owned by the ctx (contents undefined; valid until the next call)
-inline void* pinned_stage(nle_ctx* c, size_t bytes) {
-    if (c->h_stage_bytes < bytes) {
+// Page-locked staging memory of the ctx for the solvers' larger transfers, handed out bump-style within one train call
+// (large copies from / to pageable memory leave the runtime with milliseconds of clean-up at a later synchronisation).
+// pinned_reset at the start of a call; pinned_take returns nullptr when the block is exhausted (the caller then copies
+// from pageable memory; the block is sized to the high-water mark at the next reset).
+inline void pinned_reset(nle_ctx* c) {
+    if (c->h_stage_want > c->h_stage_bytes) {
         if (c->h_stage) (void)hipHostFree(c->h_stage);
         c->h_stage = nullptr;
         c->h_stage_bytes = 0;
-        HIP_OK(hipHostMalloc(&c->h_stage, bytes, hipHostMallocDefault));
-        c->h_stage_bytes = bytes;
+        const size_t want = c->h_stage_want + c->h_stage_want / 4;
+        if (hipHostMalloc(&c->h_stage, want, hipHostMallocDefault) == hipSuccess) c->h_stage_bytes = want;
+        else c->h_stage = nullptr;
     }
-    return c->h_stage;
+    c->h_stage_used = 0;
+    c->h_stage_want = 0;
+}
+inline void* pinned_take(nle_ctx* c, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    c->h_stage_want += bytes;
+    if (!c->h_stage || c->h_stage_used + bytes > c->h_stage_bytes) return nullptr;
+    void* p = static_cast<char*>(c->h_stage) + c->h_stage_used;
+    c->h_stage_used += bytes;
+    return p;
+}
+// host-to-device copy of n doubles through the staging block when it has room
+inline void upload_staged(nle_ctx* c, double* d_dst, const double* h_src, size_t n, hipStream_t st) {
+    if (void* hp = pinned_take(c, n * sizeof(double))) {
+        std::memcpy(hp, h_src, n * sizeof(double));
+        h_src = static_cast<const double*>(hp);
+    }
+    HIP_OK(hipMemcpyAsync(d_dst, h_src, n * sizeof(double), hipMemcpyHostToDevice, st));
 }
 
 inline double now_ms() {
