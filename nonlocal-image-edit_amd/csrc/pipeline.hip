@@ -719,15 +719,10 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
         if (!wa_serial) enqueue_gram();
         upload_staged(c, d_Wa.p, o.Wa.data(), qq, sa);
         HIP_OK(nlek::symm_lower64(sa, q, d_Wa.p, d_Ah.p));
-        if (!force_eig && inv_diag <= kCholMaxInvTrace) {
-            chw.factor(c, q, d_Ah.p);
-            chol_wa = chw.finish(c) && chw.inv_trace <= kCholMaxInvTrace;
-            tr.mark("ss:   Wa: Cholesky attempt (device)");
-        }
-        if (chol_wa) {
-            HIP_OK(nlek::transpose64(sa, q, chw.Linv.p, d_F.p));  // F = L^-T
-            dev_done = true;
-        } else if (!force_eig && std::getenv("NLE_NO_DEFLATE") == nullptr) {
+        // (no separate Cholesky attempt here: the host's stops at the first pivot that proves it futile, a device
+        // factorisation costs as much as the reduction -- so the eigenvalues come first and decide; none below the cut
+        // is the deflated route with nothing to deflate)
+        if (!force_eig && std::getenv("NLE_NO_DEFLATE") == nullptr) {
             esw.reduce(c, q, d_Ah.p, nullptr);
             tr.mark("ss:   Wa: tridiagonal form + eigenvalues (device)");
             int kept = 0;
@@ -759,7 +754,8 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
                         HIP_OK(nlek::gemm64s(sa, q, q, nd, d_Vd.p, 1, q, d_W.p, 1, nd, d_F.p, 1, q, nullptr, d_neg1.p, nullptr, d_F.p, 1, q));
                         HIP_OK(nlek::gemm64s(sa, q, nd, q, chw.L.p, q, 1, d_Vd.p, 1, q, d_G.p, 1, q));
                     }
-                    deflated = true;
+                    deflated = nd > 0;
+                    chol_wa = nd == 0;
                     dev_done = true;
                     r2 = kept;
                     if (std::getenv("NLE_TRACE"))
