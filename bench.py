@@ -153,6 +153,12 @@ def main():
     ap.add_argument("--inflight", type=int, default=1, help="images in flight on one GPU (throughput mode, opt-in)")
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 materialised Phi, 2 Phi-free (NLE_MODE_*)")
     ap.add_argument("--h2h-runs", type=int, default=7, help="host-to-host (section 8d) runs after 2 warm-ups; 0 skips")
+    ap.add_argument("--soak-seconds", type=float, default=5.0,
+                    help="N = 1: after the timed region keep stepping for this long (reported as `soak`; 0 skips) -- the timed "
+                         "region alone is ~0.2 s, too short for an external GPU-busy sampler to see")
+    ap.add_argument("--allow-callback-fallback", action="store_true",
+                    help="N > 1: if the native RCCL communicator cannot be created, time the torch.distributed callback path "
+                         "instead of exiting non-zero")
     ap.add_argument("--cpu-sample", type=int, default=768, help="side of the CPU-baseline sample image")
     ap.add_argument("--cpu-threads", type=int, default=16, help="BLAS threads for the CPU baseline (<= visible cores)")
     args = ap.parse_args()
@@ -189,6 +195,7 @@ def main():
     g = nle.sample_grid(H, W, cfg["n_row"], cfg["n_col"])
     p = g["n_sel_rows"] * g["n_sel_cols"]
     comm_kind = "none"
+    rccl_ranks = 0
     if world > 1:
         comm_kind = "torch.distributed all_reduce via callback"
         if args.comm == "rccl" and args.backend == "nccl" and not args.same_device:
@@ -198,15 +205,37 @@ def main():
             if rank == 0:
                 uid = torch.tensor(list(nle.rccl_unique_id()), dtype=torch.uint8, device=f"cuda:{local_rank}")
             dist.broadcast(uid, 0)
+            ok = 1
             try:
                 ctx.init_rccl(rank, world, bytes(uid.cpu().tolist()))
+            except Exception as e:  # noqa: BLE001
+                ok = 0
+                print(f"[bench] rank {rank}: native RCCL init failed ({e!r})", file=sys.stderr, flush=True)
+            # every rank must take the same path: agree on the outcome over the torch process group
+            okt = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local_rank}")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) == 1:
                 comm_kind = "native RCCL (ncclAllReduce in place on the ctx stream)"
-            except Exception as e:  # noqa: BLE001 -- keep the run alive on the callback path and say so
-                print(f"[bench] rank {rank}: native RCCL init failed ({e!r}); using the torch callback", file=sys.stderr, flush=True)
+                rccl_ranks = world
+            elif not args.allow_callback_fallback:
+                # a silent fall-back would time a different data path than the one the line claims: fail loudly, in every rank
+                print(f"[bench] rank {rank}: no native RCCL communicator on every rank; exiting (--allow-callback-fallback "
+                      "times the torch callback path instead)", file=sys.stderr, flush=True)
+                dist.destroy_process_group()
+                sys.exit(3)
+            else:
+                ctx.close()            # a half-initialised communicator is not reused
+                ctx = nle.Context(local_rank)
+                ctx.set_mode(args.mode)
         if comm_kind.startswith("torch"):
             ctx.set_shard(rank, world, p, lambda t: dist.all_reduce(t))
     elif args.simulate_world > 1:
-        ctx.set_shard(0, args.simulate_world, p, lambda t: None)
+        # rank 0 of a W-way shard without its peers: the "all-reduce" scales this rank's partial sums by W -- what the sum over
+        # W statistically alike slabs comes to -- so that the p-sized algebra sees matrices like the real run's (left
+        # unscaled they are a different problem: at cfg5 the 1e-10 cut then removes 145 eigenvalues of Wa instead of 100
+        # and the solver takes another route)
+        sw_ = float(args.simulate_world)
+        ctx.set_shard(0, args.simulate_world, p, lambda t: t.mul_(sw_))
 
     lum = torch.as_tensor(synth.synthetic_luminance(H, W).astype(np.float32), device=f"cuda:{local_rank}")
     n_local = ctx.local_pixels(H, W)
@@ -260,6 +289,28 @@ def main():
             t_.join()
 
     run_steps(args.warmup * len(lanes))
+    # N > 1: before anything is timed, this rank's rows of the sharded result against the same rows of an unsharded run on
+    # this GPU (only the order of the fp64 sums differs between the two; the test suite's bar for that is 1e-6)
+    shard_check = None
+    if world > 1:
+        c1 = nle.Context(local_rank)
+        c1.set_mode(args.mode)
+        f1 = nle.NLEFilter(c1)
+        f1.train_filter(lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"])
+        full = f1.apply_layers(lum, L)
+        r0_, r1_ = nle.slab_rows(H, rank, world)
+        mine = full[:, r0_ * W:r1_ * W]
+        errs = [float(torch.linalg.norm(out[j].double() - mine[j].double()) / torch.linalg.norm(mine[j].double())) for j in range(L)]
+        worst = torch.tensor([max(errs)], dtype=torch.float64, device=lum.device)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        shard_check = {"max_rel_l2_per_layer_vs_single_gpu": float(worst.item()), "matches": bool(worst.item() <= 1e-6)}
+        del full, mine
+        f1.close()
+        c1.close()
+        if not shard_check["matches"]:
+            print(f"[bench] rank {rank}: sharded output differs from the single-GPU result ({shard_check})", file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(4)
     for c_, _, _ in lanes:
         c_.profile(1)   # HIP events around the N-sized kernels of the timed region
     fence()
@@ -275,6 +326,18 @@ def main():
         c_.profile(False)
     info = flt.info()
     stage_ms = flt.timings()
+    soak = None
+    if world == 1 and args.soak_seconds > 0 and args.simulate_world <= 1 and len(lanes) == 1:
+        ts_, t_end = [], time.perf_counter() + args.soak_seconds
+        while time.perf_counter() < t_end:
+            t1_ = time.perf_counter()
+            step()
+            ts_.append(time.perf_counter() - t1_)      # apply_layers returns when the layers are written
+        fence()
+        a_ = np.sort(np.asarray(ts_)) * 1e3
+        soak = {"steps": int(a_.size), "seconds": float(a_.sum() / 1e3), "ms_median": float(np.median(a_)),
+                "ms_p99": float(a_[min(a_.size - 1, int(0.99 * a_.size))]), "ms_max": float(a_[-1]),
+                "what": "consecutive train + apply steps on the same ctx right after the timed region (not part of `value`)"}
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=lum.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -371,7 +434,8 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             ts = tt.tolist()
         ref = out.cpu().numpy()
-        same = bool(np.array_equal(ref, h_out)) or float(np.abs(ref - h_out).max() / max(np.abs(ref).max(), 1e-30))
+        same = bool(np.array_equal(ref, h_out))
+        h2h_diff = 0.0 if same else float(np.abs(ref - h_out).max() / max(np.abs(ref).max(), 1e-30))
         med = float(np.median(ts))
         h2h = {"value": (H * W / 1e6) / med, "unit": "MP/s", "ms_median": med * 1e3, "ms_min": min(ts) * 1e3,
                "ms_max": max(ts) * 1e3, "runs": len(ts), "warmup": 2,
@@ -379,7 +443,7 @@ def main():
                "what": "SURVEY.md section 8d: fp32 plane in page-locked host memory -> train -> L per-layer planes back in "
                        "page-locked host memory, one image at a time (nle_train_host + nle_apply_layers_host)"
                        + ("; per rank: its own rows up, its own rows of the layers down; max over ranks" if world > 1 else ""),
-               "matches_device_resident_output": same}
+               "matches_device_resident_output": same, "max_rel_diff_vs_device_resident_output": h2h_diff}
         f2.close()
 
     # ---- roofline of the dominant kernel (this rank's launches)
@@ -489,12 +553,17 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "megapixels/sec end-to-end enhance (4K img, m=200, K=50)",
+            # `value` is the device-resident figure the bench contract asks for (plane in HBM -> layers in HBM); SURVEY.md
+            # section 8d's own definition (host plane -> host layers) is `host_to_host.value` of the same line
+            "metric": ("megapixels/sec end-to-end enhance (4K img, m=200, K=50)" if args.config == "cfg4" else
+                       f"megapixels/sec end-to-end enhance ({H}x{W} img, m={p}, K={cfg['K']})")
+                      + "; device-resident input and output (host->host per SURVEY 8d: host_to_host.value)",
             "value": value, "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {H}x{W} synthetic luminance, {cfg['n_row']}x{cfg['n_col']} samples "
-                                   f"(p={p}), K={cfg['K']}, T={cfg['T']}, L={L} layers; input resident in HBM",
+                                   f"(p={p}), K={cfg['K']}, T={cfg['T']}, L={L} layers; device-resident: the luminance plane is in HBM when the "
+                                   f"timed region starts and the {L} layer planes are left in HBM (no PCIe inside `value`)",
                        "parallelism": (f"row-slab x{world}" if world > 1 else
                                        f"TIMING ONLY: rank 0 of a simulated {args.simulate_world}-way row shard, no-op all-reduce"
                                        if args.simulate_world > 1 else "single GPU")
@@ -507,6 +576,9 @@ def main():
             "pipelined": pipelined,
             "replicas": replicas,
             "comm": comm_kind,
+            "rccl_ranks": rccl_ranks,
+            "shard_check": shard_check,
+            "soak": soak,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": per_kernel,

@@ -118,9 +118,12 @@ def lib() -> C.CDLL:
     """Load libnle_hip.so (built by build.py).  Fails loudly if it is missing."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        # NLE_LIB_PATH: a measurement build of the same sources (tools/abl_run.sh) instead of the product library -- so that
+        # such a build never has to be copied over lib/libnle_hip.so
+        path = os.environ.get("NLE_LIB_PATH") or LIB_PATH
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: run `python nonlocal-image-edit_amd/build.py` "
+                f"{path} is missing: run `python nonlocal-image-edit_amd/build.py` "
                 "(or __graft_entry__.build()); there is no CPU fallback")
         # torch-rocm ships its own copy of the HIP runtime: load torch first so that this process ends up
         # with ONE libamdhip64 (loading ours first leaves torch and the library on different runtimes and
@@ -129,7 +132,7 @@ def lib() -> C.CDLL:
             import torch  # noqa: F401
         except ImportError:
             pass
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it
             fn.restype = res
@@ -266,6 +269,7 @@ class Context:
         if st != NLE_OK:
             raise NLEError(st, (lib().nle_last_error(None) or b"").decode())
         self.rank, self.world = rank, world
+        self.slab_input = False
         self._cb = None
         self._comm = None
         self._allreduce = allreduce
@@ -319,7 +323,8 @@ class Context:
         _check(lib().nle_ctx_set_mode(self._h, int(mode)), self._h)
 
     def host_alloc(self, shape, dtype=np.float32):
-        """page-locked host array (nle_host_alloc); freed with the returned array's `.base.free()` or at ctx close"""
+        """page-locked host array (nle_host_alloc).  The block belongs to the ctx and is freed by Context.close(): the
+        returned array (and every view of it) must not be used after that"""
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         ptr = C.c_void_p()
         _check(lib().nle_host_alloc(self._h, n, C.byref(ptr)), self._h)
@@ -624,11 +629,19 @@ class NLEFilter:
         """nle_apply_layers_host: x a HOST H x W fp32 array or None (= the training plane kept by
         train_filter_host); out: HOST (L, n_local) fp32 array"""
         H, W = self.shape
+        n_local = self.info()["n_local"]
         xp = None
         if x is not None:
             x = np.ascontiguousarray(x, dtype=np.float32)
+            want = n_local if (self.ctx.slab_input and self.ctx.world > 1) else H * W
+            if x.size != want:
+                raise NLEError(NLE_ERR_INVALID, f"apply_layers_host: x has {x.size} values, the filter needs {want}")
             xp = _np_ptr(x)
-        assert out.dtype == np.float32 and out.flags.c_contiguous
+        # the library writes n_layers * n_local floats into `out`: a short array would be a host heap overflow
+        if not (isinstance(out, np.ndarray) and out.dtype == np.float32 and out.flags.c_contiguous
+                and out.size == int(n_layers) * n_local):
+            raise NLEError(NLE_ERR_INVALID, f"apply_layers_host: out must be a C-contiguous float32 array of "
+                                            f"{int(n_layers)} x {n_local} values")
         _check(lib().nle_apply_layers_host(self._f, xp, H, W, int(n_layers), _np_ptr(out)), self.ctx._h)
         return out
 

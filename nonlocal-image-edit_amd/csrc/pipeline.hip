@@ -2497,6 +2497,15 @@ static void apply_host_common(nle_filter* f, const float* h_x, int H, int W, con
     }
     int flip = 0;
     const size_t n = (size_t)f->n_local;
+    // whatever happens below (an exception out of apply_impl or of a later callback), no copy may still be reading d_y or
+    // writing the caller's h_y when this function is left: d_y goes back to the ctx's cache in its destructor
+    struct CopyDrain {
+        nle_ctx* c;
+        ~CopyDrain() {
+            if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+            (void)hipStreamSynchronize(c->stream);
+        }
+    } drain{c};
     apply_impl(f, d_x, H, W, g, L, d_y.p, [&](int l0, int nl) {
         hipEvent_t ev = c->copy_ev[flip ^= 1];
         HIP_OK(hipEventRecord(ev, c->stream));

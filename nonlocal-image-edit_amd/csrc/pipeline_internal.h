@@ -328,24 +328,27 @@ struct RcclApi {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 inline RcclApi& rccl() {
-    static RcclApi api;
-    if (!api.lib) {
+    // resolved once, thread-safely (function-local static), and published only when every symbol is there: a failed
+    // attempt throws out of the initialiser and is retried by the next caller
+    static RcclApi api = [] {
+        RcclApi a;
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (api.lib) break;
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
         }
-        if (!api.lib) throw Fail{NLE_ERR_COMM, std::string("cannot load librccl.so: ") + dlerror()};
+        if (!a.lib) throw Fail{NLE_ERR_COMM, std::string("cannot load librccl.so: ") + dlerror()};
         auto sym = [&](const char* n) {
-            void* p = dlsym(api.lib, n);
+            void* p = dlsym(a.lib, n);
             if (!p) throw Fail{NLE_ERR_COMM, std::string("librccl.so lacks ") + n};
             return p;
         };
-        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
-        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
-        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
-        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
-        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
-    }
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+        a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+        return a;
+    }();
     return api;
 }
 #define RCCL_OK(expr)                                                                                           \

@@ -161,6 +161,9 @@ bool inflate_zlib(const std::vector<unsigned char>& z, std::vector<unsigned char
     static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
     static const uint16_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     out->clear();
+    // deflate expands by at most 1032 : 1 (a 258-byte match from a 2-bit code): a header promising more than the stream
+    // can hold is rejected before anything is reserved (a crafted IHDR asked for 34 GB from a 100-byte file)
+    if (expected > z.size() * 1032 + 64) return false;
     out->reserve(expected);
     for (;;) {
         const uint32_t last = br.get(1), type = br.get(2);
@@ -240,7 +243,22 @@ bool inflate_zlib(const std::vector<unsigned char>& z, std::vector<unsigned char
         }
         if (last) break;
     }
-    return out->size() == expected;
+    if (out->size() != expected) return false;
+    // the zlib trailer: Adler-32 of the inflated bytes, big endian, right after the last block (byte aligned)
+    size_t tail = br.pos - (size_t)(br.nbits / 8);  // whole bytes still in the bit buffer were not consumed
+    if (tail + 4 > br.n) return false;
+    uint32_t a = 1, b2 = 0;
+    for (size_t i = 0; i < out->size();) {
+        const size_t stop = std::min(out->size(), i + 5552);  // largest run before the sums can overflow 32 bits
+        for (; i < stop; ++i) {
+            a += (*out)[i];
+            b2 += a;
+        }
+        a %= 65521u;
+        b2 %= 65521u;
+    }
+    const uint32_t want = ((uint32_t)br.p[tail] << 24) | ((uint32_t)br.p[tail + 1] << 16) | ((uint32_t)br.p[tail + 2] << 8) | br.p[tail + 3];
+    return ((b2 << 16) | a) == want;
 }
 
 uint32_t rd32be(const unsigned char* p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }

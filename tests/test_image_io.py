@@ -104,3 +104,37 @@ def test_malformed_headers_are_refused(tool, tmp_path):
         src.write_bytes(data)
         r = subprocess.run([tool, str(src), str(tmp_path / "o.ppm")], capture_output=True, text=True, timeout=60)
         assert r.returncode == 0 and "EMPTY" in r.stdout, (name, r.returncode, r.stderr[-300:])
+
+
+def _png(w, h, idat, depth=8, ctype=2):
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + chunk(b"IDAT", idat) +
+            chunk(b"IEND", b""))
+
+
+def test_png_header_promising_gigabytes_is_refused_without_allocating(tool, tmp_path):
+    """a 16-bit RGBA header of 65535 x 65535 over a few bytes of deflate data must not reserve ~34 GB"""
+    import zlib
+    bad = tmp_path / "huge.png"
+    bad.write_bytes(_png(65535, 65535, zlib.compress(b"\0" * 64), depth=16, ctype=6))
+    env = dict(os.environ, ASAN_OPTIONS="max_allocation_size_mb=1024")   # a 34 GB reserve aborts the sanitised build
+    r = subprocess.run([tool, str(bad), str(tmp_path / "o.ppm")], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 0 and "EMPTY" in r.stdout, (r.returncode, r.stderr[-300:])
+
+
+def test_png_with_a_wrong_adler32_is_refused(tool, tmp_path):
+    import zlib
+    raw = b"".join(b"\0" + bytes([(7 * i + j) & 255 for j in range(3 * 5)]) for i in range(4))   # 5 x 4 RGB, filter 0
+    z = bytearray(zlib.compress(raw))
+    good = tmp_path / "good.png"
+    good.write_bytes(_png(5, 4, bytes(z)))
+    r = subprocess.run([tool, str(good), str(tmp_path / "g.ppm")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "EMPTY" not in r.stdout
+    z[-1] ^= 0x5a
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(_png(5, 4, bytes(z)))
+    r = subprocess.run([tool, str(bad), str(tmp_path / "b.ppm")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "EMPTY" in r.stdout

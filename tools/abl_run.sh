@@ -1,11 +1,10 @@
 #!/bin/bash
-# usage: tools/abl_run.sh V1 V2 ...  -- per-kernel averages of the default bench with lib/abl_<V>.so in place of the library
+# usage: tools/abl_run.sh V1 V2 ...  -- per-kernel averages of the default bench with the measurement build lib/abl_<V>.so
+# loaded through NLE_LIB_PATH (the product library lib/libnle_hip.so is never touched)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 L=$ROOT/nonlocal-image-edit_amd/lib
-cp $L/libnle_hip.so /tmp/libnle_hip.keep
 for v in "$@"; do
-  cp $L/abl_$v.so $L/libnle_hip.so
-  timeout -k 10 120 python $ROOT/bench.py --no-cpu-baseline --no-pipelined --h2h-runs 0 --steps 10 --warmup 3 > /tmp/abl_$v.json 2> /tmp/abl_$v.err
+  NLE_LIB_PATH=$L/abl_$v.so timeout -k 10 120 python $ROOT/bench.py --no-cpu-baseline --no-pipelined --h2h-runs 0 --steps 10 --warmup 3 > /tmp/abl_$v.json 2> /tmp/abl_$v.err
   python - <<PY
 import json
 try:
@@ -14,4 +13,3 @@ except Exception as e:
     print("$v failed", e); print(open("/tmp/abl_$v.err").read()[-300:])
 PY
 done
-cp /tmp/libnle_hip.keep $L/libnle_hip.so

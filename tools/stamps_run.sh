@@ -1,8 +1,6 @@
 #!/bin/bash
-# phase timestamps of k_sorted_pass for two co-resident workgroup pairs (library built with -DNLE_ABL_STAMPS as lib/abl_STAMPS.so)
+# phase timestamps of k_sorted_pass for two co-resident workgroup pairs (library built with -DNLE_ABL_STAMPS as
+# lib/abl_STAMPS.so, loaded through NLE_LIB_PATH: the product library is never touched)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 L=$ROOT/nonlocal-image-edit_amd/lib
-cp $L/libnle_hip.so /tmp/libnle_hip.keep
-cp $L/abl_STAMPS.so $L/libnle_hip.so
-timeout -k 10 120 python $ROOT/bench.py --no-cpu-baseline --no-pipelined --h2h-runs 0 --steps 1 --warmup 1 2>&1 | grep STAMP | tail -64
-cp /tmp/libnle_hip.keep $L/libnle_hip.so
+NLE_LIB_PATH=$L/abl_STAMPS.so timeout -k 10 120 python $ROOT/bench.py --no-cpu-baseline --no-pipelined --h2h-runs 0 --steps 1 --warmup 1 2>&1 | grep STAMP | tail -64
