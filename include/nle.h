@@ -90,6 +90,11 @@ int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
 /*   NLE_MODE_MATERIALISED_F64  the literal decomposition with Phi (N x r) and V (N x K') in fp64: fp64 affinities,
  *                          fp64-MFMA products, any luminance, up to 2048 samples (Phi must fit in device memory) */
 #define NLE_MODE_MATERIALISED_F64 4
+/*   NLE_MODE_STREAMED_F64  fp64 like NLE_MODE_MATERIALISED_F64 but without the N x r matrix: the sample-space algebra of
+ *                          NLE_MODE_PHI_FREE on fp64 affinity rows regenerated chunk by chunk (libm exp) in every pass; the
+ *                          workspace is bounded (NLE_STREAM64_CHUNK_MB, default 2048), V (N x K') is fp64.  Any plane, any
+ *                          grid with <= 2048 samples, any K: what auto mode takes when Phi would not fit the device. */
+#define NLE_MODE_STREAMED_F64 5
 int nle_ctx_set_mode(nle_ctx* ctx, int mode);
 
 /* Slab input (multi-GPU, SURVEY.md section 8e "each GPU uploads / downloads only its slab"): with on != 0 every plane

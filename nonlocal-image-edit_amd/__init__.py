@@ -101,7 +101,7 @@ _SIGNATURES = {
     "nle_bench_sinkhorn_pass": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-MODE_AUTO, MODE_MATERIALISED, MODE_PHI_FREE, MODE_PHI_FREE_EXP, MODE_MATERIALISED_F64 = 0, 1, 2, 3, 4   # NLE_MODE_* of include/nle.h
+MODE_AUTO, MODE_MATERIALISED, MODE_PHI_FREE, MODE_PHI_FREE_EXP, MODE_MATERIALISED_F64, MODE_STREAMED_F64 = 0, 1, 2, 3, 4, 5   # NLE_MODE_* of include/nle.h
 
 _lib = None
 

@@ -29,9 +29,12 @@ __device__ __forceinline__ double recip0_g(double s, double eps) {
 
 // ------------------------------------------------------------------ affinity rows, fp64
 // kab[i][s] = exp(-sw (dr^2 + dc^2) - pw (x_i - y_s)^2), natural pixel order, i in [pix0, pix0 + M); columns >= p zero
+// (skip_samples != 0: the rows of the sample pixels themselves come out as zeros -- the sample-space algebra sums over
+// the non-sample pixels only and treats the samples exactly on its p-sized side)
 __global__ __launch_bounds__(256) void k_affinity64(const float* __restrict__ lum, GridSpec gs,
                                                     const Sample4* __restrict__ samples, int p, int ld, double sw,
-                                                    double pw, long long pix0, long long M, double* __restrict__ kab) {
+                                                    double pw, long long pix0, long long M, double* __restrict__ kab,
+                                                    int skip_samples) {
     const long long total = M * ld;
     for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (long long)gridDim.x * blockDim.x) {
         const long long il = f / ld;
@@ -44,16 +47,28 @@ __global__ __launch_bounds__(256) void k_affinity64(const float* __restrict__ lu
             const long long dr = row - (int)sm.x, dc = col - (int)sm.y;  // integer spatial term (:109)
             const double dv = (double)lum[gi] - (double)sm.z;
             v = exp(-sw * (double)(dr * dr + dc * dc) - pw * (dv * dv));
+            if (skip_samples && is_sample_pixel(gs, row, col)) v = 0.0;
         }
         kab[f] = v;
     }
 }
 
 hipError_t affinity64(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples, int p, int ld, double sw,
-                      double pw, long long pix0, long long M, double* d_kab) {
+                      double pw, long long pix0, long long M, double* d_kab, bool skip_samples) {
     if (M <= 0) return hipSuccess;
     const long long nb = std::min<long long>((M * ld + 255) / 256, 16384);
-    hipLaunchKernelGGL(k_affinity64, dim3((unsigned)nb), dim3(256), 0, s, d_lum, gs, d_samples, p, ld, sw, pw, pix0, M, d_kab);
+    hipLaunchKernelGGL(k_affinity64, dim3((unsigned)nb), dim3(256), 0, s, d_lum, gs, d_samples, p, ld, sw, pw, pix0, M, d_kab,
+                       skip_samples ? 1 : 0);
+    return hipGetLastError();
+}
+
+// y[i] += x[i]
+__global__ void k_add64(double* __restrict__ y, const double* __restrict__ x, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] += x[i];
+}
+hipError_t add64(hipStream_t s, double* d_y, const double* d_x, size_t n) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_add64, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, s, d_y, d_x, n);
     return hipGetLastError();
 }
 

@@ -134,7 +134,8 @@ hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, i
 
 // ---- the literal decomposition in fp64 (generic64.hip): auto mode's fallback and the stage-level API
 hipError_t affinity64(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples, int p, int ld, double sw,
-                      double pw, long long pix0, long long M, double* d_kab);
+                      double pw, long long pix0, long long M, double* d_kab, bool skip_samples = false);
+hipError_t add64(hipStream_t s, double* d_y, const double* d_x, size_t n);  // y += x
 hipError_t row_scalings64(hipStream_t s, const double* d_X, long long M, int ld, int r, const double* d_u, double eps,
                           double* d_out);
 // C (M x ldc) = diag(rs) A (M x lda, width kd) B (kd x nc column-major on the DEVICE); rs may be null

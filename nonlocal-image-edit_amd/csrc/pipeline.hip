@@ -1229,6 +1229,47 @@ void train_generic64(nle_ctx* c, nle_filter* f, const float* d_lum, const Sample
     ms->project = tm_p.ms();
 }
 
+// Operands of the factored Sinkhorn update (fused.hip: k_sink_update_a/b) from what solve_Ka left: X1 (2p x r column-major)
+// and X2 (2p x r row-major) = [B; V_A], lambda.
+void build_update_operands(nle_ctx* c, const Nystrom& ny, int p, DevBuf<double>& d_X1, DevBuf<double>& d_X2,
+                           DevBuf<double>& d_lam) {
+    const int r = ny.r;
+    if (ny.dev) {
+        // Cholesky form with the factors on the device: X1 = [L^-T; 0] (2p x p column-major), X2 = [L^-T; Ka] row-major --
+        // row a of L^-T is column a of L^-1 and Ka is symmetric, so X2 is two plain copies and X1 one transpose
+        const size_t n2 = (size_t)2 * p, pp = (size_t)p * p;
+        d_X1.alloc(n2 * p);
+        d_X2.alloc(n2 * p);
+        d_lam.alloc(p);
+        HIP_OK(hipMemsetAsync(d_X1.p, 0, n2 * p * sizeof(double), c->stream));
+        HIP_OK(nlek::transpose64(c->stream, p, ny.dev->ch.Linv.p, d_X1.p, p, 2 * p));
+        HIP_OK(hipMemcpyAsync(d_X2.p, ny.dev->ch.Linv.p, pp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_X2.p + pp, ny.dev->Ka.p, pp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIP_OK(nlek::fill64(c->stream, d_lam.p, p, 1.0));
+    } else {
+        // X1 (2p x r column-major) and X2 (2p x r row-major) = [B; V_A]; Cholesky form: X1 = [L^-T; 0], the lower
+        // half of X2 = the rows of Ka itself (exact projector / exact V_A diag(lambda) V_A^T, see k_sink_update_b)
+        const size_t n2 = (size_t)2 * p;
+        std::vector<double> X1(n2 * r, 0.0), X2(n2 * r);
+        for (int k = 0; k < r; ++k)
+            for (int a = 0; a < p; ++a) {
+                const double b = ny.B[(size_t)k * p + a];
+                const double va = ny.chol ? ny.Ka[(size_t)k * p + a] : ny.VA[(size_t)k * p + a];  // Ka symmetric
+                X1[(size_t)k * n2 + a] = b;
+                if (!ny.chol) X1[(size_t)k * n2 + p + a] = va;
+                X2[(size_t)a * r + k] = b;
+                X2[(size_t)(p + a) * r + k] = va;
+            }
+        d_X1.alloc(X1.size());
+        d_X2.alloc(X2.size());
+        d_lam.alloc(r);
+        HIP_OK(hipMemcpyAsync(d_X1.p, X1.data(), X1.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_X2.p, X2.data(), X2.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));  // the staging vectors go out of scope (the column-sum pass is done by now)
+    }
+}
+
 // (2) Phi-free: every N-sized pass regenerates its affinity rows (fused.hip)
 // `solve` factors Ka on the host (solve_Ka); it is called only after the first pass -- the column sum, which
 // needs nothing of it -- is on the stream, so the factorisation runs under that pass.
@@ -1328,40 +1369,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     f->r = r;
     f->chol_ka = ny.chol ? 1 : 0;
     f->formulation = hist ? NLE_MODE_PHI_FREE : NLE_MODE_PHI_FREE_EXP;
-    if (ny.dev) {
-        // Cholesky form with the factors on the device: X1 = [L^-T; 0] (2p x p column-major), X2 = [L^-T; Ka] row-major --
-        // row a of L^-T is column a of L^-1 and Ka is symmetric, so X2 is two plain copies and X1 one transpose
-        const size_t n2 = (size_t)2 * p, pp = (size_t)p * p;
-        d_X1.alloc(n2 * p);
-        d_X2.alloc(n2 * p);
-        d_lam.alloc(p);
-        HIP_OK(hipMemsetAsync(d_X1.p, 0, n2 * p * sizeof(double), c->stream));
-        HIP_OK(nlek::transpose64(c->stream, p, ny.dev->ch.Linv.p, d_X1.p, p, 2 * p));
-        HIP_OK(hipMemcpyAsync(d_X2.p, ny.dev->ch.Linv.p, pp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(d_X2.p + pp, ny.dev->Ka.p, pp * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        HIP_OK(nlek::fill64(c->stream, d_lam.p, p, 1.0));
-    } else {
-        // X1 (2p x r column-major) and X2 (2p x r row-major) = [B; V_A]; Cholesky form: X1 = [L^-T; 0], the lower
-        // half of X2 = the rows of Ka itself (exact projector / exact V_A diag(lambda) V_A^T, see k_sink_update_b)
-        const size_t n2 = (size_t)2 * p;
-        std::vector<double> X1(n2 * r, 0.0), X2(n2 * r);
-        for (int k = 0; k < r; ++k)
-            for (int a = 0; a < p; ++a) {
-                const double b = ny.B[(size_t)k * p + a];
-                const double va = ny.chol ? ny.Ka[(size_t)k * p + a] : ny.VA[(size_t)k * p + a];  // Ka symmetric
-                X1[(size_t)k * n2 + a] = b;
-                if (!ny.chol) X1[(size_t)k * n2 + p + a] = va;
-                X2[(size_t)a * r + k] = b;
-                X2[(size_t)(p + a) * r + k] = va;
-            }
-        d_X1.alloc(X1.size());
-        d_X2.alloc(X2.size());
-        d_lam.alloc(r);
-        HIP_OK(hipMemcpyAsync(d_X1.p, X1.data(), X1.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(d_X2.p, X2.data(), X2.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipStreamSynchronize(c->stream));  // the staging vectors go out of scope (the column-sum pass is done by now)
-    }
+    build_update_operands(c, ny, p, d_X1, d_X2, d_lam);
     pass_update(0, nlek::ROWPASS_COLSUM);
     for (int n = 1; n < 2 * T; ++n) {
         pass_pixels(nlek::ROWPASS_RECIP, n == 2 * T - 1 ? d_cbuf.p : nullptr);
@@ -1519,6 +1527,139 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     ms->project = tm_p.ms();
 }
 
+// (3) The same sample-space algebra on fp64 affinity rows (k_affinity64: libm exp of the reference's own argument, :104-112),
+// regenerated CHUNK BY CHUNK in every pass: no N x r matrix, a bounded workspace, any luminance plane, any grid up to 2048
+// samples, any K.  Every N-sized step is a generic64.hip kernel on the chunk (k_i = row i of the chunk):
+//   Sinkhorn half-iteration   y_i = recip(k_i . w), z += k_i y_i                 k_rowpass64 (u := w)
+//   Gram                      Gk += sum c_i^2 k_i k_i^T                          k_gram64d
+//   eigenvectors              V_i = c_i k_i^T D                                  k_tsgemm64      (V: N x K' fp64, as mode 4)
+// and the p-sized side is train_sample_space's (factored update, ortho_ss_device).  Costs a pass 2 x N p 8 bytes of HBM
+// traffic (write + read of the chunk) where the materialised form reads N r 8 once -- the price of not holding it.
+void train_stream64(nle_ctx* c, nle_filter* f, const float* d_lum, const SampleSet& ss, const std::function<Nystrom()>& solve,
+                    double hx, double hy, int T, int n_eig, long long pix0, long long M, StageMs* ms) {
+    const int p = ss.p, ld = ld4(p);
+    const double sw = 1.0 / (hx * hx), pw = 1.0 / (hy * hy);
+    hipStream_t st = c->stream;
+    Trace tr;
+    Timer tm_s(st), tm_g(st), tm_p(st);
+    tm_s.start();
+    size_t budget_mb = 2048;
+    if (const char* e = std::getenv("NLE_STREAM64_CHUNK_MB")) budget_mb = (size_t)std::max(1, std::atoi(e));
+    const long long rows_fit = (long long)((budget_mb << 20) / ((size_t)ld * sizeof(double)));
+    const long long CH = std::max<long long>(256, std::min<long long>(std::max<long long>(M, 1), rows_fit));
+    DevBuf<float4> d_samples(p);
+    HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), p * sizeof(float4), hipMemcpyHostToDevice, st));
+    DevBuf<double> d_K((size_t)CH * ld), d_partial((size_t)nlek::kRowpassMaxBlocks * ld), d_zc(ld), d_z(ld), d_w(ld), d_ones(ld),
+        d_sAh((size_t)2 * T * p), d_X1, d_X2, d_lam, d_uv((size_t)3 * p), d_cbuf((size_t)std::max<long long>(M, 1));
+    HIP_OK(hipMemsetAsync(d_w.p, 0, ld * sizeof(double), st));
+    HIP_OK(nlek::fill64(st, d_ones.p, ld, 1.0));
+    tr.mark("s64: alloc+upload");
+    auto chunk_rows = [&](long long i0) { return std::min<long long>(CH, M - i0); };
+    auto gen = [&](long long i0, long long mc) {
+        PROFILED(c, NLE_K_AFFINITY, nlek::affinity64(st, d_lum, ss.gs, d_samples.p, p, ld, sw, pw, pix0 + i0, mc, d_K.p, true));
+    };
+    auto pass_pixels = [&](int mode, double* cbuf) {
+        HIP_OK(hipMemsetAsync(d_z.p, 0, ld * sizeof(double), st));
+        for (long long i0 = 0; i0 < M; i0 += CH) {
+            const long long mc = chunk_rows(i0);
+            gen(i0, mc);
+            int nb = 0;
+            PROFILED(c, NLE_K_SINKHORN_PASS, nlek::rowpass64(st, mode, d_K.p, mc, ld, d_w.p, d_ones.p, nullptr, NLE_EPS, d_partial.p, &nb));
+            PROFILED(c, NLE_K_REDUCE, nlek::reduce_partials(st, d_partial.p, nb, ld, d_zc.p));
+            HIP_OK(nlek::add64(st, d_z.p, d_zc.p, ld));
+            if (cbuf) PROFILED(c, NLE_K_SMALL, nlek::row_scalings64(st, d_K.p, mc, ld, p, d_w.p, NLE_EPS, cbuf + i0));
+        }
+    };
+    int r = 0;
+    bool chol = false;
+    auto pass_update = [&](int n, int mode) {
+        all_reduce(c, d_z.p, (size_t)ld);
+        PROFILED(c, NLE_K_SMALL, nlek::sink_update(st, mode, p, r, chol, d_X1.p, d_X2.p, d_lam.p, d_z.p, 1, ld,
+                                                   n > 0 ? d_sAh.p + (size_t)(n - 1) * p : nullptr, NLE_EPS, d_uv.p, d_uv.p + 2 * p,
+                                                   d_sAh.p + (size_t)n * p, d_w.p));
+    };
+    pass_pixels(nlek::ROWPASS_COLSUM, nullptr);
+    const Nystrom ny = solve();
+    r = ny.r;
+    chol = ny.chol;
+    f->r = r;
+    f->chol_ka = ny.chol ? 1 : 0;
+    f->formulation = NLE_MODE_STREAMED_F64;
+    build_update_operands(c, ny, p, d_X1, d_X2, d_lam);
+    pass_update(0, nlek::ROWPASS_COLSUM);
+    for (int n = 1; n < 2 * T; ++n) {
+        pass_pixels(nlek::ROWPASS_RECIP, n == 2 * T - 1 ? d_cbuf.p : nullptr);
+        pass_update(n, nlek::ROWPASS_RECIP);
+    }
+    std::vector<double> sA_c(p), sA_r(p);
+    HIP_OK(hipMemcpyAsync(sA_c.data(), d_sAh.p + (size_t)(2 * T - 2) * p, p * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(sA_r.data(), d_sAh.p + (size_t)(2 * T - 1) * p, p * sizeof(double), hipMemcpyDeviceToHost, st));
+    tm_s.stop();
+    HIP_OK(hipStreamSynchronize(st));
+    tr.mark("s64: sinkhorn");
+    // Gram: Gk = sum over the non-sample pixels of c_i^2 k_i k_i^T, chunk by chunk
+    tm_g.start();
+    const size_t pp = (size_t)p * p;
+    DevBuf<double> d_G(pp), d_Gc(pp), d_gpart(std::max<size_t>(nlek::gram64d_partial_elems(CH, p), 1));
+    auto enqueue_gram = [&] {
+        HIP_OK(hipMemsetAsync(d_G.p, 0, pp * sizeof(double), st));
+        for (long long i0 = 0; i0 < M; i0 += CH) {
+            const long long mc = chunk_rows(i0);
+            gen(i0, mc);
+            PROFILED(c, NLE_K_GRAM, nlek::gram64d(st, d_K.p, mc, ld, p, d_cbuf.p + i0, d_gpart.p, d_Gc.p));
+            HIP_OK(nlek::add64(st, d_G.p, d_Gc.p, pp));
+        }
+    };
+    OrthoSS o;
+    ortho_ss_device(c, o, ny, p, sA_c, sA_r, d_G.p, n_eig, enqueue_gram, [&] { all_reduce(c, d_G.p, pp); }, &ms->host,
+                    &ms->host_overlapped, tr);
+    tm_g.stop();
+    f->K = o.K;
+    f->ldv = ld4(o.K);
+    f->eigvals = o.Sq;
+    f->r_wa = o.r_wa;
+    f->r_q = o.r_q;
+    f->chol_wa = o.chol_wa ? 1 : 0;
+    // V = diag(c) K D (the Nystrom extension of the K' kept eigenvectors, :324-327) + the exact sample rows
+    tm_p.start();
+    DevBuf<double> d_D((size_t)p * o.K), d_V((size_t)std::max<long long>(M, 1) * f->ldv);
+    HIP_OK(hipMemcpyAsync(d_D.p, o.D.data(), o.D.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(d_V.p, 0, d_V.n * sizeof(double), st));
+    for (long long i0 = 0; i0 < M; i0 += CH) {
+        const long long mc = chunk_rows(i0);
+        gen(i0, mc);
+        PROFILED(c, NLE_K_PROJECT, nlek::ts_gemm64(st, d_K.p, mc, ld, p, d_D.p, o.K, d_cbuf.p + i0, d_V.p + (size_t)i0 * f->ldv, f->ldv));
+    }
+    {
+        std::vector<double> rows;
+        std::vector<long long> idx;
+        for (int a = 0; a < p; ++a) {
+            const long long loc = ss.pix[a] - pix0;
+            if (loc < 0 || loc >= M) continue;
+            idx.push_back(loc);
+            const size_t off = rows.size();
+            rows.resize(off + f->ldv, 0.0);
+            for (int k = 0; k < o.K; ++k) rows[off + k] = o.Vrows[(size_t)k * p + a];
+        }
+        if (!idx.empty()) {
+            DevBuf<double> d_rows(rows.size());
+            DevBuf<long long> d_idx(idx.size());
+            HIP_OK(hipMemcpyAsync(d_rows.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_OK(hipMemcpyAsync(d_idx.p, idx.data(), idx.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+            PROFILED(c, NLE_K_SMALL, nlek::scatter_rows64(st, d_rows.p, d_idx.p, (int)idx.size(), f->ldv, d_V.p, M));
+            HIP_OK(hipStreamSynchronize(st));
+        }
+    }
+    tm_p.stop();
+    HIP_OK(hipStreamSynchronize(st));
+    tr.mark("s64: project");
+    f->v64_bytes = d_V.n * sizeof(double);
+    f->d_V64 = d_V.take();
+    ms->sinkhorn = tm_s.ms();
+    ms->gram = tm_g.ms();
+    ms->project = tm_p.ms();
+}
+
 // materialise V = diag(c) K D of a lazy filter (projection kernel + exact sample rows)
 void ensure_V(nle_filter* f) {
     if (f->d_V) return;
@@ -1669,8 +1810,19 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum_in, int H, int W, int nRow
             return ny;
         };
         tm_a.stop();
+        // auto mode's fp64 fallback holds Phi (N x r doubles) when that fits comfortably (a pass reads it once); otherwise
+        // -- and when asked for -- the streamed form, which holds nothing N x r (ranks decide alike: slabs are equal)
+        bool stream64 = c->mode == NLE_MODE_STREAMED_F64;
+        if (!fuse && c->mode == NLE_MODE_AUTO) {
+            size_t free_b = 0, total_b = 0;
+            const size_t need = (size_t)std::max<long long>(M, 1) * ld4(ss.p) * sizeof(double);
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (free_b + c->arena_bytes) / 2) stream64 = true;
+            if (std::getenv("NLE_AUTO_STREAM64")) stream64 = true;
+        }
         if (fuse) {
             train_sample_space(c, f, d_lum, ss, [&] { return solve(true); }, hx, hy, T, n_eig, pix0, M, &sm);
+        } else if (stream64) {
+            train_stream64(c, f, d_lum, ss, [&] { return solve(true); }, hx, hy, T, n_eig, pix0, M, &sm);
         } else {
             const Nystrom ny = solve(false);
             f->r = ny.r;
@@ -2026,7 +2178,7 @@ int nle_ctx_set_topk_solver(nle_ctx* ctx, int solver) {
 }
 
 int nle_ctx_set_mode(nle_ctx* ctx, int mode) {
-    if (!ctx || mode < 0 || mode > NLE_MODE_MATERIALISED_F64) return NLE_ERR_INVALID;
+    if (!ctx || mode < 0 || mode > NLE_MODE_STREAMED_F64) return NLE_ERR_INVALID;
     ctx->mode = mode;
     return NLE_OK;
 }

@@ -151,10 +151,10 @@ def _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L):
     return f, Y
 
 
-FP64_MODES = (2, 4)   # what auto mode resolves to: bar asserted without slack
+FP64_MODES = (2, 4, 5)   # what auto mode resolves to: bar asserted without slack
 
 
-@pytest.fixture(params=[2, 4, 1, 3], ids=["tables_f64", "materialised_f64", "materialised_f32", "phi_free_exp_f32"])
+@pytest.fixture(params=[2, 4, 5, 1, 3], ids=["tables_f64", "materialised_f64", "streamed_f64", "materialised_f32", "phi_free_exp_f32"])
 def mode(request, ctx):
     """run the test under every formulation of the N-sized passes (NLE_MODE_* in include/nle.h)"""
     ctx.set_mode(request.param)
@@ -457,6 +457,47 @@ def test_auto_mode_falls_back_to_the_fp64_decomposition(nle, oracle, ctx, kind):
     V = f.eigvecs().cpu().numpy()[:, :S_o.size].astype(np.float64)
     assert rel_l2(_align_signs(V, V_o), V_o) < 1e-6
     f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["non-integer", "wide grid", "many eigenvectors"])
+def test_streamed_fp64_form_takes_what_does_not_fit(nle, oracle, ctx, kind):
+    """NLE_MODE_STREAMED_F64: the fp64 fallback WITHOUT the N x r matrix (affinity rows regenerated chunk by chunk, bounded
+    workspace) -- what auto mode takes when Phi would not fit the device instead of refusing.  Same three kinds of input
+    as above, forced into it through NLE_AUTO_STREAM64 with a chunk budget of 1 MB so that a pass walks several chunks;
+    it must meet the same bar and agree with the materialised fp64 form."""
+    rng = np.random.default_rng(11)
+    if kind == "non-integer":
+        H, W, nr, nc, hx, hy, T, K, L = 60, 80, 5, 6, 6.0, 25.0, 6, 12, 4
+        x = oracle.synthetic_luminance(H, W) + rng.random((H, W)) * 0.75
+    elif kind == "wide grid":
+        H, W, nr, nc, hx, hy, T, K, L = 40, 200, 3, 40, 30.0, 30.0, 5, 10, 3
+        x = oracle.synthetic_luminance(H, W)
+    else:
+        H, W, nr, nc, hx, hy, T, K, L = 64, 64, 12, 12, 12.0, 30.0, 5, 140, 3
+        x = oracle.synthetic_luminance(H, W)
+    x = x.astype(np.float32).astype(np.float64)
+    V_o, S_o = oracle.train_filter(x, nr, nc, hx, hy, T, K)
+    Y_o = oracle.apply_layers(V_o, S_o, x, L).reshape(L, -1)
+    f4, Y4 = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
+    assert f4.diag()["formulation"] == nle.MODE_MATERIALISED_F64
+    os.environ["NLE_AUTO_STREAM64"] = "1"
+    os.environ["NLE_STREAM64_CHUNK_MB"] = "1"
+    try:
+        f, Y = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
+    finally:
+        del os.environ["NLE_AUTO_STREAM64"], os.environ["NLE_STREAM64_CHUNK_MB"]
+    d = f.diag()
+    assert d["formulation"] == nle.MODE_STREAMED_F64 and d["K"] == S_o.size
+    assert d["r_Ka"] == f4.diag()["r_Ka"] and d["r_Wa"] == f4.diag()["r_Wa"] and d["r_Q"] == f4.diag()["r_Q"]
+    assert rel_l2(f.eigvals, S_o) < 1e-9
+    errs = [rel_l2(Y[j], Y_o[j]) for j in range(L)]
+    print(kind, "streamed per-layer", ["%.1e" % e for e in errs])
+    assert max(errs) < 1e-6
+    for j in range(L):
+        assert rel_l2(Y[j], Y4[j]) < 1e-6
+    f.close()
+    f4.close()
 
 
 @pytest.mark.gpu
