@@ -96,6 +96,10 @@ int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
  *                          grid with <= 2048 samples, any K: what auto mode takes when Phi would not fit the device. */
 #define NLE_MODE_STREAMED_F64 5
 int nle_ctx_set_mode(nle_ctx* ctx, int mode);
+/* The Nystrom-extension GEMM Phi = K_AB^T (V_A Lambda^-1) (src/filter.cpp:275) of NLE_MODE_MATERIALISED and of nle_nystrom on
+ * the bf16 matrix cores with SPLIT operands (each fp32 value as three bf16, six products, fp32 accumulate: fp32 accuracy at
+ * ~2.7x the exact-fp32 MFMA's rate; plain bf16 operands miss the parity bar).  Off by default. */
+int nle_ctx_set_nystrom_bf16x3(nle_ctx* ctx, int on);
 
 /* Slab input (multi-GPU, SURVEY.md section 8e "each GPU uploads / downloads only its slab"): with on != 0 every plane
  * handed to nle_train*, nle_apply* on this ctx holds ONLY the rows [row0, row1) of this rank (nle_slab_rows), n_local

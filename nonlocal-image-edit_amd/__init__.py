@@ -46,6 +46,7 @@ _SIGNATURES = {
     "nle_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "nle_dev_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "nle_ctx_set_mode": (C.c_int, [_P, C.c_int]),
+    "nle_ctx_set_nystrom_bf16x3": (C.c_int, [_P, C.c_int]),
     "nle_ctx_set_shard": (C.c_int, [_P, C.c_int, C.c_int, ALLREDUCE_FN, _P, _P, C.c_size_t]),
     "nle_comm_len": (C.c_size_t, [C.c_int]),
     "nle_sample_grid": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int)] * 6),
@@ -321,6 +322,10 @@ class Context:
     def set_mode(self, mode: int):
         """0 auto, 1 materialised Phi, 2 Phi-free (NLE_MODE_* in include/nle.h)."""
         _check(lib().nle_ctx_set_mode(self._h, int(mode)), self._h)
+
+    def set_nystrom_bf16x3(self, on: bool = True):
+        """the fused Nystrom GEMM on the bf16 matrix cores with split operands (nle_ctx_set_nystrom_bf16x3)"""
+        _check(lib().nle_ctx_set_nystrom_bf16x3(self._h, 1 if on else 0), self._h)
 
     def host_alloc(self, shape, dtype=np.float32):
         """page-locked host array (nle_host_alloc).  The block belongs to the ctx and is freed by Context.close(): the

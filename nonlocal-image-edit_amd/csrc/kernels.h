@@ -66,6 +66,14 @@ hipError_t ts_gemm(hipStream_t s, bool fused, const float* d_A, int lda, const f
                    const float* d_B, int ldb, int kd, float* d_C, int ldc, long long M,
                    const double* d_u, double eps, const float* d_c = nullptr);
 
+// The fused form on the bf16 matrix cores with split operands (tsgemm_bf16x3.hip: hi + mid + lo, six products, fp32
+// accumulate): d_Bs = ts_gemm_bf16x3_split of the kd x ldb fp32 matrix B (ts_gemm_bf16x3_bsplit_elems shorts)
+size_t ts_gemm_bf16x3_bsplit_elems(int kd, int ldb);
+hipError_t ts_gemm_bf16x3_split(hipStream_t s, const float* d_B, int kd, int ldb, unsigned short* d_Bs);
+hipError_t ts_gemm_bf16x3(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples, float nsw, float npw,
+                          long long pix0, const unsigned short* d_Bs, int ldb, int kd, float* d_C, int ldc, long long M,
+                          const float* d_c = nullptr);
+
 // One pass over X (M x ld): partial[b][j] = sum_{rows of block b} X[i][j] * y_i,
 //   mode COLSUM: y=1; RECIP: y_i = recip(X_i . (lam o t_in)); XVEC: y_i = xvec[i].
 // Returns the number of blocks used in *nblocks.

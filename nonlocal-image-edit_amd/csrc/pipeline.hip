@@ -195,8 +195,16 @@ void build_phi(nle_ctx* c, const float* d_lum, const SampleSet& ss, const Nystro
     DevBuf<float> d_B(B.size());
     HIP_OK(hipMemcpyAsync(d_B.p, B.data(), B.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     const float sw = nsw_of(hx), pw = nsw_of(hy);
-    PROFILED(c, NLE_K_NYSTROM, nlek::ts_gemm(c->stream, true, nullptr, 0, d_lum, ss.gs, d_samples.p, sw, pw, pix0,
-                                             d_B.p, ny.ldr, p, d_phi, ny.ldr, M, nullptr, NLE_EPS));
+    static const bool env3 = std::getenv("NLE_NYSTROM_BF16X3") != nullptr;
+    if (c->nystrom_bf16x3 || env3) {  // split-bf16 operands on the bf16 matrix cores (tsgemm_bf16x3.hip)
+        DevBuf<unsigned short> d_Bs(nlek::ts_gemm_bf16x3_bsplit_elems(p, ny.ldr));
+        HIP_OK(nlek::ts_gemm_bf16x3_split(c->stream, d_B.p, p, ny.ldr, d_Bs.p));
+        PROFILED(c, NLE_K_NYSTROM, nlek::ts_gemm_bf16x3(c->stream, d_lum, ss.gs, d_samples.p, sw, pw, pix0, d_Bs.p, ny.ldr, p,
+                                                        d_phi, ny.ldr, M));
+    } else {
+        PROFILED(c, NLE_K_NYSTROM, nlek::ts_gemm(c->stream, true, nullptr, 0, d_lum, ss.gs, d_samples.p, sw, pw, pix0,
+                                                 d_B.p, ny.ldr, p, d_phi, ny.ldr, M, nullptr, NLE_EPS));
+    }
     // sample pixels carry their exact V_A row (top block of phi, reference :275)
     std::vector<float> rows;
     std::vector<long long> idx;
@@ -2174,6 +2182,12 @@ int nle_ctx_set_slab_input(nle_ctx* ctx, int on) {
 int nle_ctx_set_topk_solver(nle_ctx* ctx, int solver) {
     if (!ctx || solver < 0 || solver > 1) return NLE_ERR_INVALID;
     ctx->topk_solver = solver;
+    return NLE_OK;
+}
+
+int nle_ctx_set_nystrom_bf16x3(nle_ctx* ctx, int on) {
+    if (!ctx) return NLE_ERR_INVALID;
+    ctx->nystrom_bf16x3 = on != 0;
     return NLE_OK;
 }
 

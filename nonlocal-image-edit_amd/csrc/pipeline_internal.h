@@ -57,6 +57,7 @@ struct nle_ctx {
     hipEvent_t copy_ev[2] = {nullptr, nullptr};
     int mode = 0;  // nle_ctx_set_mode: 0 auto, 1 materialised Phi, 2 Phi-free, 3 Phi-free without look-up tables
     bool slab_input = false;  // nle_ctx_set_slab_input: planes handed in hold this rank's rows only
+    bool nystrom_bf16x3 = false;  // nle_ctx_set_nystrom_bf16x3: the fused Nystrom GEMM on the bf16 MFMA with split operands
     int topk_solver = 0;  // nle_ctx_set_topk_solver: 0 full eigensolve of Q (:313-316), 1 Lanczos top-K (:170-199)
     bool profiling = false;
     bool profile_all = false;  // level 2: also the small / second-stage kernels (each timed launch costs ~10 us of gaps)
