@@ -405,50 +405,71 @@ constexpr int kChB = 32;  // panel width
 // `diag` (32 x 32 column-major per panel) and is put in place by k_potrf_finish; workgroup b solves rows j0 + nb + 256 b + tid
 // of the panel (one row per thread); workgroup 0 also writes the block's inverse into Linv.  status |= 2 on a
 // non-positive pivot (the factor is then meaningless; the pivot is replaced by 1 so that nothing overflows).
+__device__ __forceinline__ double bcast_lane(double v, int src) {  // v of lane `src` (a compile-time constant) to every lane
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void k_potrf_panel(int n, int j0, double* __restrict__ A, double* __restrict__ diag,
                                                      double* __restrict__ Linv, int* status) {
     __shared__ double sL[kChB][kChB + 1];
-    __shared__ double sX[kChB][kChB + 1];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int nb = min(kChB, n - j0);
-    for (int t = tid; t < kChB * kChB; t += 256) {
-        const int r = t % kChB, c = t / kChB;
-        sL[r][c] = (r < nb && c < nb && r >= c) ? A[(size_t)(j0 + c) * n + j0 + r] : 0.0;
+    if (tid < 64) {
+        // wave 0: lane r holds row r of the diagonal block in registers (rows >= nb: identity); right-looking
+        // factorisation with every exchange a lane broadcast -- no LDS round trips, no barriers
+        const int r = lane & 31;
+        double a[kChB];
+#pragma unroll
+        for (int c = 0; c < kChB; ++c) {
+            double v = (r == c) ? 1.0 : 0.0;
+            if (r < nb && c < nb && r >= c) v = A[(size_t)(j0 + c) * n + j0 + r];
+            a[c] = v;
+        }
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < kChB; ++c) {
+            double d = bcast_lane(a[c], c);
+            if (!(d > 0.0)) {
+                bad = true;
+                d = 1.0;
+            }
+            const double piv = sqrt(d), rp = 1.0 / piv;
+            a[c] = (r == c) ? piv : a[c] * rp;
+#pragma unroll
+            for (int j = c + 1; j < kChB; ++j) {
+                const double ljc = bcast_lane(a[c], j);
+                a[j] -= a[c] * ljc;  // meaningful for r >= j
+            }
+        }
+        if (lane < 32) {
+#pragma unroll
+            for (int c = 0; c < kChB; ++c) sL[r][c] = (c <= r) ? a[c] : 0.0;
+        }
+        if (blockIdx.x == 0) {
+            if (bad && lane == 0) atomicOr(status, 2);
+            double* dg = diag + (size_t)(j0 / kChB) * kChB * kChB;
+            if (lane < 32) {
+#pragma unroll
+                for (int c = 0; c < kChB; ++c) dg[(size_t)c * kChB + r] = (c <= r && r < nb) ? a[c] : 0.0;
+            }
+            // column `r` of the block's inverse: x_i = (delta_ir - sum_{k < i} L(i,k) x_k) / L(i,i); x_k = 0 for k < r
+            double x[kChB];
+#pragma unroll
+            for (int i = 0; i < kChB; ++i) {
+                double acc = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) acc -= bcast_lane(a[k], i) * x[k];
+                x[i] = acc / bcast_lane(a[i], i);
+            }
+            if (lane < nb) {
+#pragma unroll
+                for (int i = 0; i < kChB; ++i)
+                    if (i < nb) Linv[(size_t)(j0 + r) * n + j0 + i] = x[i];
+            }
+        }
     }
     __syncthreads();
-    for (int c = 0; c < nb; ++c) {
-        double dcc = sL[c][c];
-        __syncthreads();
-        if (!(dcc > 0.0)) {
-            if (tid == 0 && blockIdx.x == 0) atomicOr(status, 2);
-            dcc = 1.0;
-        }
-        const double piv = sqrt(dcc), rp = 1.0 / piv;
-        if (tid < nb && tid >= c) sL[tid][c] = (tid == c) ? piv : sL[tid][c] * rp;
-        __syncthreads();
-        // trailing block of the diagonal block: (r, cc) with cc > c, r >= cc
-        for (int t = tid; t < kChB * kChB; t += 256) {
-            const int r = t % kChB, cc = t / kChB;
-            if (cc > c && r >= cc && r < nb) sL[r][cc] -= sL[r][c] * sL[cc][c];
-        }
-        __syncthreads();
-    }
-    if (blockIdx.x == 0) {
-        double* dg = diag + (size_t)(j0 / kChB) * kChB * kChB;
-        for (int t = tid; t < kChB * kChB; t += 256) {
-            const int r = t % kChB, c = t / kChB;
-            dg[t] = (r < nb && c < nb && r >= c) ? sL[r][c] : 0.0;
-        }
-        if (tid < nb) {  // column tid of the block's inverse by forward substitution
-            const int c = tid;
-            for (int i = 0; i < nb; ++i) {
-                double acc = (i == c) ? 1.0 : 0.0;
-                for (int k = c; k < i; ++k) acc -= sL[i][k] * sX[k][c];
-                sX[i][c] = i >= c ? acc / sL[i][i] : 0.0;
-            }
-            for (int i = 0; i < nb; ++i) Linv[(size_t)(j0 + c) * n + j0 + i] = sX[i][c];
-        }
-    }
     const int row = j0 + nb + blockIdx.x * 256 + tid;
     if (row < n) {  // x L11^T = a
         double x[kChB];
@@ -485,18 +506,63 @@ __global__ void k_potrf_finish(double* __restrict__ A, int n, const double* __re
 __global__ void k_fill64(double* p, size_t n, double v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
-// out[0] = sum of squares of n doubles (one workgroup: n <= 1152^2, a few microseconds)
-__global__ __launch_bounds__(1024) void k_sumsq(const double* __restrict__ x, size_t n, double* out) {
-    __shared__ double sred[16];
+// sum of squares of n doubles: 128 workgroup partials, then one wave adds them in a fixed order
+__global__ __launch_bounds__(256) void k_sumsq_part(const double* __restrict__ x, size_t n, double* __restrict__ part) {
+    __shared__ double sred[4];
     double acc = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += 1024) acc += x[i] * x[i];
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += x[i] * x[i];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < 16; ++w) t += sred[w];
-        out[0] = t;
+    if (threadIdx.x == 0) part[blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+__global__ void k_sum128(const double* __restrict__ part, double* out) {
+    double v = part[threadIdx.x] + part[threadIdx.x + 64];
+    v = wave_sum(v);
+    if (threadIdx.x == 0) out[0] = v;
+}
+
+// One level of the inverse of a lower-triangular matrix by doubling: with the diagonal blocks of size s already inverted
+// (X11, X22 in place in X), pair b = blockIdx.y gets X21 = -X22 L21 X11 in two phases
+//   phase 0: T_b (m x s) = L21 X11        phase 1: X21 = -X22 T_b        (rows row0 = 2 b s + s .. , m = min(s, n - row0))
+// one wave per 16 x 16 output tile on v_mfma_f64_16x16x4_f64, operands straight from L2 (the matrices are a few MB).
+__global__ __launch_bounds__(256) void k_trtri_level(int phase, int n, int s, const double* __restrict__ L,
+                                                     double* __restrict__ X, double* __restrict__ T) {
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.y, col0 = 2 * b * s, row0 = col0 + s;
+    const int m = min(s, n - row0);
+    if (m <= 0) return;
+    const int rt = (m + 15) / 16, ct = s / 16;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= rt * ct) return;  // wave-uniform
+    const int ti = t / ct, tj = t - ti * ct;
+    const int ai = ti * 16 + l15, bj = tj * 16 + l15;
+    const bool aok = ai < m;
+    double* Tb = T + (size_t)b * s * s;  // m x s, column-major, leading dimension s
+    const int kk = phase == 0 ? s : m;
+    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < kk; k0 += 4) {
+        const int k = k0 + kq;
+        double av = 0.0, bv = 0.0;
+        if (k < kk) {
+            if (phase == 0) {
+                if (aok) av = L[(size_t)(col0 + k) * n + row0 + ai];   // L21(ai, k)
+                bv = X[(size_t)(col0 + bj) * n + col0 + k];            // X11(k, bj)
+            } else {
+                if (aok) av = X[(size_t)(row0 + k) * n + row0 + ai];   // X22(ai, k)
+                bv = Tb[(size_t)bj * s + k];                           // T(k, bj)
+            }
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ro = ti * 16 + kq + 4 * e;
+        if (ro < m) {
+            if (phase == 0) Tb[(size_t)bj * s + ro] = acc[e];
+            else X[(size_t)(col0 + bj) * n + row0 + ro] = -acc[e];
+        }
     }
 }
 
@@ -534,13 +600,25 @@ hipError_t fill64(hipStream_t s, double* d_p, size_t n, double v) {
 // d_A (n x n column-major, lower triangle read) -> d_L = its Cholesky factor (lower, zeros above the diagonal), d_Linv =
 // L^-1 (likewise), d_scal[0] = trace(A^-1) = ||L^-1||_F^2; *d_status |= 2 if A is not positive definite.  d_A is left
 // untouched; d_tmp: n x 32 doubles of scratch; d_minus: 32 doubles (filled here with -1).
-size_t potrf_tmp_elems(int n) { return (size_t)2 * kChB * ((size_t)n + kChB) + 2 * kChB; }
+// scratch of potrf_inverse: the doubling levels' T blocks (pairs x s x s at level s), the factored diagonal blocks,
+// 32 x (-1), 128 partial sums
+static size_t trtri_T_elems(int n) {
+    size_t mx = 1;
+    for (long long sz = kChB; sz < n; sz *= 2) {
+        const size_t pairs = (size_t)((n + 2 * sz - 1) / (2 * sz));
+        mx = std::max(mx, pairs * (size_t)sz * (size_t)sz);
+    }
+    return mx;
+}
+size_t potrf_tmp_elems(int n) { return trtri_T_elems(n) + (size_t)kChB * ((size_t)n + kChB) + kChB + 128; }
 
 hipError_t potrf_inverse(hipStream_t s, int n, const double* d_A, double* d_L, double* d_Linv, double* d_tmp, double* d_scal,
                          int* d_status) {
     if (n < 1) return hipErrorInvalidValue;
-    double* d_diag = d_tmp + (size_t)kChB * n;                  // one 32 x 32 block per panel
+    double* d_T = d_tmp;                                        // pairs x s x s at level s
+    double* d_diag = d_tmp + trtri_T_elems(n);                  // one 32 x 32 block per panel
     double* d_minus = d_diag + (size_t)kChB * (n + kChB);       // 32 x (-1)
+    double* d_part = d_minus + kChB;                            // 128 partial sums
     hipError_t e = hipMemcpyAsync(d_L, d_A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(d_Linv, 0, (size_t)n * n * sizeof(double), s);
@@ -553,20 +631,22 @@ hipError_t potrf_inverse(hipStream_t s, int n, const double* d_A, double* d_L, d
         if (below > 0) {  // A22 -= L21 L21^T (both triangles; only the lower one is read later)
             double* a22 = d_L + (size_t)(j0 + nb) * n + j0 + nb;
             const double* l21 = d_L + (size_t)j0 * n + j0 + nb;
-            e = gemm64s(s, below, below, nb, l21, 1, n, l21, n, 1, a22, 1, n, nullptr, d_minus, nullptr, a22, 1, n);
+            // (the update is symmetric: written through the transposed strides, so that the 16 lanes of a tile column store
+            // to consecutive addresses instead of 16 different columns)
+            e = gemm64s(s, below, below, nb, l21, 1, n, l21, n, 1, a22, n, 1, nullptr, d_minus, nullptr, a22, n, 1);
             if (e != hipSuccess) return e;
         }
     }
     hipLaunchKernelGGL(k_potrf_finish, dim3(256), dim3(256), 0, s, d_L, n, d_diag);
-    // L^-1 by block rows: X[i, 0:i) = -X_ii (L[i, 0:i) X[0:i, 0:i))
-    for (int j0 = kChB; j0 < n; j0 += kChB) {
-        const int nb = std::min(kChB, n - j0);
-        e = gemm64s(s, nb, j0, j0, d_L + j0, 1, n, d_Linv, 1, n, d_tmp, 1, nb);
-        if (e != hipSuccess) return e;
-        e = gemm64s(s, nb, j0, nb, d_Linv + (size_t)j0 * n + j0, 1, n, d_tmp, 1, nb, d_Linv + j0, 1, n, nullptr, d_minus);
-        if (e != hipSuccess) return e;
+    // L^-1 by doubling: the 32 x 32 diagonal blocks are inverted (k_potrf_panel); level s joins pairs of s x s blocks
+    for (int sz = kChB; sz < n; sz *= 2) {
+        const int pairs = (n + 2 * sz - 1) / (2 * sz);
+        const dim3 grid((unsigned)(((sz / 16) * (sz / 16) + 3) / 4), (unsigned)pairs);
+        hipLaunchKernelGGL(k_trtri_level, grid, dim3(256), 0, s, 0, n, sz, d_L, d_Linv, d_T);
+        hipLaunchKernelGGL(k_trtri_level, grid, dim3(256), 0, s, 1, n, sz, d_L, d_Linv, d_T);
     }
-    hipLaunchKernelGGL(k_sumsq, dim3(1), dim3(1024), 0, s, d_Linv, (size_t)n * n, d_scal);
+    hipLaunchKernelGGL(k_sumsq_part, dim3(128), dim3(256), 0, s, d_Linv, (size_t)n * n, d_part);
+    hipLaunchKernelGGL(k_sum128, dim3(1), dim3(64), 0, s, d_part, d_scal);
     return hipGetLastError();
 }
 
