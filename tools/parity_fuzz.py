@@ -23,8 +23,8 @@ def main():
     rng = np.random.default_rng(seed)
     nle, oracle = entry.load_package(), entry.load_oracle()
     ctx = nle.Context(0)
-    MODES = (0, 2, 4, 1, 3)     # auto, tables (fp64), literal decomposition in fp64; the two opt-in fp32 forms
-    FP64 = (0, 2, 4)
+    MODES = (0, 2, 4, 5, 1, 3)  # auto, tables (fp64), literal decomposition in fp64, streamed fp64; the two opt-in fp32 forms
+    FP64 = (0, 2, 4, 5)
     worst = {m: 0.0 for m in MODES}
     skipped = {m: 0 for m in MODES}
     bad = {m: 0 for m in MODES}
@@ -155,7 +155,7 @@ def main():
                              params=np.array([nr, nc, hx, hy, T, K, L, mode], dtype=np.float64))
                 print("FAIL mode", mode, (H, W, nr, nc, round(hx, 2), round(hy, 2), T, K, L), "kind", int(kind), "p", p, "r", r,
                       "lam_min %.2e" % lam[-1], "amp %.1e" % amp, "solver_sens %.1e" % solver_sens, "layers", ["%.1e" % e for e in errs], "eig %.1e" % ev, flush=True)
-    names = {0: "auto", 2: "tables_f64", 4: "materialised_f64", 1: "materialised_f32 (opt-in)", 3: "phi_free_exp_f32 (opt-in)"}
+    names = {0: "auto", 2: "tables_f64", 4: "materialised_f64", 5: "streamed_f64", 1: "materialised_f32 (opt-in)", 3: "phi_free_exp_f32 (opt-in)"}
     print(f"{done} cases ({borderline['cases']} with a borderline rank cut); per formulation: asserted / failures / worst per-layer error")
     for m in MODES:
         print(f"  {names[m]:28s} {done - skipped[m]:4d} / {bad[m]:3d} / {worst[m]:.2e}")
