@@ -449,6 +449,8 @@ def main():
     # ---- roofline of the dominant kernel (this rank's launches)
     ran = {k for k, v in stats.items() if v[0] > 0}
     form = "materialised" if "nystrom_extend" in ran else ("phi_free_tables" if "gram_gemm" in ran else "phi_free_exp")
+    form_label = {1: "materialised_f32", 2: "phi_free_tables", 3: "phi_free_exp_f32", 4: "materialised_f64",
+                  5: "streamed_f64 (no N x r matrix: fp64 affinity rows regenerated chunk by chunk)"}.get(flt.diag()["formulation"], form)
     lazy = form == "phi_free_tables" and "project" not in ran
     models = roofline_models(info, L, form, g, lazy)
     # (the committed PMC summary was collected at N = 1 on the default config: per-launch bytes of a row slab or of
@@ -557,8 +559,10 @@ def main():
                                        f"TIMING ONLY: rank 0 of a simulated {args.simulate_world}-way row shard, no-op all-reduce"
                                        if args.simulate_world > 1 else "single GPU")
                        + (f", {args.inflight} images in flight" if args.inflight > 1 else ""),
-                       "formulation": form + (" (V implicit, apply in sample space)" if lazy else ""),
+                       "formulation": form_label + (" (V implicit, apply in sample space)" if lazy else ""),
                        "storage": ("fp64 tables, histograms, reductions and MFMA; fp32 output planes; V implicit" if lazy else
+                                   "fp64 affinities, Phi / chunks, V, reductions and MFMA; fp32 output planes"
+                                   if flt.diag()["formulation"] in (4, 5) else
                                    "fp64 reductions and Gram/projection MFMA; fp32 affinities, V and outputs")},
             "host_to_host": h2h,
             "slab_input": bool(slab_input),
