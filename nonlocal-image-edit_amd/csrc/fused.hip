@@ -1689,6 +1689,55 @@ __global__ __launch_bounds__(256) void k_ghist_final(const double* __restrict__ 
     }
 }
 
+// ---- Gram by index sums (sorted.hip: k_sorted_gsum has the derivation).  Rows: er[r][a] er[r][a'] =
+// exp(-(a - a')^2 rs^2 / (2 hx^2)) F_{a+a'}(r), F_s(r) = exp(-2 (r - rowOff - s rs / 2)^2 / hx^2): the GEMM over image rows needs
+// 2 nR - 1 rows instead of nR (nR + 1) / 2.
+//   k_gsum_rowf : F[r][s] (row stride ldm, zero padded)
+//   k_ghist_gemm: T[s][t, x] = sum_r F[r][s] S_r[t, x]
+//   k_gsum_final: Gk[(a,b)][(a',b')] = kr_{|a-a'|} kc_{|b-b'|} sum_x Ep[x][a,b] Ep[x][a',b'] T[a+a'][b+b', x]
+__global__ void k_gsum_rowf(GridSpec gs, int row0, int nrows, int ldm, double inv_hx2, double* __restrict__ F) {
+    const long long n = (long long)nrows * ldm;
+    const int ns = 2 * gs.nSelRows - 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / ldm), sidx = (int)(i % ldm);
+        double v = 0.0;
+        if (sidx < ns) {
+            const double d = (double)(row0 + r - gs.rowOff) - 0.5 * (double)sidx * (double)gs.rowStep;
+            v = exp(-2.0 * d * d * inv_hx2);
+        }
+        F[i] = v;
+    }
+}
+
+// one wave per pair of samples i <= j (grid: x = groups of 4 j's, y = i)
+__global__ __launch_bounds__(256) void k_gsum_final(const double* __restrict__ T, long long N, int nsplit, size_t zstride,
+                                                    const double* __restrict__ Ep, int p, int nC, double kr2, double kc2,
+                                                    double* __restrict__ Gk) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.y, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j < i || j >= p) return;  // wave-uniform
+    const int a1 = i / nC, b1 = i - a1 * nC, a2 = j / nC, b2 = j - a2 * nC;
+    const int da = a1 - a2, db = b1 - b2;
+    const double kappa = exp(-(double)(da * da) * kr2 - (double)(db * db) * kc2);
+    const double* Tm = T + (size_t)(a1 + a2) * N + (size_t)(b1 + b2) * kLevels;
+    double u = 0.0;
+#pragma unroll
+    for (int q = 0; q < kLevels / 64; ++q) {
+        const int x = q * 64 + lane;
+        double tx = 0.0;
+        for (int z = 0; z < nsplit; ++z) tx += Tm[z * zstride + x];  // fixed order
+        const double* e = Ep + (size_t)x * p;
+        u += e[i] * e[j] * tx;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) u += __shfl_xor(u, off);
+    if (lane == 0) {
+        u *= kappa;
+        Gk[(size_t)i * p + j] = u;
+        Gk[(size_t)j * p + i] = u;
+    }
+}
+
 int ghist_ldm(int nR) { return ((nR * (nR + 1) / 2) + 15) & ~15; }
 constexpr int kGhistMT = 14;
 // image rows per GEMM split (a multiple of the 16-row k step) and the number of splits: ~4 workgroups per CU
@@ -1700,12 +1749,18 @@ static void ghist_split(long long N, int ldm, int nrows_local, int* ksplit, int*
     *ksplit = ks;
     *nsplit = std::max(1, (nrows_local + ks - 1) / ks);
 }
+static int gsum_ldm(int nR) { return ((2 * nR - 1) + 15) & ~15; }
 size_t ghist_workspace_elems(GridSpec gs, int nrows_local) {
     const size_t NP = (size_t)gs.nSelCols * (gs.nSelCols + 1) / 2, N = 256 * NP;
     const size_t ldm = (size_t)ghist_ldm(gs.nSelRows);
     int ks, ns;
     ghist_split((long long)N, (int)ldm, nrows_local, &ks, &ns);
-    return (size_t)nrows_local * N + (size_t)nrows_local * ldm + (size_t)ns * ldm * N;
+    const size_t pairs = (size_t)nrows_local * N + (size_t)nrows_local * ldm + (size_t)ns * ldm * N;
+    // the index-sum form (2 nC - 1 tables, 2 nR - 1 GEMM rows) needs less of each, but may split the rows further
+    const size_t N2 = (size_t)256 * (2 * gs.nSelCols - 1), ldm2 = (size_t)gsum_ldm(gs.nSelRows);
+    ghist_split((long long)N2, (int)ldm2, nrows_local, &ks, &ns);
+    const size_t sums = (size_t)nrows_local * N2 + (size_t)nrows_local * ldm2 + (size_t)ns * ldm2 * N2;
+    return std::max(pairs, sums);
 }
 
 // d_ws: ghist_workspace_elems doubles; d_Gk: p x p doubles (full symmetric matrix of this rank's rows)
@@ -1714,6 +1769,31 @@ hipError_t gram_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, int 
                      double* d_Gk, LaunchObserver* obs, const SortedRows* sorted) {
     const int nC = gs.nSelCols, nR = gs.nSelRows;
     if (nC > kGhistMaxCols) return hipErrorInvalidValue;
+    if (sorted != nullptr && sorted->E2 != nullptr) {  // index sums: 2 nC - 1 tables, 2 nR - 1 GEMM rows (sorted_gsum_ok)
+        const long long N2 = (long long)kLevels * (2 * nC - 1);
+        const int ldm2 = gsum_ldm(nR);
+        double* d_S = d_ws;
+        double* d_F = d_S + (size_t)nrows_local * N2;
+        double* d_T = d_F + (size_t)nrows_local * ldm2;
+        const double hx = sorted->hx;
+        if (obs) obs->begin(SUB_GHIST_ROWS);
+        hipError_t e2 = sorted_gram_sums(s, gs, nrows_local, sorted->scol, sorted->desc, sorted->first, sorted->E2, d_c, d_S, hx);
+        if (e2 != hipSuccess) return e2;
+        if (obs) obs->end(), obs->begin(SUB_GHIST_EE);
+        hipLaunchKernelGGL(k_gsum_rowf, dim3(256), dim3(256), 0, s, gs, row0, nrows_local, ldm2, 1.0 / (hx * hx), d_F);
+        constexpr int MT2 = 4;  // 2 nR - 1 <= 63: one group of four 16-row tiles
+        int ksplit2, nsplit2;
+        ghist_split(N2, ldm2, nrows_local, &ksplit2, &nsplit2);
+        const dim3 grid2((unsigned)((N2 / 16 + 3) / 4), (unsigned)((ldm2 / 16 + MT2 - 1) / MT2), (unsigned)nsplit2);
+        if (obs) obs->end(), obs->begin(SUB_GHIST_GEMM);
+        hipLaunchKernelGGL((k_ghist_gemm<MT2>), grid2, dim3(256), 0, s, d_F, ldm2, d_S, N2, nrows_local, ksplit2, d_T);
+        if (obs) obs->end(), obs->begin(SUB_GHIST_FINAL);
+        const double rs = gs.rowStep, cs2 = gs.colStep;
+        hipLaunchKernelGGL(k_gsum_final, dim3((unsigned)((p + 3) / 4), (unsigned)p), dim3(256), 0, s, d_T, N2, nsplit2,
+                           (size_t)ldm2 * N2, d_Ep, p, nC, rs * rs / (2.0 * hx * hx), cs2 * cs2 / (2.0 * hx * hx), d_Gk);
+        if (obs) obs->end();
+        return hipGetLastError();
+    }
     const int NP = nC * (nC + 1) / 2;
     const long long N = (long long)kLevels * NP;
     const int ldm = ghist_ldm(nR);

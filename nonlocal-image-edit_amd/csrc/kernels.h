@@ -205,7 +205,13 @@ struct SortedRows {
     const double* E;              // [W + 1] exp(-d^2 / hx^2)
     bool rec;                     // column factors by recurrence from two table reads (sorted_recurrence)
     double kappa;                 // exp(-2 colStep^2 / hx^2)
+    const double* E2 = nullptr;   // [W + 1] exp(-2 d^2 / hx^2): set (with hx) where the Gram runs on index sums (sorted_gsum_ok)
+    double hx = 0.0;
 };
+// Gram by index sums (sorted.hip: k_sorted_gsum): S_r[t][x] = sum c_i^2 G_t(col_i), t < 2 nC - 1; layout [row][t][level]
+bool sorted_gsum_ok(GridSpec gs, double hx);
+hipError_t sorted_gram_sums(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
+                            const unsigned short* d_first, const double* d_E2, const double* d_cvec, double* d_Aout, double hx);
 bool sorted_recurrence(GridSpec gs, double hx, double* kappa);
 int sorted_max_width();
 size_t sorted_scol_elems(int W, int nrows_local);  // allocation size of SortedRows::scol

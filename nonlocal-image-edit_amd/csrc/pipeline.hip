@@ -1321,7 +1321,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     const bool sorted = hist_tiled && ss.gs.W <= nlek::sorted_max_width() && std::getenv("NLE_NO_SORTED_ROWS") == nullptr;
     DevBuf<unsigned short> d_scol, d_first;
     DevBuf<uint2> d_desc;
-    DevBuf<double> d_E;
+    DevBuf<double> d_E, d_E2;
     nlek::SortedRows sr{};
     if (sorted) {
         d_scol.alloc(nlek::sorted_scol_elems(ss.gs.W, nrows_local));  // k_sort_rows writes every entry a pass reads
@@ -1333,6 +1333,12 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         HIP_OK(hipMemsetAsync(d_cbuf.p, 0, d_cbuf.n * sizeof(double), c->stream));  // sample pixels are never visited
         sr = nlek::SortedRows{d_scol.p, d_desc.p, d_first.p, d_E.p, false, 0.0};
         sr.rec = nlek::sorted_recurrence(ss.gs, hx, &sr.kappa);
+        if (nlek::sorted_gsum_ok(ss.gs, hx)) {  // the Gram on index sums: one more distance table, exp(-2 d^2 / hx^2)
+            d_E2.alloc((size_t)ss.gs.W + 1);
+            PROFILED(c, NLE_K_SMALL, nlek::dist_table(c->stream, ss.gs.W, hx / std::sqrt(2.0), d_E2.p));
+            sr.E2 = d_E2.p;
+            sr.hx = hx;
+        }
     }
     const nlek::SortedRows* srp = sorted ? &sr : nullptr;
     const int nrows = hist ? nrows_local : nlek::sink_pass_rows(std::max<long long>(M, 1));

@@ -798,6 +798,135 @@ __global__ __launch_bounds__(kT) void k_sorted_gram(const unsigned short* __rest
     }
 }
 
+// ------------------------------------------------------------------ Gram by INDEX SUMS (any nC <= 36: one launch)
+// On the reference's sample grid (samplePixels :56-80: equispaced columns g_b = cb0 + b cs) the product of two column factors
+// of a pixel depends on the pair (b, b') only through b + b':
+//     ec[c][b] ec[c][b'] = exp(-((c - g_b)^2 + (c - g_b')^2) / hx^2) = exp(-(b - b')^2 cs^2 / (2 hx^2)) . G_{b+b'}(c),
+//     G_t(c) = exp(-2 (c - m_t)^2 / hx^2),   m_t = cb0 + t cs / 2,   t = 0 .. 2 nC - 2
+// (complete the square).  So the nC (nC + 1) / 2 pair tables of k_sorted_gram(_wide) collapse to 2 nC - 1 tables
+//     S_r[t][x] = sum_{i in row r, x_i = x} c_i^2 G_t(col_i)
+// -- 59 instead of 465 at cfg5, in one launch instead of 15, an eighth of the table bytes -- and the same identity on the rows
+// shrinks the GEMM behind it from nR (nR + 1) / 2 to 2 nR - 1 rows (fused.hip: gram_hist).  Exact algebra; only the order and
+// grouping of roundings differ from the pair form.
+// G_t along t by the recurrence of a Gaussian on an equispaced grid (as column_factors<REC>), started from ONE table value:
+//     G_0 = E2[|c - cb0|],   G_{t+1} = G_t rho_t,   rho_0 = exp(theta (c - cb0)) kappa1,   rho_{t+1} = rho_t kappa1^2,
+//     E2[d] = exp(-2 d^2 / hx^2),  theta = 2 cs / hx^2,  kappa1 = exp(-cs^2 / (2 hx^2));  exp(theta u) = PH[c >> 6] PL[c & 63].
+// The host enables it only where no term leaves fp64's normal range (sorted_gsum_ok); O(t^2) ulp like the other recurrence.
+template <int NT>
+__global__ __launch_bounds__(kT) void k_sorted_gsum(const unsigned short* __restrict__ scol, const uint2* __restrict__ desc,
+                                                    const unsigned short* __restrict__ first, GridSpec gs, int nrows,
+                                                    const double* __restrict__ E2tab, const double* __restrict__ cvec,
+                                                    double* __restrict__ Aout, double theta, double kappa1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int SL = 11, PS = SL;
+    const int W = gs.W;
+    double* sE = reinterpret_cast<double*>(smem_raw);               // E2[0 .. W]
+    double* sPH = sE + ((W + 2) & ~1);                              // exp(theta (64 k - cb0)), k <= W / 64
+    double* sPL = sPH + (((W >> 6) + 2) & ~1);                      // exp(theta l), l < 64
+    double* sP = sPL + 64;
+    unsigned short* sfirst = reinterpret_cast<unsigned short*>(sP + (size_t)kT * PS);
+    const int tid = threadIdx.x;
+    const int cb0 = gs.colOff;
+    for (int i = tid; i <= W; i += kT) sE[i] = E2tab[i];
+    for (int i = tid; i <= (W >> 6); i += kT) sPH[i] = exp(theta * (double)(64 * i - cb0));
+    if (tid < 64) sPL[tid] = exp(theta * (double)tid);
+    const double kappa2 = kappa1 * kappa1;
+    const size_t pitch = sorted_row_pitch(W);
+    for (int lrow = blockIdx.x; lrow < nrows; lrow += gridDim.x) {
+        if (tid < 258) sfirst[tid] = first[(size_t)lrow * 258 + tid];
+        const uint2 dsc = desc[(size_t)lrow * kT + tid];
+        const int len = dsc_len(dsc);
+        double acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = 0.0;
+        __syncthreads();
+        const uint2* slot = reinterpret_cast<const uint2*>(scol + (size_t)lrow * pitch + (size_t)tid * dsc_chp(dsc));
+        const double* cv_row = cvec + (size_t)lrow * W;
+        uint2 cur = slot[0];
+        for (int t0 = 0; t0 < len; t0 += 4) {
+            const uint2 nxt = slot[(t0 >> 2) + 1];
+            const unsigned c8v[4] = {cur.x & 0xffffu, cur.x >> 16, cur.y & 0xffffu, cur.y >> 16};
+            double cfv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cfv[k] = cv_row[c8v[k] >> 3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double cf = (t0 + k < len) ? cfv[k] : 0.0;  // padding adds exact zeros
+                const int c = (int)(c8v[k] >> 3);
+                const int du = c - cb0;
+                double g = cf * cf * sE[du < 0 ? -du : du];
+                double rho = sPH[c >> 6] * sPL[c & 63] * kappa1;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] += g;
+                    g *= rho;
+                    rho *= kappa2;
+                }
+            }
+            cur = nxt;
+        }
+        const int steps = dsc_steps(dsc), j = dsc_j(dsc), m = dsc_m(dsc);
+        double* out = Aout + (size_t)lrow * kLevels * NT;
+#pragma unroll
+        for (int s0 = 0; s0 < NT; s0 += SL) {
+            double v[SL];
+#pragma unroll
+            for (int i = 0; i < SL; ++i) v[i] = (s0 + i < NT) ? acc[s0 + i] : 0.0;
+            combine_chunks<SL, PS>(v, sP, tid, len > 0, j, m, steps);
+            const int ns = (NT - s0 < SL) ? NT - s0 : SL;
+            for (int i = tid; i < ns * kLevels; i += kT) {
+                const int jj = i / kLevels, xx = i & (kLevels - 1);
+                const int f0 = sfirst[xx];
+                out[(size_t)(s0 + jj) * kLevels + xx] = sfirst[xx + 1] > f0 ? sP[f0 * PS + jj] : 0.0;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// where the recurrence above stays inside fp64's normal range (with a wide margin): every G_t and every rho_t, and the
+// exp(theta u) table; the same on the rows (the GEMM's F[r][s] is evaluated directly, no recurrence)
+bool sorted_gsum_ok(GridSpec gs, double hx) {
+    if (std::getenv("NLE_GRAM_PAIRS") != nullptr) return false;  // measurement: the pair-table form
+    const double cs = gs.colStep, nC = gs.nSelCols, Wd = gs.W;
+    // every centre m_t lies inside the image, so |c - m_t| < W: -log of the smallest G_t; and the |log| of the largest
+    // rho_t = exp(theta (c - cb0) - (2 t + 1) cs^2 / (2 hx^2)) and of the exp(theta (64 k - cb0)) table
+    const double m_g = 2.0 * Wd * Wd / (hx * hx);
+    const double m_rho = (2.0 * cs * Wd + 2.0 * nC * cs * cs) / (hx * hx);
+    return gs.W <= sorted_max_width() && m_g < 600.0 && m_rho < 600.0;
+}
+
+hipError_t sorted_gram_sums(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
+                            const unsigned short* d_first, const double* d_E2, const double* d_cvec, double* d_Aout,
+                            double hx) {
+    const int nC = gs.nSelCols, nt = 2 * nC - 1;
+    if (nC < 1 || nC > 36 || gs.W > sorted_max_width()) return hipErrorInvalidValue;
+    if (nrows_local <= 0) return hipSuccess;
+    const double cs = gs.colStep;
+    const double theta = 2.0 * cs / (hx * hx), kappa1 = std::exp(-cs * cs / (2.0 * hx * hx));
+    const size_t shm = sorted_lds_bytes(gs.W, 11) + (size_t)((((gs.W >> 6) + 2) & ~1) + 64) * sizeof(double);
+    const int grid = sorted_grid(nrows_local);
+#define NLE_GS(NTV)                                                                                                      \
+    case NTV: {                                                                                                          \
+        if (shm > 48 * 1024) {                                                                                           \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sorted_gsum<NTV>),                       \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                   \
+            if (ea != hipSuccess) return ea;                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL((k_sorted_gsum<NTV>), dim3((unsigned)grid), dim3(kT), shm, s, d_scol, d_desc, d_first, gs,     \
+                           nrows_local, d_E2, d_cvec, d_Aout, theta, kappa1);                                            \
+    } break;
+    switch (nt) {
+        NLE_GS(1) NLE_GS(3) NLE_GS(5) NLE_GS(7) NLE_GS(9) NLE_GS(11) NLE_GS(13) NLE_GS(15) NLE_GS(17) NLE_GS(19) NLE_GS(21)
+        NLE_GS(23) NLE_GS(25) NLE_GS(27) NLE_GS(29) NLE_GS(31) NLE_GS(33) NLE_GS(35) NLE_GS(37) NLE_GS(39) NLE_GS(41)
+        NLE_GS(43) NLE_GS(45) NLE_GS(47) NLE_GS(49) NLE_GS(51) NLE_GS(53) NLE_GS(55) NLE_GS(57) NLE_GS(59) NLE_GS(61)
+        NLE_GS(63) NLE_GS(65) NLE_GS(67) NLE_GS(69) NLE_GS(71)
+        default: return hipErrorInvalidValue;
+    }
+#undef NLE_GS
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ Gram pair tables for wider grids (12 <= nC <= 36)
 // nC (nC + 1) / 2 accumulators do not fit in registers any more, so a launch takes BB = 64 / nC rows b0 .. b0 + nb - 1 of
 // the pair triangle: acc[i][b'] += q_{b0+i} q_{b'} for ALL b' (the b' < b half is computed and dropped: the row index b0 is

@@ -460,6 +460,37 @@ def test_auto_mode_falls_back_to_the_fp64_decomposition(nle, oracle, ctx, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(96, 128, 6, 8, 32.0, 30.0, 10, 10, 4), (267, 400, 10, 20, 100.0, 30.0, 12, 30, 4),
+                                  (120, 300, 5, 33, 80.0, 25.0, 6, 20, 3), (64, 64, 3, 1, 20.0, 30.0, 5, 3, 2)])
+def test_gram_by_index_sums_equals_the_pair_table_form(nle, oracle, ctx, case):
+    """On the equispaced sample grid the product of two column (row) factors depends on the pair only through the sum of
+    its indices (sorted.hip: k_sorted_gsum): the Gram stage then needs 2 nC - 1 tables and 2 nR - 1 GEMM rows instead of
+    nC (nC + 1) / 2 and nR (nR + 1) / 2.  Exact algebra: against the pair-table form (NLE_GRAM_PAIRS=1) eigenvalues and
+    layers agree to rounding, and both meet the oracle."""
+    H, W, nr, nc, hx, hy, T, K, L = case
+    x = oracle.synthetic_luminance(H, W)
+    V_o, S_o = oracle.train_filter(x, nr, nc, hx, hy, T, K)
+    Y_o = oracle.apply_layers(V_o, S_o, x, L).reshape(L, -1)
+    ctx.set_mode(2)
+    try:
+        f1, Y1 = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
+        os.environ["NLE_GRAM_PAIRS"] = "1"
+        try:
+            f2, Y2 = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
+        finally:
+            del os.environ["NLE_GRAM_PAIRS"]
+    finally:
+        ctx.set_mode(0)
+    assert f1.diag() == f2.diag()
+    assert rel_l2(f1.eigvals, f2.eigvals) < 1e-10
+    for j in range(L):
+        assert rel_l2(Y1[j], Y2[j]) < 1e-6, (j, rel_l2(Y1[j], Y2[j]))
+        assert rel_l2(Y1[j], Y_o[j]) < 1e-4
+    f1.close()
+    f2.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["non-integer", "wide grid", "many eigenvectors"])
 def test_streamed_fp64_form_takes_what_does_not_fit(nle, oracle, ctx, kind):
     """NLE_MODE_STREAMED_F64: the fp64 fallback WITHOUT the N x r matrix (affinity rows regenerated chunk by chunk, bounded
