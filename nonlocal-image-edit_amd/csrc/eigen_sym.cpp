@@ -757,6 +757,39 @@ int default_threads(int n, int) {
     return n >= 512 ? 8 : 1;
 }
 
+// x <- x minus its components along the m orthonormal vectors z_0 .. z_{m-1} (stride n), two passes.  Four vectors at a
+// time: their four dot products in ONE sweep over x (independent accumulators), their combined update in one more -- half the
+// sweeps of vector-by-vector modified Gram-Schmidt and vectorisable; inside a block the projection is classical, across
+// blocks sequential, and the second pass makes either form orthogonal to rounding ("twice is enough").  With the ~100
+// eigenvalues the 1e-10 cut drops from a 900 x 900 Wa in ONE cluster this loop was 10 of the 10.8 ms of inverse iteration.
+NLE_SIMD_CLONES static void orth_against_cluster(int n, const double* Zc, int m, double* x) {
+    for (int pass = 0; pass < 2; ++pass) {
+        int q = 0;
+        for (; q + 4 <= m; q += 4) {
+            const double *z0 = Zc + (size_t)q * n, *z1 = z0 + n, *z2 = z1 + n, *z3 = z2 + n;
+            double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;
+#pragma omp simd reduction(+ : h0, h1, h2, h3)
+            for (int i = 0; i < n; ++i) {
+                const double xi = x[i];
+                h0 += z0[i] * xi;
+                h1 += z1[i] * xi;
+                h2 += z2[i] * xi;
+                h3 += z3[i] * xi;
+            }
+#pragma omp simd
+            for (int i = 0; i < n; ++i) x[i] -= (h0 * z0[i] + h1 * z1[i]) + (h2 * z2[i] + h3 * z3[i]);
+        }
+        for (; q < m; ++q) {
+            const double* zq = Zc + (size_t)q * n;
+            double h = 0.0;
+#pragma omp simd reduction(+ : h)
+            for (int i = 0; i < n; ++i) h += zq[i] * x[i];
+#pragma omp simd
+            for (int i = 0; i < n; ++i) x[i] -= h * zq[i];
+        }
+    }
+}
+
 // Eigenvectors of the symmetric tridiagonal T (diagonal d[0..n), sub-diagonal e[1..n)) for k of its eigenvalues
 // lam[0..k), given in DESCENDING order and accurate to rounding, by inverse iteration -- the scheme of LAPACK's dstein:
 // LU of T - lam I with partial pivoting (tiny pivots perturbed), a few solves from a pseudo-random start, vectors of
@@ -836,13 +869,7 @@ bool tridiag_inverse_iteration(int n, const double* d, const double* e, const do
                 if (i + 2 < n) t -= dd[i] * x[i + 2];
                 x[i] = t * ra[i];
             }
-            for (int pass = 0; pass < 2; ++pass)  // the cluster's earlier vectors
-                for (int q = gp; q < j; ++q) {
-                    const double* zq = Z + (size_t)q * n;
-                    double h = 0.0;
-                    for (int i = 0; i < n; ++i) h += zq[i] * x[i];
-                    for (int i = 0; i < n; ++i) x[i] -= h * zq[i];
-                }
+            orth_against_cluster(n, Z + (size_t)gp * n, j - gp, x.data());  // the cluster's earlier vectors, twice
             double nrm = 0.0;
             for (int i = 0; i < n; ++i) nrm += x[i] * x[i];
             nrm = std::sqrt(nrm);

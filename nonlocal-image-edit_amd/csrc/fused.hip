@@ -1391,7 +1391,9 @@ hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int
                              LaunchObserver* obs, const SortedRows* sorted) {
     const int nC = gs.nSelCols, nR = gs.nSelRows;
     if (nC > 36 || nR > 32 || nrows_local <= 0) return nrows_local <= 0 ? hipSuccess : hipErrorInvalidValue;
-    if (nl < 1 || nl > apply_layers_per_launch(gs)) return hipErrorInvalidValue;
+    const bool use_sorted = sorted != nullptr && nC <= sorted_expand_max_cols() && gs.W <= sorted_expand_max_width() &&
+                            std::getenv("NLE_NO_SORTED_EXPAND") == nullptr;
+    if (nl < 1 || nl > (use_sorted ? sorted_expand_layers(gs) : apply_layers_per_launch(gs))) return hipErrorInvalidValue;
     const size_t n = (size_t)kLevels * nC, gstride = (size_t)nrows_local * n;
     if (obs) obs->begin(SUB_HIST_G);
     for (int l = 0; l < nl; ++l) {
@@ -1399,10 +1401,9 @@ hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int
         if (eg != hipSuccess) return eg;
     }
     if (obs) obs->end(), obs->begin(SUB_HIST_PIX);
-    if (sorted != nullptr && nC <= sorted_expand_max_cols() && gs.W <= sorted_expand_max_width() &&
-        nl <= sorted_expand_layers() && std::getenv("NLE_NO_SORTED_EXPAND") == nullptr) {
+    if (use_sorted) {
         hipError_t ex = sorted_expand(s, gs, nrows_local, sorted->scol, sorted->desc, sorted->E, d_ws, gstride, nl, d_c, d_out,
-                                      ostride);
+                                      ostride, sorted->rec, sorted->kappa);
         if (obs) obs->end();
         return ex;
     }

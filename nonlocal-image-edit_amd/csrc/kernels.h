@@ -219,10 +219,10 @@ int sorted_gram_max_cols();
 // expand half of the sample-space apply on the sorted rows (nl <= sorted_expand_layers() layers per launch)
 int sorted_expand_max_cols();
 int sorted_expand_max_width();
-int sorted_expand_layers();
+int sorted_expand_layers(GridSpec gs);
 hipError_t sorted_expand(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
                          const double* d_E, const double* d_g, size_t gstride, int nl, const double* d_cvec, float* d_out,
-                         long long ostride);
+                         long long ostride, bool rec = false, double kappa = 0.0);
 hipError_t dist_table(hipStream_t s, int W, double hx, double* d_E);
 hipError_t sort_rows(hipStream_t s, const float* d_lum, GridSpec gs, int row0, int nrows_local, unsigned short* d_scol,
                      uint2* d_desc, unsigned short* d_first);

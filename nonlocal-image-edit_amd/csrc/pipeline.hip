@@ -1733,6 +1733,9 @@ void apply_sample_space(nle_filter* f, const float* d_x, const double* h_g /* L 
     if (M > 0) {
         static const int emap[4] = {NLE_K_SINK_TABLES, NLE_K_APPLY_EXPAND, NLE_K_REDUCE, NLE_K_REDUCE};
         int lb = std::min(L, nlek::apply_layers_per_launch(f->gs));
+        if (f->has_sorted && f->gs.nSelCols <= nlek::sorted_expand_max_cols() && f->gs.W <= nlek::sorted_expand_max_width() &&
+            std::getenv("NLE_NO_SORTED_EXPAND") == nullptr)
+            lb = std::min(L, nlek::sorted_expand_layers(f->gs));  // what one launch of the sorted expand kernel takes
         if (group > 0) lb = std::min(lb, group);
         DevBuf<double> d_gws((size_t)lb * nrows_local * 256 * f->gs.nSelCols);
         for (int l = 0; l < L; l += lb) {

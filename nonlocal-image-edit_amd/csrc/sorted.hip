@@ -613,18 +613,20 @@ hipError_t sorted_pass(hipStream_t s, int mode, GridSpec gs, int row0, int nrows
 // are scattered into the row's output buffer in LDS and leave it coalesced.  Sample pixels are not in the sorted lists:
 // their slots hold whatever the buffer held and are overwritten by k_scatter_samples with the exact sample rows, as before.
 // nC <= 12 (registers), W <= 4096 (LDS: E table + 4 rows of fp32 output).
+// Wider grids (13 .. 36 columns) and wider images (W <= 8192): two layers per launch (2 nC table values in registers; LDS: the
+// E table + two rows of output) and, where sorted_recurrence allows, the column factors by recurrence.
 constexpr int kExpLayers = 4;
-template <int NC>
+template <int NC, int kExpL, bool REC>
 __global__ __launch_bounds__(kT) void k_sorted_expand(const unsigned short* __restrict__ scol, const uint2* __restrict__ desc,
                                                       GridSpec gs, int nrows, const double* __restrict__ Etab,
                                                       const double* __restrict__ g, size_t gstride, int nl,
                                                       const double* __restrict__ cvec, float* __restrict__ out,
-                                                      long long ostride) {
+                                                      long long ostride, double kappa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int n = kLevels * NC;
     const int W = gs.W;
     double* sE = reinterpret_cast<double*>(smem_raw);
-    float* sOut = reinterpret_cast<float*>(sE + ((W + 2) & ~1));  // [kExpLayers][W]
+    float* sOut = reinterpret_cast<float*>(sE + ((W + 2) & ~1));  // [kExpL][W]
     const int tid = threadIdx.x;
     for (int i = tid; i <= W; i += kT) sE[i] = Etab[i];
     const int cb0 = gs.colOff, cs = gs.colStep;
@@ -642,9 +644,9 @@ __global__ __launch_bounds__(kT) void k_sorted_expand(const unsigned short* __re
             if (4 * b < len) v = slot[b];
             idx[b] = v;
         }
-        double gv[kExpLayers][NC];
+        double gv[kExpL][NC];
 #pragma unroll
-        for (int l = 0; l < kExpLayers; ++l)
+        for (int l = 0; l < kExpL; ++l)
 #pragma unroll
             for (int b = 0; b < NC; ++b) gv[l][b] = (l < nl) ? g[(size_t)l * gstride + (size_t)lrow * n + b * kLevels + x] : 0.0;
         const double* cv_row = cvec + (size_t)lrow * W;
@@ -656,9 +658,9 @@ __global__ __launch_bounds__(kT) void k_sorted_expand(const unsigned short* __re
             const unsigned c = c8 >> 3;
             const double cv = cv_row[c];
             double e[NC];
-            column_factors<NC, false>(sEa, c8, cb0, cs, 0.0, [&](const int b, const double ev) { e[b] = ev; });
+            column_factors<NC, REC>(sEa, c8, cb0, cs, kappa, [&](const int b, const double ev) { e[b] = ev; });
 #pragma unroll
-            for (int l = 0; l < kExpLayers; ++l) {
+            for (int l = 0; l < kExpL; ++l) {
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                 for (int b = 0; b < NC; ++b) {
@@ -695,37 +697,50 @@ __global__ __launch_bounds__(kT) void k_sorted_expand(const unsigned short* __re
     }
 }
 
-int sorted_expand_max_cols() { return 12; }
-int sorted_expand_max_width() { return 4096; }
-int sorted_expand_layers() { return kExpLayers; }
+int sorted_expand_max_cols() { return 36; }
+int sorted_expand_max_width() { return 8192; }
+// layers one launch takes: four up to 12 columns and 4096 pixels per row, two beyond (registers, LDS)
+int sorted_expand_layers(GridSpec gs) { return (gs.nSelCols <= 12 && gs.W <= 4096) ? kExpLayers : 2; }
 
 hipError_t sorted_expand(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
                          const double* d_E, const double* d_g, size_t gstride, int nl, const double* d_cvec, float* d_out,
-                         long long ostride) {
+                         long long ostride, bool rec, double kappa) {
     const int nC = gs.nSelCols;
-    if (nC < 1 || nC > sorted_expand_max_cols() || gs.W > sorted_expand_max_width() || nl < 1 || nl > kExpLayers)
+    const int lmax = sorted_expand_layers(gs);
+    if (nC < 1 || nC > sorted_expand_max_cols() || gs.W > sorted_expand_max_width() || nl < 1 || nl > lmax)
         return hipErrorInvalidValue;
     if (nrows_local <= 0) return hipSuccess;
-    const size_t shm = (size_t)((gs.W + 2) & ~1) * sizeof(double) + (size_t)kExpLayers * gs.W * sizeof(float);
+    const size_t shm = (size_t)((gs.W + 2) & ~1) * sizeof(double) + (size_t)lmax * gs.W * sizeof(float);
     int ncu = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = std::max(1, std::min(nrows_local, ncu));  // one 512-thread workgroup per CU (registers, LDS)
-#define NLE_SX(NCV)                                                                                                    \
-    case NCV: {                                                                                                        \
+#define NLE_SX1(NCV, LV, RECV)                                                                                         \
+    {                                                                                                                  \
         if (shm > 48 * 1024) {                                                                                         \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sorted_expand<NCV>),                   \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sorted_expand<NCV, LV, RECV>),         \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                 \
             if (ea != hipSuccess) return ea;                                                                           \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_sorted_expand<NCV>), dim3((unsigned)grid), dim3(kT), shm, s, d_scol, d_desc, gs,         \
-                           nrows_local, d_E, d_g, gstride, nl, d_cvec, d_out, ostride);                                \
-    } break;
+        hipLaunchKernelGGL((k_sorted_expand<NCV, LV, RECV>), dim3((unsigned)grid), dim3(kT), shm, s, d_scol, d_desc,   \
+                           gs, nrows_local, d_E, d_g, gstride, nl, d_cvec, d_out, ostride, kappa);                     \
+    }
+#define NLE_SX(NCV)                                                                                                    \
+    case NCV:                                                                                                          \
+        if constexpr ((NCV) <= 12) {                                                                                   \
+            if (lmax == kExpLayers) NLE_SX1(NCV, kExpLayers, false) else NLE_SX1(NCV, 2, false)                        \
+        } else {                                                                                                       \
+            if (rec) NLE_SX1(NCV, 2, true) else NLE_SX1(NCV, 2, false)                                                 \
+        }                                                                                                              \
+        break;
     switch (nC) {
         NLE_SX(1) NLE_SX(2) NLE_SX(3) NLE_SX(4) NLE_SX(5) NLE_SX(6) NLE_SX(7) NLE_SX(8) NLE_SX(9) NLE_SX(10) NLE_SX(11)
-        NLE_SX(12)
+        NLE_SX(12) NLE_SX(13) NLE_SX(14) NLE_SX(15) NLE_SX(16) NLE_SX(17) NLE_SX(18) NLE_SX(19) NLE_SX(20) NLE_SX(21)
+        NLE_SX(22) NLE_SX(23) NLE_SX(24) NLE_SX(25) NLE_SX(26) NLE_SX(27) NLE_SX(28) NLE_SX(29) NLE_SX(30) NLE_SX(31)
+        NLE_SX(32) NLE_SX(33) NLE_SX(34) NLE_SX(35) NLE_SX(36)
         default: return hipErrorInvalidValue;
     }
 #undef NLE_SX
+#undef NLE_SX1
     return hipGetLastError();
 }
 
