@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
     constexpr int n = kLevels * NC;
     constexpr int SL = NC < 11 ? NC : 11;  // sums combined per tree (slices of the nC sums when nC > 11)
     constexpr int PS = SL | 1;             // odd stride: consecutive threads' rows start on different banks
-    constexpr bool KEEP_E = NC <= 12;      // keep the column factors of a pixel in registers between the two loops
+    constexpr bool KEEP_E = NC <= 32;      // keep the column factors of a pixel in registers between the two loops (254 VGPRs at NC = 30, no spills)
     const int W = gs.W;
     const size_t pitch = sorted_row_pitch(W);
     double* sE = reinterpret_cast<double*>(smem_raw);
