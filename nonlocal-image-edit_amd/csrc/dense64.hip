@@ -597,6 +597,18 @@ hipError_t symm_lower64(hipStream_t s, int n, const double* d_src, double* d_dst
     hipLaunchKernelGGL(k_symm_lower64, dim3(256), dim3(256), 0, s, n, d_src, d_dst);
     return hipGetLastError();
 }
+// dst (n x n, column-major) = diag(dl) src[:n, :n] diag(dr), src with column stride lds
+__global__ void k_scale_rc64(int n, const double* __restrict__ src, int lds, const double* __restrict__ dl,
+                             const double* __restrict__ dr, double* __restrict__ dst) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < (size_t)n * n; t += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(t % n), c = (int)(t / n);
+        dst[t] = dl[r] * src[(size_t)c * lds + r] * dr[c];
+    }
+}
+hipError_t scale_rc64(hipStream_t s, int n, const double* d_src, int lds, const double* d_dl, const double* d_dr, double* d_dst) {
+    hipLaunchKernelGGL(k_scale_rc64, dim3(256), dim3(256), 0, s, n, d_src, lds, d_dl, d_dr, d_dst);
+    return hipGetLastError();
+}
 hipError_t fill64(hipStream_t s, double* d_p, size_t n, double v) {
     hipLaunchKernelGGL(k_fill64, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, s, d_p, n, v);
     return hipGetLastError();

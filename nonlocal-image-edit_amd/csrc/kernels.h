@@ -195,6 +195,8 @@ hipError_t potrf_inverse(hipStream_t s, int n, const double* d_A, double* d_L, d
 hipError_t transpose64(hipStream_t s, int n, const double* d_src, double* d_dst, int lds = 0, int ldd = 0);
 hipError_t symm_lower64(hipStream_t s, int n, const double* d_src, double* d_dst);  // mirror the lower triangle
 hipError_t fill64(hipStream_t s, double* d_p, size_t n, double v);
+// d_dst (n x n) = diag(dl) src[:n, :n] diag(dr); src column stride lds
+hipError_t scale_rc64(hipStream_t s, int n, const double* d_src, int lds, const double* d_dl, const double* d_dr, double* d_dst);
 
 // ---- level-sorted rows (sorted.hip): the pixel halves of the table passes without LDS atomics
 constexpr int kSortedThreads = 512;

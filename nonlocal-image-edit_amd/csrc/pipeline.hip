@@ -689,14 +689,23 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     // ---- Wa and a factor F of its (pseudo-)inverse, beside the Gram kernels: on the host below dev_solver_min_n(), else on
     // the device on the ctx's second stream (the Gram kernels are on the first)
     double h0 = now_ms();
-    o.Wa.resize(qq);
-    for (int b = 0; b < q; ++b)
-        for (int a = 0; a < q; ++a) o.Wa[(size_t)b * q + a] = o.rA[a] * o.Kr[(size_t)b * p + a] * o.cA[b];  // :249
+    const bool dev_wa = use_dev_solver(q) && !std::getenv("NLE_HOST_WA");
+    // Wa = diag(rA) Kr[:q,:q] diag(cA) (:249).  On the device route with Ka resident there (solve_Ka's device Cholesky) it is
+    // formed on the device; the host copy is built only if the host root has to take over.
+    const bool wa_on_device = dev_wa && ny.dev != nullptr;
+    auto build_Wa_host = [&] {
+        if (!o.Wa.empty()) return;
+        o.Wa.resize(qq);
+        for (int b = 0; b < q; ++b)
+            for (int a = 0; a < q; ++a) o.Wa[(size_t)b * q + a] = o.rA[a] * o.Kr[(size_t)b * p + a] * o.cA[b];  // :249
+    };
+    if (!wa_on_device) build_Wa_host();
     std::vector<double> L, Li, U2, Us, l2_kept;
     int r2 = 0;
     bool chol_wa = false;
     double inv_diag = 0.0;
-    for (int a = 0; a < q; ++a) inv_diag += o.Wa[(size_t)a * q + a] > 0.0 ? 1.0 / o.Wa[(size_t)a * q + a] : 1e300;
+    if (!wa_on_device)
+        for (int a = 0; a < q; ++a) inv_diag += o.Wa[(size_t)a * q + a] > 0.0 ? 1.0 / o.Wa[(size_t)a * q + a] : 1e300;
     bool deflated = false;
     std::vector<double> Fdefl, Gdefl;  // F (q x q) and G = L^T Vd (q x d):  F^T A^2 F = L^T L - G G^T
     int nd = 0;
@@ -704,7 +713,6 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     const bool force_eig = std::getenv("NLE_FORCE_EIG") != nullptr;
     // device form: the same three routes (Cholesky when the cut provably removes nothing; deflated Cholesky when it removes
     // at most q / 8 eigenvalues; else all kept eigenvectors -- that last one stays on the host)
-    const bool dev_wa = use_dev_solver(q) && !std::getenv("NLE_HOST_WA");
     DevBuf<double> d_Wa(qq), d_F, d_L, d_G;
     DevSymEig esw;
     DevChol chw;
@@ -725,7 +733,10 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
         HIP_OK(hipStreamSynchronize(st));
         const bool wa_serial = std::getenv("NLE_WA_SERIAL") != nullptr;  // measurement: the Gram kernels after the root
         if (!wa_serial) enqueue_gram();
-        upload_staged(c, d_Wa.p, o.Wa.data(), qq, sa);
+        if (wa_on_device)  // Wa(a, b) = rA[a] Ka(a, b) cA[b]: one product with both diagonals, no upload
+            HIP_OK(nlek::scale_rc64(sa, q, ny.dev->Ka.p, p, d_rA.p, d_cA.p, d_Wa.p));
+        else
+            upload_staged(c, d_Wa.p, o.Wa.data(), qq, sa);
         HIP_OK(nlek::symm_lower64(sa, q, d_Wa.p, d_Ah.p));
         // (no separate Cholesky attempt here: the host's stops at the first pivot that proves it futile, a device
         // factorisation costs as much as the reduction -- so the eigenvalues come first and decide; none below the cut
@@ -784,6 +795,7 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     }
     if (!dev_done) {
         // (see ortho_ss_prepare for why any root of the pseudo-inverse serves and when Cholesky is admissible)
+        build_Wa_host();
         nd = 0;
         if (!dev_wa && !force_eig && inv_diag <= kCholMaxInvTrace) {
             L.resize(qq);
