@@ -123,6 +123,17 @@ def test_compute_needs_a_gpu_and_says_so(nle):
     assert b"HIP" in nle.lib().nle_last_error(None) or b"hip" in nle.lib().nle_last_error(None)
 
 
+def test_rccl_bootstrap_argument_checks_need_no_gpu(nle):
+    """the communicator bootstrap refuses malformed calls before it loads librccl or touches a device"""
+    import ctypes as C
+    L = nle.lib()
+    short = (C.c_char * 64)()
+    assert L.nle_rccl_unique_id(None, 128) == nle.NLE_ERR_INVALID
+    assert L.nle_rccl_unique_id(short, 64) == nle.NLE_ERR_INVALID
+    assert L.nle_ctx_init_rccl(None, 0, 1, short, 128) == nle.NLE_ERR_INVALID
+    assert L.nle_ctx_set_rccl_comm(None, 0, 1, None) == nle.NLE_ERR_INVALID
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "nonlocal-image-edit_amd")
     for dirpath, _, files in os.walk(pkg):

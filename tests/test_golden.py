@@ -132,10 +132,12 @@ def test_device_matches_flower_cfg1(nle, ctx, flower):
     Y = f.apply_layers(Lp, 4).cpu().numpy().astype(np.float64)
     assert np.allclose(np.linalg.norm(Y, axis=1), flower["layer_norms"], rtol=1e-4)
     for j in range(4):
-        # every 997th pixel of each layer; error relative to the layer's RMS level
+        # every 997th pixel of each layer: relative L2 over the probes at the contract's 1e-4, and no single probe further
+        # off than 1e-3 of the layer's RMS level
         got, want = Y[j, ::997], flower["Y_probe"][j]
         rms = flower["layer_norms"][j] / np.sqrt(Y.shape[1])
-        assert np.abs(got - want).max() < 1e-3 * rms * 10, j
+        assert rel_l2(got, want) < 1e-4, (j, rel_l2(got, want))
+        assert np.abs(got - want).max() < 1e-3 * rms, j
     y = f.apply(Lp, nle.transform_eigenvalues(f.eigvals, [2.0, 3.0, 4.0, 1.0])).cpu().numpy()
     L_out = np.rint(np.clip(y.astype(np.float64), 0, 255)).astype(np.uint8).reshape(Lp.shape)
     diff = np.abs(L_out.astype(int) - flower["L_out"].astype(int))

@@ -142,3 +142,63 @@ def test_native_rccl_single_rank(nle, oracle):
             assert rel_l2(Y1, Y0) < 1e-6
         f1.close()
     c1.close()
+
+
+@pytest.mark.gpu
+def test_native_rccl_bad_arguments_leave_the_ctx_usable(nle, oracle):
+    """failure injection at world = 1: every malformed bootstrap call is refused with NLE_ERR_INVALID
+    before anything collective is started, and the ctx filters afterwards exactly as one that never saw them"""
+    import ctypes as C
+    H, W, nr, nc, hx, hy, T, K, L = 64, 96, 5, 6, 28.0, 30.0, 5, 8, 3
+    x = oracle.synthetic_luminance(H, W).astype(np.float32)
+    c0 = nle.Context(0)
+    f0 = nle.NLEFilter(c0).train_filter(x, nr, nc, hx, hy, T, K)
+    Y0 = f0.apply_layers(x, L).cpu().numpy()
+    f0.close()
+    c = nle.Context(0)
+    uid = nle.rccl_unique_id()
+    for rank, world in ((1, 1), (-1, 1), (0, 0), (2, 2)):
+        with pytest.raises(nle.NLEError) as ei:
+            c.init_rccl(rank, world, uid)
+        assert ei.value.code == nle.NLE_ERR_INVALID, (rank, world)
+    L_ = nle.lib()
+    short = (C.c_char * 64)()
+    assert L_.nle_ctx_init_rccl(c._h, 0, 1, short, 64) == nle.NLE_ERR_INVALID   # id buffer too small
+    assert L_.nle_ctx_init_rccl(c._h, 0, 1, None, 128) == nle.NLE_ERR_INVALID
+    assert L_.nle_ctx_init_rccl(None, 0, 1, short, 128) == nle.NLE_ERR_INVALID
+    assert L_.nle_rccl_unique_id(short, 64) == nle.NLE_ERR_INVALID
+    assert L_.nle_ctx_set_rccl_comm(c._h, 0, 1, None) == nle.NLE_ERR_INVALID
+    f = nle.NLEFilter(c).train_filter(x, nr, nc, hx, hy, T, K)
+    assert np.array_equal(f.apply_layers(x, L).cpu().numpy(), Y0)
+    f.close()
+    c.close()
+    c0.close()
+
+
+@pytest.mark.gpu
+def test_native_rccl_reinit_and_lifetimes(nle, oracle):
+    """communicator lifetime at world = 1: a second nle_ctx_init_rccl on the same ctx replaces (and destroys) the first
+    communicator; a ctx with a communicator can be destroyed while another one lives; a filter trained before the
+    re-initialisation still applies; the next ctx bootstraps again from a fresh id.  All outputs bitwise equal."""
+    H, W, nr, nc, hx, hy, T, K, L = 64, 96, 5, 6, 28.0, 30.0, 5, 8, 3
+    x = oracle.synthetic_luminance(H, W).astype(np.float32)
+    ca = nle.Context(0)
+    ca.init_rccl(0, 1, nle.rccl_unique_id())
+    fa = nle.NLEFilter(ca).train_filter(x, nr, nc, hx, hy, T, K)
+    Ya = fa.apply_layers(x, L).cpu().numpy()
+    ca.init_rccl(0, 1, nle.rccl_unique_id())          # replaces the communicator under a live filter
+    assert np.array_equal(fa.apply_layers(x, L).cpu().numpy(), Ya)
+    cb = nle.Context(0)
+    cb.init_rccl(0, 1, nle.rccl_unique_id())          # two communicators of one process on one device, one after the other
+    fb = nle.NLEFilter(cb).train_filter(x, nr, nc, hx, hy, T, K)
+    fa.close()
+    ca.close()                                        # destroy order: the older ctx first, the younger keeps working
+    assert np.array_equal(fb.apply_layers(x, L).cpu().numpy(), Ya)
+    fb.close()
+    cb.close()
+    cc = nle.Context(0)
+    cc.init_rccl(0, 1, nle.rccl_unique_id())
+    fc = nle.NLEFilter(cc).train_filter(x, nr, nc, hx, hy, T, K)
+    assert np.array_equal(fc.apply_layers(x, L).cpu().numpy(), Ya)
+    fc.close()
+    cc.close()
