@@ -87,7 +87,7 @@ def build_host(force: bool = False):
     """C++ surface (filter.hpp names) + enhance CLI + unit-test binary, linked to the .so."""
     os.makedirs(BINDIR, exist_ok=True)
     out = []
-    common = [os.path.join(HOST, "filter.cpp"), os.path.join(HOST, "image_io.cpp")]
+    common = [os.path.join(HOST, "filter.cpp"), os.path.join(HOST, "image_io.cpp"), os.path.join(HOST, "jpeg.cpp")]
     hdrs = [os.path.join(ROOT, "include", "nle", "filter.hpp"), os.path.join(ROOT, "include", "nle", "image_io.hpp"),
             os.path.join(ROOT, "include", "nle.h"), os.path.join(HOST, "cli_common.hpp")]
     for name, main in (("enhance", "enhance.cpp"), ("denoise", "denoise.cpp"), ("test_filter", "test_filter.cpp")):

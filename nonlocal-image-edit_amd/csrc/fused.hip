@@ -1008,7 +1008,8 @@ static hipError_t launch_hist_g(hipStream_t s, GridSpec gs, int p, int nrows_loc
     const int gx = (n / 16 + 3) / 4;
     // ~2560 waves on the chip (or one row tile per wave if the slab is short); at most 16 tiles (256 rows x nR <= 32
     // doubles = 64 KB of LDS) per workgroup
-    const int chunks = std::max(1, std::min(ntiles, std::max((640 + gx - 1) / gx, (ntiles + 15) / 16)));
+    const int cap = gs.nSelRows > 24 ? 8 : 16;  // the staged er rows: <= 32 KB of LDS per workgroup (cfg5: -3 % on the Sinkhorn stage)
+    const int chunks = std::max(1, std::min(ntiles, std::max((640 + gx - 1) / gx, (ntiles + cap - 1) / cap)));
     const int tpw = (ntiles + chunks - 1) / chunks;
     const size_t shm = (size_t)tpw * 16 * gs.nSelRows * sizeof(double);
     if (shm > 48 * 1024) {

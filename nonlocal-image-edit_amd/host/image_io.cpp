@@ -1,5 +1,5 @@
 // Image file I/O for the enhance CLI (stand-in for OpenCV highgui/imgcodecs, which the reference
-// uses at src/enhance.cpp:33,47).  No arithmetic of the filter lives here.
+// uses at src/enhance.cpp:33,47).  No arithmetic of the filter lives here.  BMP / PPM / PNG here, JPEG in jpeg.cpp.
 #include "nle/image_io.hpp"
 
 #include <cstdint>
@@ -9,6 +9,8 @@
 #include <vector>
 
 namespace nle {
+
+Image read_jpeg(const std::vector<unsigned char>& b);  // jpeg.cpp
 
 namespace {
 
@@ -413,6 +415,7 @@ Image imread(const std::string& path) {
     if (b[0] == 'B' && b[1] == 'M') return read_bmp(b);
     if (b[0] == 'P' && b[1] == '6') return read_ppm(b);
     if (b[0] == 0x89 && b[1] == 'P') return read_png(b);
+    if (b[0] == 0xff && b[1] == 0xd8) return read_jpeg(b);
     return Image();
 }
 

@@ -3,8 +3,8 @@ Both files of every pair are data fixtures copied from the reference's data/ dir
 (flower, BASELINE.json configs[0]) and tests/golden/readme/ (the others).  `mountain` is the row the README
 keeps commented out (README.md:84); its files are in data/ all the same.
 
-The two JPEG rows (paper.jpg, rock2.jpg) are not here: no JPEG decoder exists in this image's toolchain for
-the C++ CLI, and a JPEG decoded by a different library than the author's OpenCV is not the same input.
+The two JPEG rows (paper.jpg progressive 4:2:0, rock2.jpg baseline 4:4:4) are read by host/jpeg.cpp, whose pixels are
+bit-identical to libjpeg's default decode (tests/test_jpeg.py) -- the decoder behind the author's cv::imread.
 """
 import os
 
@@ -22,6 +22,8 @@ PAIRS = [
     ("snow-mountain", "readme/snow-mountain-15.bmp",   "readme/snow-mountain-filtered.png",   10, 20, 200.0, 30.0, 30, 10, [3, 10, 1, 1]),
     ("red-cherries",  "readme/red-cherries-10.bmp",    "readme/red-cherries-filtered.png",    20, 10, 400.0, 30.0, 50, 20, [2, 2, 2, 1]),
     ("mountain",      "readme/mountain-15.bmp",        "readme/mountain-filtered.png",        10, 20, 1000.0, 20.0, 50, 80, [2, 2, 2, 1]),
+    ("paper",         "readme/paper.jpg",              "readme/paper-filtered.png",           20, 20, 1000.0, 40.0, 50, 20, [0.5, 1, 5, 1]),
+    ("rock2",         "readme/rock2.jpg",              "readme/rock2-filtered.png",           20, 30, 500.0, 10.0, 50, 50, [4, 3, 4, 1]),
 ]
 
 

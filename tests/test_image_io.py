@@ -13,6 +13,7 @@ import pytest
 from conftest import GOLDEN, ROOT
 
 SRC = os.path.join(ROOT, "nonlocal-image-edit_amd", "host", "image_io.cpp")
+SRC_JPEG = os.path.join(ROOT, "nonlocal-image-edit_amd", "host", "jpeg.cpp")
 MAIN = r"""
 #include <cstdio>
 #include "nle/image_io.hpp"
@@ -31,7 +32,7 @@ def tool(tmp_path_factory):
     main.write_text(MAIN)
     exe = d / "imgio"
     subprocess.run(["g++", "-O2", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I",
-                    os.path.join(ROOT, "include"), str(main), SRC, "-o", str(exe)], check=True)
+                    os.path.join(ROOT, "include"), str(main), SRC, SRC_JPEG, "-o", str(exe)], check=True)
     return str(exe)
 
 

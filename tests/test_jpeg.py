@@ -1,0 +1,135 @@
+"""The CLI's JPEG reader (host/jpeg.cpp; stand-in for cv::imread, src/enhance.cpp:33, on the README's two JPEG rows): the
+decoded pixels ARE the filter's input, so they are held bit for bit to Pillow's decode (libjpeg-turbo with the same default
+arithmetic OpenCV's imread runs: slow-integer IDCT, fancy upsampling) -- on the reference's own two files (data fixtures
+under tests/golden/readme/) and on every kind of file the reader claims: baseline and progressive, 4:4:4 / 4:2:2 / 4:2:0,
+grey, restart intervals, optimised tables, tiny and odd sizes.  Damaged files are refused or decoded, never crash
+(AddressSanitizer + UBSan build).  Host only."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+HOST = os.path.join(ROOT, "nonlocal-image-edit_amd", "host")
+MAIN = r"""
+#include <cstdio>
+#include "nle/image_io.hpp"
+int main(int argc, char** argv) {
+    int rc = 0;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        nle::Image im = nle::imread(argv[i]);
+        if (im.empty()) { std::printf("EMPTY %s\n", argv[i]); continue; }
+        if (!nle::imwrite(argv[i + 1], im)) rc = 3;
+    }
+    return rc;
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def tool(tmp_path_factory):
+    d = tmp_path_factory.mktemp("jpeg")
+    main = d / "main.cpp"
+    main.write_text(MAIN)
+    exe = d / "jpegio"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I",
+                    os.path.join(ROOT, "include"), str(main), os.path.join(HOST, "image_io.cpp"),
+                    os.path.join(HOST, "jpeg.cpp"), "-o", str(exe)], check=True)
+    return str(exe)
+
+
+def _rgb(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"))
+
+
+def _decode(tool, files, tmp_path):
+    """run the reader over `files`; returns {file: array or None (refused)}"""
+    args, outs = [], {}
+    for i, f in enumerate(files):
+        o = str(tmp_path / f"o{i}.ppm")
+        if os.path.exists(o):
+            os.remove(o)
+        args += [f, o]
+        outs[f] = o
+    r = subprocess.run([tool] + args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    return {f: (_rgb(o) if os.path.exists(o) else None) for f, o in outs.items()}
+
+
+@pytest.mark.parametrize("name", ["paper.jpg", "rock2.jpg"])
+def test_reference_jpegs_decode_as_pillow_does(tool, tmp_path, name):
+    """README.md:81-82: paper.jpg is progressive 4:2:0, rock2.jpg baseline 4:4:4"""
+    f = os.path.join(GOLDEN, "readme", name)
+    got = _decode(tool, [f], tmp_path)[f]
+    assert got is not None and np.array_equal(got, _rgb(f))
+
+
+def test_every_supported_kind_matches_pillow(tool, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(1)
+
+    def picture(h, w):
+        y, x = np.mgrid[0:h, 0:w]
+        base = np.stack([128 + 100 * np.sin(x / 7.0 + y / 11.0), 128 + 90 * np.cos(x / 5.0 - y / 3.0), 40 + 2 * x + y], -1)
+        return np.clip(base + rng.normal(0, 12, (h, w, 3)), 0, 255).astype(np.uint8)
+
+    files = []
+    for (h, w) in [(1, 1), (2, 2), (3, 5), (5, 3), (8, 8), (17, 33), (40, 4), (4, 40), (7, 6), (64, 48), (131, 97)]:
+        img = picture(h, w)
+        for sub in ("4:4:4", "4:2:2", "4:2:0"):
+            for prog in (False, True):
+                for k, extra in enumerate(({}, {"restart_marker_blocks": 3}, {"optimize": True}, {"quality": 12},
+                                           {"quality": 100}, {"restart_marker_rows": 1})):
+                    f = str(tmp_path / f"t_{h}x{w}_{sub.replace(':', '')}_{int(prog)}_{k}.jpg")
+                    try:
+                        Image.fromarray(img).save(f, "JPEG", subsampling=sub, progressive=prog, **({"quality": 85} | extra))
+                    except OSError:      # an option combination this Pillow cannot write
+                        continue
+                    files.append(f)
+        for prog in (False, True):
+            f = str(tmp_path / f"g_{h}x{w}_{int(prog)}.jpg")
+            Image.fromarray(img[..., 0]).save(f, "JPEG", progressive=prog)
+            files.append(f)
+    assert len(files) > 350
+    got = _decode(tool, files, tmp_path)
+    bad = [os.path.basename(f) for f in files if got[f] is None or not np.array_equal(got[f], _rgb(f))]
+    assert not bad, bad[:10]
+
+
+def test_damaged_files_never_crash(tool, tmp_path):
+    """truncations, flipped bytes in the entropy data and in the headers: refused (empty image) or decoded to something,
+    and the sanitizers stay quiet; what cannot be a JPEG at all is refused"""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    seeds = []
+    for sub in ("4:4:4", "4:2:0"):
+        for prog in (False, True):
+            f = str(tmp_path / "seed.jpg")
+            Image.fromarray(img).save(f, "JPEG", subsampling=sub, progressive=prog, quality=60,
+                                      restart_marker_blocks=0 if prog else 4)
+            seeds.append(open(f, "rb").read())
+    files = []
+    for it in range(600):
+        b = bytearray(seeds[it % len(seeds)])
+        if it % 3 == 0:
+            b = b[:rng.integers(2, len(b))]
+        elif it % 3 == 1:
+            for _ in range(rng.integers(1, 6)):
+                b[rng.integers(2, len(b))] = rng.integers(0, 256)
+        else:
+            b[rng.integers(2, min(len(b), 400))] = rng.integers(0, 256)
+        f = str(tmp_path / f"d{it}.jpg")
+        open(f, "wb").write(bytes(b))
+        files.append(f)
+    for k, blob in enumerate((b"\xff\xd8", b"\xff\xd8\xff\xd9", b"\xff\xd8\xff\xc0\x00\x02", b"\xff\xd8" + b"\xff" * 64,
+                              # 65535 x 65535 frame: refused before any allocation
+                              b"\xff\xd8\xff\xc0\x00\x11\x08\xff\xff\xff\xff\x03\x01\x22\x00\x02\x11\x01\x03\x11\x01\xff\xd9")):
+        f = str(tmp_path / f"junk{k}.jpg")
+        open(f, "wb").write(blob)
+        files.append(f)
+    got = _decode(tool, files, tmp_path)       # asserts a clean exit of the sanitizer build
+    assert all(got[f] is None for f in files[-5:])
