@@ -1,6 +1,6 @@
 """Pins the CPU oracle where the reference actually operates: every sample pair of the reference's README table
-(README.md:72-83: input image, enhance arguments, the author's output image; fixtures under tests/golden/).  Six of
-the nine pairs are rank-truncated -- eigenvalues of Ka, Wa and Q sit right at the 1e-10 cut (src/filter.cpp:214 via
+(README.md:72-83: input image, enhance arguments, the author's output image; fixtures under tests/golden/).  Most of
+the eleven pairs are rank-truncated -- eigenvalues of Ka, Wa and Q sit right at the 1e-10 cut (src/filter.cpp:214 via
 :262, :287, :313) -- so these are the inputs on which the truncation rules, `q = phi.cols()` (:247) and the
 lower-triangle reading of the non-symmetric Wa (:287) matter.
 
