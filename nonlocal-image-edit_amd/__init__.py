@@ -20,89 +20,19 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnle_hip.so")
 
-NLE_OK, NLE_ERR_INVALID, NLE_ERR_HIP, NLE_ERR_NUMERIC, NLE_ERR_COMM = 0, 1, 2, 3, 4
-EPS = 1e-10
-KERNEL_COUNT = 12  # NLE_KERNEL_COUNT
+# the signature table and the integer constants are generated from include/nle.h (tools/gen_ctypes.py -> _abi.py;
+# tests/test_abi.py regenerates and compares), so this mirror cannot drift from the header
+from . import _abi
+from ._abi import (ALLREDUCE_FN, NLE_ERR_COMM, NLE_ERR_HIP, NLE_ERR_INVALID, NLE_ERR_NUMERIC, NLE_OK)  # noqa: F401
 
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
-
-# every symbol include/nle.h declares: name -> (restype, argtypes)
+EPS = 1e-10  # NLE_EPS
+KERNEL_COUNT = _abi.NLE_KERNEL_COUNT
 _P = C.c_void_p
-_SIGNATURES = {
-    "nle_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
-    "nle_ctx_destroy": (None, [_P]),
-    "nle_last_error": (C.c_char_p, [_P]),
-    "nle_ctx_synchronize": (C.c_int, [_P]),
-    "nle_ctx_trim": (C.c_int, [_P]),
-    "nle_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
-    "nle_dev_free": (None, [_P, _P]),
-    "nle_ctx_set_topk_solver": (C.c_int, [_P, C.c_int]),
-    "nle_ctx_set_slab_input": (C.c_int, [_P, C.c_int]),
-    "nle_rccl_unique_id": (C.c_int, [_P, C.c_size_t]),
-    "nle_ctx_init_rccl": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
-    "nle_ctx_set_rccl_comm": (C.c_int, [_P, C.c_int, C.c_int, _P]),
-    "nle_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
-    "nle_host_free": (None, [_P, _P]),
-    "nle_dev_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
-    "nle_dev_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
-    "nle_ctx_set_mode": (C.c_int, [_P, C.c_int]),
-    "nle_ctx_set_nystrom_bf16x3": (C.c_int, [_P, C.c_int]),
-    "nle_ctx_set_shard": (C.c_int, [_P, C.c_int, C.c_int, ALLREDUCE_FN, _P, _P, C.c_size_t]),
-    "nle_comm_len": (C.c_size_t, [C.c_int]),
-    "nle_sample_grid": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int)] * 6),
-    "nle_slab_rows": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_int)] * 2),
-    "nle_eigen_decomposition": (C.c_int, [_P, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),
-    "nle_eigen_decomposition_top": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, _P, _P, C.POINTER(C.c_int)]),
-    "nle_eigen_decomposition_top_device": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_int, _P, _P, C.POINTER(C.c_int)]),
-    "nle_sym_eigen_device": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_int, C.c_int, _P, _P, C.POINTER(C.c_int)]),
-    "nle_cholesky_device": (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
-    "nle_topk_eigen_decomposition": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, _P, C.POINTER(C.c_int)]),
-    "nle_transform_eigenvalues": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
-    "nle_layer_responses": (C.c_int, [_P, C.c_int, C.c_int, _P]),
-    "nle_compute_kernel": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P]),
-    "nle_nystrom": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P,
-                              C.POINTER(C.c_int), _P]),
-    "nle_ts_gemm": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, C.c_int, _P]),
-    "nle_sinkhorn_scalings": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
-    "nle_gram": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, _P]),
-    "nle_row_scalings": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, _P]),
-    "nle_compute_kernel64": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P]),
-    "nle_ts_gemm64": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, C.c_int, _P]),
-    "nle_sinkhorn_scalings64": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
-    "nle_gram64": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, _P]),
-    "nle_row_scalings64": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, _P, _P]),
-    "nle_train": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
-                            C.POINTER(_P)]),
-    "nle_train_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
-                                 C.c_int, C.POINTER(_P)]),
-    "nle_filter_destroy": (None, [_P]),
-    "nle_filter_info": (C.c_int, [_P, C.POINTER(C.c_longlong)] + [C.POINTER(C.c_int)] * 5),
-    "nle_filter_diag": (C.c_int, [_P, _P]),
-    "nle_filter_eigvals": (C.c_int, [_P, _P]),
-    "nle_filter_eigvec_range": (C.c_int, [_P, C.c_int, _P, _P]),
-    "nle_filter_eigvecs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int)]),
-    "nle_filter_copy_eigvecs": (C.c_int, [_P, _P]),
-    "nle_filter_timings": (C.c_int, [_P, _P]),
-    "nle_apply": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
-    "nle_apply_layers": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
-    "nle_apply_host": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
-    "nle_apply_layers_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
-    "nle_bgr2lab8": (C.c_int, [_P, _P, C.c_longlong, _P, _P]),
-    "nle_lab2bgr8": (C.c_int, [_P, _P, _P, C.c_longlong, _P]),
-    "nle_lab2bgr8_planes": (C.c_int, [_P, _P, _P, _P, _P, C.c_longlong, _P]),
-    "nle_lab8_channel": (C.c_int, [_P, _P, C.c_longlong, C.c_int, _P]),
-    "nle_bilateral8": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _P]),
-    "nle_bilateral_tables": (C.c_int, [C.c_double, C.c_double, _P, _P, _P]),
-    "nle_ld": (C.c_int, [C.c_int]),
-    "nle_kernel_name": (C.c_char_p, [C.c_int]),
-    "nle_ctx_profile": (C.c_int, [_P, C.c_int]),
-    "nle_ctx_kernel_stats": (C.c_int, [_P, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
-    "nle_bench_affinity": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P, C.c_int,
-                                     C.POINTER(C.c_double)]),
-    "nle_bench_sinkhorn_pass": (C.c_int, [_P, _P, C.c_longlong, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
-}
+_SIGNATURES = _abi.SIGNATURES
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-MODE_AUTO, MODE_MATERIALISED, MODE_PHI_FREE, MODE_PHI_FREE_EXP, MODE_MATERIALISED_F64, MODE_STREAMED_F64 = 0, 1, 2, 3, 4, 5   # NLE_MODE_* of include/nle.h
+MODE_AUTO, MODE_MATERIALISED, MODE_PHI_FREE, MODE_PHI_FREE_EXP, MODE_MATERIALISED_F64, MODE_STREAMED_F64 = (
+    _abi.NLE_MODE_AUTO, _abi.NLE_MODE_MATERIALISED, _abi.NLE_MODE_PHI_FREE, _abi.NLE_MODE_PHI_FREE_EXP,
+    _abi.NLE_MODE_MATERIALISED_F64, _abi.NLE_MODE_STREAMED_F64)
 
 _lib = None
 

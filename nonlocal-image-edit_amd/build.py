@@ -102,7 +102,15 @@ def build_host(force: bool = False):
     return out
 
 
+def gen_abi():
+    """the ctypes mirror's signature table, regenerated from include/nle.h"""
+    import subprocess
+    import sys
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_ctypes.py")], check=True)
+
+
 def build_all(force: bool = False):
+    gen_abi()
     lib = build_lib(force)
     bins = build_host(force)
     return lib, bins

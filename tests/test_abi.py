@@ -26,6 +26,15 @@ def test_every_declared_symbol_is_exported_and_bound(nle):
     assert sorted(nle.EXPORTED_SYMBOLS) == declared, "Python mirror and header disagree"
 
 
+def test_ctypes_mirror_is_generated_from_the_header():
+    """nonlocal-image-edit_amd/_abi.py (signatures + constants of the Python mirror) is what tools/gen_ctypes.py makes of
+    include/nle.h today"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_ctypes.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_library_is_gfx950_native(nle):
     """the shared object carries a gfx950 code object (hipcc --offload-arch=gfx950)"""
     blob = open(nle.LIB_PATH, "rb").read()
