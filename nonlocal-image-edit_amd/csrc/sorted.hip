@@ -32,10 +32,8 @@
 #include <cmath>
 #include <cstdlib>
 
-// Measurement hooks (tools/abl_run.sh, tools/stamps_run.sh, profiles/r2_pass_ablation.txt): -DNLE_ABL_NOLOOP builds
-// k_sorted_pass without its pixel work, -DNLE_ABL_NOTREE without the combine tree and the table stores, -DNLE_ABL_NOPRIO
-// without the priority changes, -DNLE_ABL_STAMPS prints phase timestamps of four workgroups.  Never defined in the
-// product build.
+// (The ablation / timestamp variants of k_sorted_pass behind profiles/r2_pass_ablation.txt are not in this file: they are
+// tools/micro/sorted_pass_ablation.patch, applied to a copy of it by tools/abl_build.sh.)
 #define NLE_PIXEL_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 namespace nlek {
@@ -376,16 +374,7 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
 #pragma unroll
     for (int b = 0; b < NC; ++b) gv[b] = recip ? g[(size_t)lrow * n + b * kLevels + dsc_level(dsc)] : 0.0;
     __syncthreads();  // sE, sfirst visible
-#ifdef NLE_ABL_STAMPS
-    unsigned long long stamps[8][4];
-    int srow = 0;
-    const bool stamp = tid == 0 && (blockIdx.x == 0 || blockIdx.x == 256 || blockIdx.x == 8 || blockIdx.x == 264) && mode == ROWPASS_RECIP && ybuf == nullptr;
-#define NLE_STAMP(k) if (stamp && srow < 8) stamps[srow][k] = wall_clock64()
-#else
-#define NLE_STAMP(k) ((void)0)
-#endif
     for (int par = 0;; par ^= 1) {
-        NLE_STAMP(0);
         const bool has_next = nrow < nrows;
         const int nnrow = nrow + G;
         const unsigned short* sfc = sfirst + par * 260;
@@ -444,9 +433,6 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wlen = max(wlen, __shfl_xor(wlen, off));
         wlen = __builtin_amdgcn_readfirstlane(wlen);
-#ifdef NLE_ABL_NOLOOP
-        wlen = 0;
-#endif
 #pragma unroll
         for (int b = 0; b < kMaxBlocks; ++b) {
             if (4 * b >= wlen) break;
@@ -465,14 +451,11 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
                 NLE_PIXEL_FENCE();
             }
         }
-        NLE_STAMP(1);
-#ifndef NLE_ABL_NOPRIO
         // The combine / load / store phase is a chain of barriers and memory round trips; the other workgroup of the CU is
         // (usually) in its pixel loop and, being older or younger, wins or loses every issue slot wholesale (the stamps of
         // tools/stamps_run.sh: the second workgroup's combine took 4-5 us against 2.2 us alone).  Raise the priority here,
         // drop it for the loop.
         __builtin_amdgcn_s_setprio(3);
-#endif
         int steps = dsc_steps(dsc), j = dsc_j(dsc), m = dsc_m(dsc);
         asm volatile("" : "+v"(steps), "+v"(j), "+v"(m));  // decoded before the loads below are issued, not after
         // the next row's table row: in flight under the combine.  (Requested before the pixel loop -- registers
@@ -482,10 +465,6 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
             for (int b = 0; b < NC; ++b) gv[b] = g[(size_t)nrow * n + b * kLevels + dsc_level(dsc_n)];
         }
         double* hrow = hout + (size_t)lrow * n;
-#ifdef NLE_ABL_NOTREE
-        if (acc[0] == 12345.678) hrow[tid] = acc[0] + acc[NC - 1];
-        steps = 0;
-#endif
 #pragma unroll
         for (int s0 = 0; s0 < NC; s0 += SL) {
             double v[SL];
@@ -504,26 +483,17 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
                 // next row's first-chunk table (its last readers left before the previous row's end barrier; its next
                 // readers come after the barriers of the next combine)
                 if (has_next && tid < 258) sfirst[(par ^ 1) * 260 + tid] = sf_n;
-                NLE_STAMP(2);
             }
             const int ns = (NC - s0 < SL) ? NC - s0 : SL;
-#ifndef NLE_ABL_NOTREE
             for (int i = tid; i < ns * kLevels; i += kT) {
                 const int bb = i / kLevels, xx = i & (kLevels - 1);
                 const int f0 = sfc[xx];
                 hrow[(size_t)(s0 + bb) * kLevels + xx] = sfc[xx + 1] > f0 ? sP[f0 * PS + bb] : 0.0;
             }
-#endif
             __syncthreads();  // before the next slice / row overwrites sP and sfirst
         }
-        NLE_STAMP(3);
-#ifndef NLE_ABL_NOPRIO
         __builtin_amdgcn_s_setprio(0);  // (letting the two workgroups take turns at priority 1 in their loops balanced
                                         // their finish times, 65 / 71 us instead of 61 / 74, but not the kernel's)
-#endif
-#ifdef NLE_ABL_STAMPS
-        if (stamp) ++srow;
-#endif
         if (!has_next) break;
         lrow = nrow;
         nrow = nnrow;
@@ -532,13 +502,6 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
 #pragma unroll
         for (int b = 0; b < kMaxBlocks; ++b) idx[b] = idx_n[b];
     }
-#ifdef NLE_ABL_STAMPS
-    if (stamp)
-        for (int r = 0; r < srow && r < 8; ++r)
-            printf("STAMP wg %d row %d: top %llu loop %llu tree+loads %llu stores+barrier %llu (x10 ns, from row top: %llu %llu %llu)\n",
-                   (int)blockIdx.x, r, stamps[r][0] - stamps[0][0], stamps[r][1] - stamps[0][0], stamps[r][2] - stamps[0][0],
-                   stamps[r][3] - stamps[0][0], stamps[r][1] - stamps[r][0], stamps[r][2] - stamps[r][1], stamps[r][3] - stamps[r][2]);
-#endif
 }
 
 static int sorted_grid(int nrows) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/abl_run.sh V1 V2 ...  -- per-kernel averages of the default bench with the measurement build lib/abl_<V>.so
+# usage: tools/abl_run.sh V1 V2 ...  -- per-kernel averages of the default bench with the measurement build lib/abl_<V>.so (made by tools/abl_build.sh)
 # loaded through NLE_LIB_PATH (the product library lib/libnle_hip.so is never touched)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 L=$ROOT/nonlocal-image-edit_amd/lib

@@ -1,5 +1,5 @@
 #!/bin/bash
-# phase timestamps of k_sorted_pass for two co-resident workgroup pairs (library built with -DNLE_ABL_STAMPS as
+# phase timestamps of k_sorted_pass for two co-resident workgroup pairs (tools/abl_build.sh STAMPS builds
 # lib/abl_STAMPS.so, loaded through NLE_LIB_PATH: the product library is never touched)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 L=$ROOT/nonlocal-image-edit_amd/lib
