@@ -22,7 +22,7 @@ LIBDIR = os.path.join(HERE, "lib")
 BINDIR = os.path.join(HERE, "bin")
 LIB = os.path.join(LIBDIR, "libnle_hip.so")
 
-LIB_SOURCES = ["kernels.hip", "tsgemm_bf16x3.hip", "fused.hip", "sorted.hip", "generic64.hip", "tridiag.hip", "dense64.hip", "colour.hip", "pipeline.hip", "devsolve.hip", "eigen_sym.cpp"]
+LIB_SOURCES = ["kernels.hip", "tsgemm_bf16x3.hip", "fused.hip", "sorted.hip", "generic64.hip", "tridiag.hip", "dense64.hip", "colour.hip", "pipeline.hip", "ortho.hip", "abi_ctx.hip", "devsolve.hip", "eigen_sym.cpp"]
 ARCH = "gfx950"
 
 

@@ -2,7 +2,7 @@
 // fused train pipeline (NLEFilter::trainFilter, reference src/filter.cpp:480-502) and
 // apply (:445-458).  Small (p x p, r x r) algebra and the three symmetric eigensolves run
 // on the host in fp64; everything N-sized is a HIP kernel (kernels.hip).
-#include "devsolve.h"
+#include "ortho.h"
 
 using nlek::GridSpec;
 using namespace nlep;
@@ -96,24 +96,7 @@ std::vector<double> build_Ka(const SampleSet& s, double hx, double hy) {
 // so when Ka is provably full rank at the reference's threshold (every eigenvalue >= 1e-10, certified
 // by 1 / trace(Ka^-1)) the Cholesky factor serves as well: VA = L, lam = 1, B = L^-T (P = I) -- a
 // p^3/3 factorisation instead of a p x p eigensolve.  The materialised path keeps the eigenpairs.
-// Ka and its Cholesky factors left on the device by solve_Ka's device route (then VA and B stay empty on the host)
-struct KaDevice {
-    DevBuf<double> Ka;
-    DevChol ch;
-};
 
-struct Nystrom {
-    int r = 0, ldr = 0;
-    bool chol = false;
-    std::shared_ptr<KaDevice> dev;  // set: L = dev->ch.L, L^-1 = dev->ch.Linv (p x p column-major, device)
-    std::vector<double> VA;   // p x r col-major
-    std::vector<double> lam;  // r
-    std::vector<double> B;    // p x r col-major
-    std::vector<double> Ka;   // p x p (kept for the W blocks)
-};
-
-// every eigenvalue of an SPD matrix with trace(M^-1) <= kCholMaxInvTrace is >= 1e-9 > NLE_EPS
-constexpr double kCholMaxInvTrace = 1e9;
 
 Nystrom solve_Ka(nle_ctx* c, const std::vector<double>& Ka, int p, bool allow_chol) {
     Nystrom n;
@@ -324,726 +307,9 @@ std::vector<double> gram_all(nle_ctx* c, const float* d_phi, long long M, int ld
     return G;
 }
 
-// ---- small host algebra, column-major ----
-// The p x p products of the orthogonalisation run on the register-blocked kernels of eigen_sym.cpp (a 200^3
-// product is ~0.2 ms on one core); only products of more than ~80 MFLOP per thread are split by output columns
-// over short-lived threads (nleh::run_parts; thread start-up and remote caches cost more than that on the GPU box).
-template <typename F>
-void par_cols(int n, long long work_per_col, F&& body) {
-    const long long work = work_per_col * n;  // multiply-adds
-    int nt = (int)std::min<long long>(16, work / 40000000 + 1);
-    if (const char* e = std::getenv("NLE_HOST_THREADS")) nt = std::max(1, std::atoi(e));
-    nt = std::min(nt, n);
-    if (nt <= 1) {
-        body(0, n);
-        return;
-    }
-    nleh::run_parts(nt, nt, [&](int t) { body((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); });
-}
-// C (m x n) = A (m x k) * B (k x n)
-void mm(const double* A, const double* B, double* C, int m, int k, int n) {
-    par_cols(n, (long long)m * k, [&](int j0, int j1) { nleh::gemm_nn_cols(A, B, C, m, k, n, j0, j1); });
-}
-// C (m x n) = A (m x k) * B^T (B is n x k)
-void mm_nt(const double* A, const double* B, double* C, int m, int k, int n) {
-    par_cols(n, (long long)m * k, [&](int j0, int j1) { nleh::gemm_nt_cols(A, B, C, m, k, n, j0, j1); });
-}
-// C (k x n) = A^T (A is m x k) * B (m x n)
-void mm_tn(const double* A, const double* B, double* C, int m, int k, int n) {
-    par_cols(n, (long long)m * k, [&](int j0, int j1) { nleh::gemm_tn_cols(A, B, C, m, k, n, j0, j1); });
-}
-
 }  // namespace
 
-// The W blocks and the orthogonalisation on the host.  Inputs: V_A (p x r), lambda, u_c, u_r,
-// G = sum over ALL pixels of c^2 phi phi^T.  Outputs: Sq (K'), Cproj (r x K'), VArows (q x K').
-// reference src/filter.cpp:247-250 (W blocks, q = phi.cols()), :282-331 (orthogonalize).
 namespace {
-// Top eigenpairs of Q (reference src/filter.cpp:310-317).  solver 0: the default build's eigenDecomposition(Q) -- all
-// eigenvalues, the leading run >= eps counted in *rq, eigenvectors of the first min(n_eig, q) only.  solver 1: the
-// USE_SPECTRA build's topkEigenDecomposition (:170-199): nev = min(n_eig, q - 1) pairs of largest magnitude by Lanczos,
-// *rq = converged pairs in the leading run >= eps.  Vq: q x (columns formed), Sq: their eigenvalues, descending.
-void top_eigenpairs(const std::vector<double>& Qm, int q, int n_eig, int solver, std::vector<double>* Vq,
-                    std::vector<double>* Sq, int* rq) {
-    if (solver == 1 && q > 1) {
-        const int nev = std::min(std::max(n_eig, 1), q - 1);
-        Vq->assign((size_t)q * nev, 0.0);
-        Sq->assign(nev, 0.0);
-        int restarts = 0;
-        const int nconv = nleh::lanczos_topk(Qm.data(), q, nev, NLE_EPS, 1000, Vq->data(), Sq->data(), &restarts);
-        if (nconv < 0) throw Fail{NLE_ERR_NUMERIC, "Lanczos: the projected eigenproblem did not converge"};
-        if (nconv < nev)  // Spectra only warns on stderr and goes on with the converged pairs (:180-183)
-            std::fprintf(stderr, "# converged eigenvalues: %d\nEigen decomposition NOT successful. Results might be inaccurate.\n", nconv);
-        int r = 0;
-        while (r < nconv && (*Sq)[r] >= NLE_EPS) ++r;  // :186-196
-        *rq = r;
-        if (std::getenv("NLE_TRACE")) std::fprintf(stderr, "[nle trace] Lanczos top-%d of %d: %d restarts, %d converged\n", nev, q, restarts, nconv);
-        return;
-    }
-    Vq->assign((size_t)q * std::min(q, std::max(n_eig, 1)), 0.0);  // only the kept eigenvectors (:314)
-    Sq->assign(q, 0.0);
-    if (!nleh::eigen_decomposition_top(Qm.data(), q, NLE_EPS, n_eig, Vq->data(), Sq->data(), rq))
-        throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Q"};
-}
-
-struct Ortho {
-    int q = 0, K = 0, r_wa = 0, r_q = 0;
-    std::vector<double> Sq, Cproj, VArows, Wa;
-};
-
-Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_c,
-                         const std::vector<double>& u_r, std::vector<double> G, int n_eig, bool device_f32 = true,
-                         int topk_solver = 0) {
-    const int r = ny.r, q = ny.r;  // :247 -- the A block is the first q = r permuted rows
-    // phi_A = V_A[:q] (exact, fp64); what the device holds for those rows is float(V_A)
-    std::vector<double> cA(q), rA(q), cA32(q);
-    std::vector<double> left((size_t)q * r), right((size_t)q * r), phi32((size_t)q * r);
-    for (int a = 0; a < q; ++a) {
-        double sc = 0.0, sr = 0.0, sc32 = 0.0;
-        for (int k = 0; k < r; ++k) {
-            const double v = ny.VA[(size_t)k * p + a];
-            const double v32 = device_f32 ? (double)(float)v : v;  // what the device holds for that row
-            phi32[(size_t)k * q + a] = v32;
-            sc += v * u_c[k];
-            sr += v * u_r[k];
-            sc32 += v32 * u_c[k];
-        }
-        cA[a] = recip0(sc);
-        rA[a] = recip0(sr);
-        cA32[a] = recip0(sc32);
-    }
-    for (int k = 0; k < r; ++k)
-        for (int a = 0; a < q; ++a) {
-            const double v = ny.VA[(size_t)k * p + a];
-            left[(size_t)k * q + a] = rA[a] * v * ny.lam[k];  // R * (phi_top * D)
-            right[(size_t)k * q + a] = cA[a] * v;             // c o phi_top
-        }
-    Ortho o;
-    o.q = q;
-    o.Wa.resize((size_t)q * q);
-    mm_nt(left.data(), right.data(), o.Wa.data(), q, r, q);  // :249
-    // remove the A rows from the all-pixel Gram: G_B = G - sum_a c_a^2 phi_a phi_a^T
-    for (int a = 0; a < q; ++a) {
-        const double c2 = cA32[a] * cA32[a];
-        for (int j = 0; j < r; ++j) {
-            const double vj = c2 * phi32[(size_t)j * q + a];
-            for (int i = 0; i < r; ++i) G[(size_t)j * r + i] -= phi32[(size_t)i * q + a] * vj;
-        }
-    }
-    // Wab Wab^T = left * G_B * left^T  (:296)
-    std::vector<double> LG((size_t)q * r), WW((size_t)q * q);
-    mm(left.data(), G.data(), LG.data(), q, r, r);
-    mm_nt(LG.data(), left.data(), WW.data(), q, r, q);
-    // S = Wa^{-1/2} (pseudo-inverse root), :287-292
-    std::vector<double> U2((size_t)q * q), l2(q);
-    int r2 = 0;
-    if (!nleh::eigen_decomposition(o.Wa.data(), q, NLE_EPS, U2.data(), l2.data(), &r2))
-        throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Wa"};
-    std::vector<double> Us((size_t)q * std::max(r2, 1)), S((size_t)q * q);
-    for (int k = 0; k < r2; ++k) {
-        const double s = std::sqrt(recip0(l2[k]));
-        for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * s;
-    }
-    o.r_wa = r2;
-    if (r2 <= 0) throw Fail{NLE_ERR_NUMERIC, "Wa has no eigenvalue >= 1e-10"};
-    std::vector<double> Vq, Sq, T2;
-    int rq = 0, K = 0;
-    if (topk_solver == 0) {
-        // Q = Wa + S (Wab Wab^T) S  (:296) on the subspace the Wa cut kept: with F = U2 L2^-1/2 (q x r2), S = F U2^T and
-        // Q = U2 (L2 + F^T WW F) U2^T + U1 L1 U1^T, so the eigenpairs of Q are those of Qt = L2 + F^T WW F (order r2)
-        // mapped by U2, plus the dropped (U1, L1 < 1e-10) -- which the literal S (.) S product, with entries of S up to
-        // 1e5, can lift back over the cut by its rounding alone (tools/parity_fuzz.py, seed 12 "big", case 59: 9.5e-11
-        // became 1.11e-10 here and 9.97e-11 in numpy).  S Vq = F Vt.
-        std::vector<double> WF((size_t)q * r2), Qt((size_t)r2 * r2);
-        mm(WW.data(), Us.data(), WF.data(), q, q, r2);
-        mm_tn(Us.data(), WF.data(), Qt.data(), q, r2, r2);
-        for (int k = 0; k < r2; ++k) Qt[(size_t)k * r2 + k] += l2[k];
-        std::vector<double> Vt;
-        top_eigenpairs(Qt, r2, n_eig, topk_solver, &Vt, &Sq, &rq);
-        K = std::min(n_eig, rq);  // :314
-        if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
-        T2.resize((size_t)q * K);
-        mm(Us.data(), Vt.data(), T2.data(), q, r2, K);
-    } else {
-        // the USE_SPECTRA build's solver works on the literal Q (full matrix, :170-199)
-        mm_nt(Us.data(), U2.data(), S.data(), q, r2, q);
-        std::vector<double> T1((size_t)q * q), Qm((size_t)q * q);
-        mm(S.data(), WW.data(), T1.data(), q, q, q);
-        mm(T1.data(), S.data(), Qm.data(), q, q, q);
-        for (size_t i = 0; i < Qm.size(); ++i) Qm[i] += o.Wa[i];
-        top_eigenpairs(Qm, q, n_eig, topk_solver, &Vq, &Sq, &rq);
-        K = std::min(n_eig, rq);  // :314
-        if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
-        T2.resize((size_t)q * K);
-        mm(S.data(), Vq.data(), T2.data(), q, q, K);
-    }
-    o.K = K;
-    o.r_q = rq;
-    o.Sq.assign(Sq.begin(), Sq.begin() + K);
-    // T2 = S * Vq * diag(Sq^-1/2)  (q x K)
-    for (int k = 0; k < K; ++k) {
-        const double s = std::sqrt(recip0(Sq[k]));
-        for (int i = 0; i < q; ++i) T2[(size_t)k * q + i] *= s;
-    }
-    o.Cproj.resize((size_t)r * K);
-    mm_tn(left.data(), T2.data(), o.Cproj.data(), q, r, K);  // M * T2, M = left^T
-    o.VArows.resize((size_t)q * K);
-    mm(o.Wa.data(), T2.data(), o.VArows.data(), q, q, K);  // top block of :327
-    return o;
-}
-
-// ---- orthogonalisation in sample space (Phi-free path) ----
-// Inputs: V_A (p x r), lambda, the two final Sinkhorn scaling vectors and
-//   Gk = sum over NON-sample pixels of c_i^2 k_i k_i^T  (p x p, from k_gram_fused).
-// With P = V_r V_r^T (projector on range(Ka); I when r == p) and Kr = V_r L V_r^T:
-//   phi_a L phi_j^T = (P k_j)[a]  for a sample a and a pixel j, so (reference :247-250, q = r)
-//   Wa  = R_A Kr[:q,:q] C_A,   Wab Wab^T = R_A (P Gk' P)[:q,:q] R_A,
-//   Gk' = Gk + sum_{samples a >= q} c_a^2 Kr[:,a] Kr[:,a]^T   (samples that fall in the B block),
-//   V_j = c_j k_j^T D,  D = P[:, :q] R_A T2,  T2 = S Vq Sq^-1/2   (:327), V_A rows = Wa T2.
-// No 1/lambda factor appears anywhere: the ill-conditioned B = V_A / lambda is only used for
-// the r-vectors of the Sinkhorn update.
-struct OrthoSS {
-    int q = 0, K = 0, r_wa = 0, r_q = 0;
-    bool chol_wa = false;
-    std::vector<double> Sq, D, Vrows;  // D: p x K, Vrows: p x K (col-major)
-    // state between the two halves
-    int p = 0, r = 0;
-    std::vector<double> cA, rA, Kr, P, Wa, S, St, A2;  // Q = A2 + S^T (Wab Wab^T) S,  St = S^T
-};
-
-// first half: everything that does not depend on the Gram matrix (runs on the host while the GPU
-// computes Gk): sample scalings, Kr, P, Wa and S = Wa^-1/2 (:287-292)
-void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<double>& sA_c,
-                      const std::vector<double>& sA_r) {
-    const int r = ny.r, q = ny.r;
-    o.p = p;
-    o.r = r;
-    o.q = q;
-    o.cA.resize(p);
-    o.rA.resize(p);
-    for (int a = 0; a < p; ++a) {  // sA = V_A u: the samples' row sums under the two final scalings
-        o.cA[a] = recip0(sA_c[a]);
-        o.rA[a] = recip0(sA_r[a]);
-    }
-    if (ny.chol) {
-        o.Kr = ny.Ka;  // r == p: Kr = Ka, P = I
-    } else {
-        std::vector<double> VL((size_t)p * r);
-        o.Kr.resize((size_t)p * p);
-        for (int k = 0; k < r; ++k)
-            for (int a = 0; a < p; ++a) VL[(size_t)k * p + a] = ny.VA[(size_t)k * p + a] * ny.lam[k];
-        mm_nt(VL.data(), ny.VA.data(), o.Kr.data(), p, r, p);
-        if (r < p) {
-            o.P.resize((size_t)p * p);
-            mm_nt(ny.VA.data(), ny.VA.data(), o.P.data(), p, r, p);
-        }
-    }
-    o.Wa.resize((size_t)q * q);
-    for (int b = 0; b < q; ++b)
-        for (int a = 0; a < q; ++a) o.Wa[(size_t)b * q + a] = o.rA[a] * o.Kr[(size_t)b * p + a] * o.cA[b];  // :249
-    // S with S S^T = A^-1, A = the symmetric matrix the reference's solver sees (lower triangle of Wa).
-    // The reference takes the symmetric root A^-1/2 (:287-292); any other root F gives the similar matrix
-    // G^T Q G (G = A^1/2 F orthogonal) with the same eigenvalues and the same product S Vq, hence the same
-    // eigenvectors V (:327).  When A is provably free of eigenvalues below the cut, F = L^-T (Cholesky).
-    o.S.resize((size_t)q * q);
-    // (A^-1)_ii >= 1 / A_ii, so sum_i 1 / A_ii above the certificate's bound already rules the Cholesky form out
-    double inv_diag = 0.0;
-    for (int a = 0; a < q; ++a) inv_diag += o.Wa[(size_t)a * q + a] > 0.0 ? 1.0 / o.Wa[(size_t)a * q + a] : 1e300;
-    if (std::getenv("NLE_FORCE_EIG") == nullptr && inv_diag <= kCholMaxInvTrace) {
-        std::vector<double> L((size_t)q * q), Li((size_t)q * q);
-        double inv_trace = 0.0;
-        if (nleh::cholesky_with_inverse(o.Wa.data(), q, L.data(), Li.data(), &inv_trace, kCholMaxInvTrace) && inv_trace <= kCholMaxInvTrace) {
-            std::vector<double> Lt((size_t)q * q);
-            for (int k = 0; k < q; ++k)
-                for (int a = 0; a < q; ++a) {
-                    o.S[(size_t)k * q + a] = Li[(size_t)a * q + k];  // L^-T
-                    Lt[(size_t)k * q + a] = L[(size_t)a * q + k];
-                }
-            o.St = std::move(Li);
-            o.A2.resize((size_t)q * q);
-            mm(Lt.data(), L.data(), o.A2.data(), q, q, q);  // F^T A^2 F = L^T L
-            o.r_wa = q;
-            o.chol_wa = true;
-            return;
-        }
-    }
-    std::vector<double> U2((size_t)q * q), l2(q);
-    int r2 = 0;
-    if (!nleh::eigen_decomposition(o.Wa.data(), q, NLE_EPS, U2.data(), l2.data(), &r2))
-        throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Wa"};
-    std::vector<double> Us((size_t)q * std::max(r2, 1));
-    for (int k = 0; k < r2; ++k) {
-        const double sv = std::sqrt(recip0(l2[k]));
-        for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * sv;
-    }
-    mm_nt(Us.data(), U2.data(), o.S.data(), q, r2, q);  // :287-292
-    o.r_wa = r2;
-    if (std::getenv("NLE_TRACE"))
-        fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e)\n", r2, q, l2[0],
-                r2 > 0 ? l2[r2 - 1] : 0.0);
-    o.St = o.S;
-    o.A2 = o.Wa;  // :296 (the solver reads the lower triangle of the sum)
-}
-
-// second half: needs Gk
-void ortho_ss_finish(OrthoSS& o, std::vector<double> Gk, int n_eig, int topk_solver = 0) {
-    const int p = o.p, r = o.r, q = o.q;
-    const std::vector<double>&cA = o.cA, &rA = o.rA, &Kr = o.Kr, &Wa = o.Wa, &S = o.S;
-    for (int a = q; a < p; ++a) {  // B-block samples
-        const double c2 = cA[a] * cA[a];
-        const double* ka = Kr.data() + (size_t)a * p;
-        for (int j = 0; j < p; ++j) {
-            const double vj = c2 * ka[j];
-            for (int i = 0; i < p; ++i) Gk[(size_t)j * p + i] += ka[i] * vj;
-        }
-    }
-    if (r < p) {
-        std::vector<double> T((size_t)p * p);
-        mm(o.P.data(), Gk.data(), T.data(), p, p, p);
-        mm(T.data(), o.P.data(), Gk.data(), p, p, p);
-    }
-    std::vector<double> WW((size_t)q * q);
-    for (int b = 0; b < q; ++b)
-        for (int a = 0; a < q; ++a) WW[(size_t)b * q + a] = rA[a] * Gk[(size_t)b * p + a] * rA[b];  // Wab Wab^T, :296
-    std::vector<double> T1((size_t)q * q), Qm((size_t)q * q);
-    mm(o.St.data(), WW.data(), T1.data(), q, q, q);
-    mm(T1.data(), S.data(), Qm.data(), q, q, q);
-    for (size_t i = 0; i < Qm.size(); ++i) Qm[i] += o.A2[i];  // :296
-    std::vector<double> Vq, Sq;
-    int rq = 0;
-    top_eigenpairs(Qm, q, n_eig, topk_solver, &Vq, &Sq, &rq);
-    const int K = std::min(n_eig, rq);  // :314
-    if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
-    o.K = K;
-    o.r_q = rq;
-    o.Sq.assign(Sq.begin(), Sq.begin() + K);
-    std::vector<double> T2((size_t)q * K), RT2((size_t)q * K);
-    mm(S.data(), Vq.data(), T2.data(), q, q, K);
-    for (int k = 0; k < K; ++k) {
-        const double sv = std::sqrt(recip0(Sq[k]));  // :319-321
-        for (int i = 0; i < q; ++i) {
-            T2[(size_t)k * q + i] *= sv;
-            RT2[(size_t)k * q + i] = rA[i] * T2[(size_t)k * q + i];
-        }
-    }
-    o.D.resize((size_t)p * K);
-    if (r < p) {
-        mm(o.P.data(), RT2.data(), o.D.data(), p, q, K);  // first q columns of P
-    } else {
-        o.D = RT2;
-    }
-    o.Vrows.assign((size_t)p * K, 0.0);
-    std::vector<double> WT((size_t)q * K);
-    mm(Wa.data(), T2.data(), WT.data(), q, q, K);  // top block of :327
-    for (int k = 0; k < K; ++k) {
-        for (int a = 0; a < q; ++a) o.Vrows[(size_t)k * p + a] = WT[(size_t)k * q + a];
-        for (int a = q; a < p; ++a) {
-            double sv = 0.0;
-            for (int j = 0; j < p; ++j) sv += Kr[(size_t)a * p + j] * o.D[(size_t)k * p + j];
-            o.Vrows[(size_t)k * p + a] = cA[a] * sv;
-        }
-    }
-}
-
-// The same orthogonalisation with every p- and q-sized product on the GPU (generic64.hip: gemm64s, fp64 MFMA); the host
-// keeps what is inherently serial -- the two symmetric eigensolves (Wa, Q) or their Cholesky shortcut.  `d_Gk`: the local
-// Gram matrix (p x p, device); `enqueue_gram` puts the Gram kernels on the stream (they run under the host's eigensolve of
-// Wa), `reduce_gram` sums d_Gk over the ranks.  On return o.K, o.Sq, o.D, o.Vrows (host, column-major p x K), o.r_wa,
-// o.r_q, o.chol_wa are set exactly as ortho_ss_prepare + ortho_ss_finish set them.
-// At cfg4 (p = 200) this takes ~0.6 ms of 200^3 host products off the critical path, at cfg5 (p = 900) ~50 ms.
-void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std::vector<double>& sA_c,
-                     const std::vector<double>& sA_r, double* d_Gk, int n_eig, const std::function<void()>& enqueue_gram,
-                     const std::function<void()>& reduce_gram, double* host_ms, double* host_overlapped_ms, Trace& tr) {
-    const int r = ny.r, q = ny.r;
-    hipStream_t st = c->stream;
-    o.p = p;
-    o.r = r;
-    o.q = q;
-    o.cA.resize(p);
-    o.rA.resize(p);
-    for (int a = 0; a < p; ++a) {
-        o.cA[a] = recip0(sA_c[a]);
-        o.rA[a] = recip0(sA_r[a]);
-    }
-    const size_t pp = (size_t)p * p, qq = (size_t)q * q;
-    DevBuf<double> d_rA(p), d_cA(p), d_Kr, d_P, d_VA, d_lam;
-    HIP_OK(hipMemcpyAsync(d_rA.p, o.rA.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(d_cA.p, o.cA.data(), p * sizeof(double), hipMemcpyHostToDevice, st));
-    if (ny.chol) {
-        o.Kr = ny.Ka;  // r == p: Kr = Ka, P = I
-    } else {  // Kr = V_r L V_r^T, P = V_r V_r^T on the device; Kr comes back for Wa
-        d_VA.alloc((size_t)p * r);
-        d_lam.alloc(r);
-        d_Kr.alloc(pp);
-        HIP_OK(hipMemcpyAsync(d_VA.p, ny.VA.data(), (size_t)p * r * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemcpyAsync(d_lam.p, ny.lam.data(), r * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_OK(nlek::gemm64s(st, p, p, r, d_VA.p, 1, p, d_VA.p, p, 1, d_Kr.p, 1, p, nullptr, d_lam.p));
-        if (r < p) {
-            d_P.alloc(pp);
-            HIP_OK(nlek::gemm64s(st, p, p, r, d_VA.p, 1, p, d_VA.p, p, 1, d_P.p, 1, p));
-        }
-        o.Kr.resize(pp);
-        HIP_OK(hipMemcpyAsync(o.Kr.data(), d_Kr.p, pp * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-    }
-    // ---- Wa and a factor F of its (pseudo-)inverse, beside the Gram kernels: on the host below dev_solver_min_n(), else on
-    // the device on the ctx's second stream (the Gram kernels are on the first)
-    double h0 = now_ms();
-    const bool dev_wa = use_dev_solver(q) && !std::getenv("NLE_HOST_WA");
-    // Wa = diag(rA) Kr[:q,:q] diag(cA) (:249).  On the device route with Ka resident there (solve_Ka's device Cholesky) it is
-    // formed on the device; the host copy is built only if the host root has to take over.
-    const bool wa_on_device = dev_wa && ny.dev != nullptr;
-    auto build_Wa_host = [&] {
-        if (!o.Wa.empty()) return;
-        o.Wa.resize(qq);
-        for (int b = 0; b < q; ++b)
-            for (int a = 0; a < q; ++a) o.Wa[(size_t)b * q + a] = o.rA[a] * o.Kr[(size_t)b * p + a] * o.cA[b];  // :249
-    };
-    if (!wa_on_device) build_Wa_host();
-    std::vector<double> L, Li, U2, Us, l2_kept;
-    int r2 = 0;
-    bool chol_wa = false;
-    double inv_diag = 0.0;
-    if (!wa_on_device)
-        for (int a = 0; a < q; ++a) inv_diag += o.Wa[(size_t)a * q + a] > 0.0 ? 1.0 / o.Wa[(size_t)a * q + a] : 1e300;
-    bool deflated = false;
-    std::vector<double> Fdefl, Gdefl;  // F (q x q) and G = L^T Vd (q x d):  F^T A^2 F = L^T L - G G^T
-    int nd = 0;
-    const int max_defl = q / 8;
-    const bool force_eig = std::getenv("NLE_FORCE_EIG") != nullptr;
-    // device form: the same three routes (Cholesky when the cut provably removes nothing; deflated Cholesky when it removes
-    // at most q / 8 eigenvalues; else all kept eigenvectors -- that last one stays on the host)
-    DevBuf<double> d_Wa(qq), d_F, d_L, d_G;
-    DevSymEig esw;
-    DevChol chw;
-    DevBuf<double> d_Ah, d_Vd, d_wgt, d_W, d_neg1;
-    bool dev_done = false;
-    if (dev_wa) {
-        hipStream_t sa = aux_stream(c);
-        // (workspace taken from the ctx cache now, while the first stream is idle: blocks of the cache are only ordered on it)
-        esw.prepare(c, q, sa);
-        chw.prepare(c, q, sa);
-        d_Ah.alloc(qq);
-        d_F.alloc(qq);
-        d_Vd.alloc((size_t)q * (max_defl + 1));
-        d_wgt.alloc(max_defl + 1);
-        d_W.alloc((size_t)(max_defl + 1) * q);
-        d_G.alloc((size_t)q * (max_defl + 1));
-        d_neg1.alloc(max_defl + 1);
-        HIP_OK(hipStreamSynchronize(st));
-        const bool wa_serial = std::getenv("NLE_WA_SERIAL") != nullptr;  // measurement: the Gram kernels after the root
-        if (!wa_serial) enqueue_gram();
-        if (wa_on_device)  // Wa(a, b) = rA[a] Ka(a, b) cA[b]: one product with both diagonals, no upload
-            HIP_OK(nlek::scale_rc64(sa, q, ny.dev->Ka.p, p, d_rA.p, d_cA.p, d_Wa.p));
-        else
-            upload_staged(c, d_Wa.p, o.Wa.data(), qq, sa);
-        HIP_OK(nlek::symm_lower64(sa, q, d_Wa.p, d_Ah.p));
-        // (no separate Cholesky attempt here: the host's stops at the first pivot that proves it futile, a device
-        // factorisation costs as much as the reduction -- so the eigenvalues come first and decide; none below the cut
-        // is the deflated route with nothing to deflate)
-        if (!force_eig && std::getenv("NLE_NO_DEFLATE") == nullptr) {
-            esw.reduce(c, q, d_Ah.p, nullptr);
-            tr.mark("ss:   Wa: tridiagonal form + eigenvalues (device)");
-            int kept = 0;
-            while (kept < q && esw.D[kept] >= NLE_EPS) ++kept;  // :213-216
-            nd = q - kept;
-            if (kept > 0 && nd <= max_defl && esw.D[0] > 0.0) {
-                const double sig = esw.D[0];
-                if (nd > 0) {
-                    esw.vectors(c, kept, nd, d_Vd.p);
-                    tr.mark("ss:   Wa: dropped eigenvectors (host inverse iteration)");
-                    std::vector<double> wgt(nd);
-                    for (int t = 0; t < nd; ++t) wgt[t] = sig - esw.D[kept + t];
-                    HIP_OK(hipMemcpyAsync(d_wgt.p, wgt.data(), nd * sizeof(double), hipMemcpyHostToDevice, sa));
-                    // Ahat = A + Vd (sig I - Ld) Vd^T
-                    HIP_OK(nlek::gemm64s(sa, q, q, nd, d_Vd.p, 1, q, d_Vd.p, q, 1, d_Ah.p, 1, q, nullptr, d_wgt.p, nullptr, d_Ah.p, 1, q));
-                    HIP_OK(hipStreamSynchronize(sa));  // `wgt` (host) is consumed
-                }
-                chw.factor(c, q, d_Ah.p);
-                const bool fact_ok = chw.finish(c);
-                if (!fact_ok && std::getenv("NLE_TRACE"))
-                    fprintf(stderr, "[nle trace] Wa: the deflated matrix did not factor (trace of the inverse %.3e, %d dropped, sigma %.3e)\n",
-                            chw.inv_trace, nd, sig);
-                if (fact_ok) {
-                    // F = L^-T - Vd (Vd^T L^-T),  G = L^T Vd
-                    HIP_OK(nlek::transpose64(sa, q, chw.Linv.p, d_F.p));
-                    if (nd > 0) {
-                        HIP_OK(nlek::fill64(sa, d_neg1.p, nd, -1.0));
-                        HIP_OK(nlek::gemm64s(sa, nd, q, q, d_Vd.p, q, 1, chw.Linv.p, q, 1, d_W.p, 1, nd));
-                        HIP_OK(nlek::gemm64s(sa, q, q, nd, d_Vd.p, 1, q, d_W.p, 1, nd, d_F.p, 1, q, nullptr, d_neg1.p, nullptr, d_F.p, 1, q));
-                        HIP_OK(nlek::gemm64s(sa, q, nd, q, chw.L.p, q, 1, d_Vd.p, 1, q, d_G.p, 1, q));
-                    }
-                    deflated = nd > 0;
-                    chol_wa = nd == 0;
-                    dev_done = true;
-                    r2 = kept;
-                    if (std::getenv("NLE_TRACE"))
-                        fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e), %d deflated (device)\n",
-                                kept, q, esw.D[0], esw.D[kept - 1], nd);
-                }
-            }
-        }
-        if (dev_done) {
-            d_L.alloc(qq);
-            HIP_OK(hipMemcpyAsync(d_L.p, chw.L.p, qq * sizeof(double), hipMemcpyDeviceToDevice, sa));
-        }
-        HIP_OK(hipEventRecord(c->aux_ev, sa));
-        HIP_OK(hipStreamWaitEvent(st, c->aux_ev, 0));  // the first stream's later kernels see F, L, G, Wa
-        if (wa_serial) enqueue_gram();
-    } else {
-        enqueue_gram();
-    }
-    if (!dev_done) {
-        // (see ortho_ss_prepare for why any root of the pseudo-inverse serves and when Cholesky is admissible)
-        build_Wa_host();
-        nd = 0;
-        if (!dev_wa && !force_eig && inv_diag <= kCholMaxInvTrace) {
-            L.resize(qq);
-            Li.resize(qq);
-            double inv_trace = 0.0;
-            chol_wa = nleh::cholesky_with_inverse(o.Wa.data(), q, L.data(), Li.data(), &inv_trace, kCholMaxInvTrace) && inv_trace <= kCholMaxInvTrace;
-        }
-        // Few eigenvalues below the cut (the usual case on large images: 4 of 200 at cfg4): deflate them and take the Cholesky
-        // route after all.  With Vd, Ld the dropped eigenpairs and s = lambda_max, Ahat = A + Vd (s I - Ld) Vd^T has A's kept
-        // eigenpairs and s on span(Vd); Ahat = L L^T, and with Pk = I - Vd Vd^T (which commutes with Ahat)
-        //     F = Pk L^-T  satisfies  F F^T = Pk Ahat^-1 Pk = pinv of the kept part of A,    F^T A^2 F = L^T Pk L
-        // -- the two things the device half needs.  Only the d dropped eigenvectors are formed (inverse iteration), not all q:
-        // reduction + QL values + Cholesky with inverse, ~1.0 ms at q = 200 against 1.5 ms for the full eigensolve.
-        // (on the host tried only where it pays: below q = 512, where the eigensolver is single threaded -- at q = 900 with 100
-        // dropped eigenvalues it lost 40 ms to the threaded full solve -- and for at most q / 8 dropped eigenvalues)
-        if (!dev_wa && !chol_wa && std::getenv("NLE_FORCE_EIG") == nullptr && std::getenv("NLE_NO_DEFLATE") == nullptr && q >= 16 && q < 512) {
-            std::vector<double> Dall(q), Vd((size_t)q * (max_defl + 1));
-            int kept = 0;
-            tr.mark("ss:   Wa built, Cholesky attempt");
-            if (nleh::sym_eigen_select(o.Wa.data(), q, Dall.data(), 0, 0, Vd.data(), NLE_EPS, max_defl, &kept)) {
-                tr.mark("ss:   Wa eigenvalues + dropped eigenvectors");
-                nd = q - kept;
-                if (kept > 0 && nd <= max_defl && Dall[0] > 0.0) {
-                    const double sig = Dall[0];
-                    std::vector<double> Ah(qq);
-                    for (int cidx = 0; cidx < q; ++cidx)  // the symmetric matrix the reference's solver sees: lower triangle
-                        for (int ridx = 0; ridx < q; ++ridx)
-                            Ah[(size_t)cidx * q + ridx] = ridx >= cidx ? o.Wa[(size_t)cidx * q + ridx] : o.Wa[(size_t)ridx * q + cidx];
-                    for (int t = 0; t < nd; ++t) {
-                        const double wgt = sig - Dall[kept + t];
-                        const double* v = Vd.data() + (size_t)t * q;
-                        for (int cidx = 0; cidx < q; ++cidx) {
-                            const double vc = wgt * v[cidx];
-                            for (int ridx = 0; ridx < q; ++ridx) Ah[(size_t)cidx * q + ridx] += v[ridx] * vc;
-                        }
-                    }
-                    L.resize(qq);
-                    Li.resize(qq);
-                    double inv_trace = 0.0;
-                    if (nleh::cholesky_with_inverse(Ah.data(), q, L.data(), Li.data(), &inv_trace)) {
-                        tr.mark("ss:   deflated matrix + its Cholesky factor and inverse");
-                        // F = L^-T - Vd (Vd^T L^-T),  G = L^T Vd
-                        Fdefl.resize(qq);
-                        for (int k = 0; k < q; ++k)
-                            for (int a = 0; a < q; ++a) Fdefl[(size_t)k * q + a] = Li[(size_t)a * q + k];
-                        Gdefl.assign((size_t)q * std::max(nd, 1), 0.0);
-                        std::vector<double> wv(q);
-                        for (int t = 0; t < nd; ++t) {
-                            const double* v = Vd.data() + (size_t)t * q;
-                            for (int k = 0; k < q; ++k) {  // w = (Vd^T L^-T)[t, k] = sum_a v[a] L^-T(a, k) = sum_a v[a] Li(k, a)
-                                double acc = 0.0, g = 0.0;
-                                for (int a = 0; a < q; ++a) {
-                                    acc += v[a] * Li[(size_t)a * q + k];
-                                    g += L[(size_t)k * q + a] * v[a];  // (L^T v)[k] = sum_a L(a, k) v[a]
-                                }
-                                wv[k] = acc;
-                                Gdefl[(size_t)t * q + k] = g;
-                            }
-                            for (int k = 0; k < q; ++k)
-                                for (int a = 0; a < q; ++a) Fdefl[(size_t)k * q + a] -= v[a] * wv[k];
-                        }
-                        deflated = true;
-                        r2 = kept;
-                        if (std::getenv("NLE_TRACE"))
-                            fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e), %d deflated\n",
-                                    kept, q, Dall[0], Dall[kept - 1], nd);
-                    }
-                }
-            }
-        }
-        if (!chol_wa && !deflated) {
-            std::vector<double> Uf(qq), l2(q);
-            if (!nleh::eigen_decomposition(o.Wa.data(), q, NLE_EPS, Uf.data(), l2.data(), &r2))
-                throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Wa"};
-            U2.assign(Uf.begin(), Uf.begin() + (size_t)q * std::max(r2, 1));
-            l2_kept.assign(l2.begin(), l2.begin() + r2);
-            Us.resize((size_t)q * std::max(r2, 1));
-            for (int k = 0; k < r2; ++k) {
-                const double sv = std::sqrt(recip0(l2[k]));
-                for (int i = 0; i < q; ++i) Us[(size_t)k * q + i] = U2[(size_t)k * q + i] * sv;
-            }
-            if (std::getenv("NLE_TRACE"))
-                fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e)\n", r2, q, l2[0],
-                        r2 > 0 ? l2[r2 - 1] : 0.0);
-        }
-    }
-    o.r_wa = chol_wa ? q : r2;
-    o.chol_wa = chol_wa;
-    const bool chol_form = chol_wa || deflated;  // F is q x q and F^T A^2 F = L^T L (- G G^T)
-    *host_overlapped_ms += now_ms() - h0;
-    tr.mark(dev_done ? "ss: Wa root (device, second stream, beside the Gram kernels)" : "ss: Wa root (host, under the Gram kernels)");
-    // ---- device: with a factor F of the (pseudo-)inverse of A = sym-lower(Wa), F F^T = A^+, the matrix the reference
-    // diagonalises, Q = Wa + S (Wab Wab^T) S with S = A^+1/2 (:296), is similar on range(A) to
-    //     Qt = F^T A^2 F + F^T WW F          (m x m, m = number of eigenvalues of Wa kept by the cut, :287)
-    // and T2 = S Vq Sq^-1/2 = F Vt Sq^-1/2 for Qt's eigenvectors Vt (:324-327).  Eigensolver form: F = U2 L2^-1/2,
-    // F^T A^2 F = L2 (diagonal); Cholesky form (no eigenvalue cut): F = L^-T, F^T A^2 F = L^T L.  On the subspace the
-    // cut removed, Q acts as Wa alone -- eigenvalues < 1e-10, cut again at :313 -- so nothing is lost, and the rounding
-    // of the S (..) S products (entries of S reach 1e5) can no longer lift one of them back over the cut.
-    const int m = chol_form ? q : std::max(r2, 0);
-    if (m <= 0) throw Fail{NLE_ERR_NUMERIC, "Wa has no eigenvalue >= 1e-10"};
-    const size_t mm_ = (size_t)m * m;
-    DevBuf<double> d_T(pp), d_T1((size_t)m * q), d_Qm(mm_);
-    if (!dev_wa) HIP_OK(hipMemcpyAsync(d_Wa.p, o.Wa.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));
-    if (!dev_done) {
-        std::vector<double> F;  // q x m column-major
-        if (chol_form) {
-            if (deflated) {
-                F = Fdefl;
-            } else {
-                F.resize(qq);
-                for (int k = 0; k < q; ++k)
-                    for (int a = 0; a < q; ++a) F[(size_t)k * q + a] = Li[(size_t)a * q + k];  // L^-T
-            }
-            d_L.alloc(qq);
-            HIP_OK(hipMemcpyAsync(d_L.p, L.data(), qq * sizeof(double), hipMemcpyHostToDevice, st));
-        } else {
-            F = Us;
-        }
-        d_F.alloc((size_t)q * m);
-        HIP_OK(hipMemcpyAsync(d_F.p, F.data(), (size_t)q * m * sizeof(double), hipMemcpyHostToDevice, st));
-        if (deflated && nd > 0) {
-            d_G.alloc((size_t)q * nd);
-            HIP_OK(hipMemcpyAsync(d_G.p, Gdefl.data(), (size_t)q * nd * sizeof(double), hipMemcpyHostToDevice, st));
-        }
-        HIP_OK(hipStreamSynchronize(st));  // the staging vectors go out of scope
-    }
-    reduce_gram();
-    if (q < p) {  // samples that fall in the B block: Gk += Kr[:, q:] diag(cA[q:]^2) Kr[:, q:]^T
-        std::vector<double> c2(p - q);
-        for (int a = q; a < p; ++a) c2[a - q] = o.cA[a] * o.cA[a];
-        DevBuf<double> d_c2(p - q);
-        HIP_OK(hipMemcpyAsync(d_c2.p, c2.data(), (p - q) * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_OK(nlek::gemm64s(st, p, p, p - q, d_Kr.p + (size_t)q * p, 1, p, d_Kr.p + (size_t)q * p, p, 1, d_Gk, 1, p, nullptr,
-                             d_c2.p, nullptr, d_Gk, 1, p));
-        HIP_OK(hipStreamSynchronize(st));  // c2 (host) is consumed
-    }
-    if (r < p) {  // Gk' = P Gk P
-        HIP_OK(nlek::gemm64s(st, p, p, p, d_P.p, 1, p, d_Gk, 1, p, d_T.p, 1, p));
-        HIP_OK(nlek::gemm64s(st, p, p, p, d_T.p, 1, p, d_P.p, 1, p, d_Gk, 1, p));
-    }
-    // T1 = F^T diag(rA) Gk'[:q,:q]  (m x q);   Qt = T1 diag(rA) F (+ L^T L in the Cholesky form; + diag(l2) on the host)
-    HIP_OK(nlek::gemm64s(st, m, q, q, d_F.p, q, 1, d_Gk, 1, p, d_T1.p, 1, m, nullptr, d_rA.p));
-    if (chol_form) {
-        DevBuf<double> d_A2(qq);
-        HIP_OK(nlek::gemm64s(st, q, q, q, d_L.p, q, 1, d_L.p, 1, q, d_A2.p, 1, q));
-        if (deflated && nd > 0) {  // - G G^T
-            DevBuf<double> d_neg(nd);
-            HIP_OK(nlek::fill64(st, d_neg.p, nd, -1.0));
-            HIP_OK(nlek::gemm64s(st, q, q, nd, d_G.p, 1, q, d_G.p, q, 1, d_A2.p, 1, q, nullptr, d_neg.p, nullptr, d_A2.p, 1, q));
-        }
-        HIP_OK(nlek::gemm64s(st, m, m, q, d_T1.p, 1, m, d_F.p, 1, q, d_Qm.p, 1, m, nullptr, d_rA.p, nullptr, d_A2.p, 1, q));
-    } else {
-        HIP_OK(nlek::gemm64s(st, m, m, q, d_T1.p, 1, m, d_F.p, 1, q, d_Qm.p, 1, m, nullptr, d_rA.p));
-    }
-    std::vector<double> Vq, Sq;
-    int rq = 0;
-    // Top eigenpairs of Qt.  From dev_solver_min_n() on: reduction, eigenvalues and back-transformation on the device
-    // (dense64.hip), only the inverse iteration for the K kept vectors on the host.  Below it: on the host
-    // (NLE_DEVICE_TRIDIAG=1, opt-in, K <= m / 2, m <= 224: the one-workgroup reduction of tridiag.hip -- measured at m = 196:
-    // 0.66 ms on the device against 0.43 ms of the 1.26 ms host solve, so it is not the default).
-    const int kq = std::min(std::max(n_eig, 1), m);
-    const bool dev_eig = c->topk_solver == 0 && use_dev_solver(m) && !std::getenv("NLE_HOST_Q");
-    const bool dev_tridiag = !dev_eig && c->topk_solver == 0 && m >= 16 && m <= nlek::tridiag_max_n() && 2 * kq <= m &&
-                             std::getenv("NLE_DEVICE_TRIDIAG") != nullptr;
-    DevSymEig es;  // (its staging buffer must outlive the upload it enqueues: function scope)
-    DevBuf<double> d_Vq, d_l2q;
-    if (dev_eig) {
-        const double* d_add = nullptr;
-        if (!chol_form) {
-            d_l2q.alloc(m);
-            HIP_OK(hipMemcpyAsync(d_l2q.p, l2_kept.data(), m * sizeof(double), hipMemcpyHostToDevice, st));
-            d_add = d_l2q.p;
-        }
-        es.reduce(c, m, d_Qm.p, d_add);
-        tr.mark("ss: Q, its tridiagonal form and eigenvalues (device)");
-        h0 = now_ms();
-        Sq = es.D;
-        while (rq < m && Sq[rq] >= NLE_EPS) ++rq;  // :213-216
-        const int Kd = std::min(n_eig, rq);
-        if (Kd > 0) {
-            d_Vq.alloc((size_t)m * Kd);
-            es.vectors(c, 0, Kd, d_Vq.p);
-        }
-    } else if (dev_tridiag) {
-        DevBuf<double> d_tv(mm_), d_td((size_t)3 * m), d_l2;
-        const double* d_add = nullptr;
-        if (!chol_form) {
-            d_l2.alloc(m);
-            HIP_OK(hipMemcpyAsync(d_l2.p, l2_kept.data(), m * sizeof(double), hipMemcpyHostToDevice, st));
-            d_add = d_l2.p;
-        }
-        HIP_OK(nlek::tridiag(st, m, d_Qm.p, d_add, d_tv.p, d_td.p, d_td.p + m, d_td.p + 2 * m));
-        std::vector<double> tv(mm_), td((size_t)3 * m);
-        HIP_OK(hipMemcpyAsync(td.data(), d_td.p, td.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(tv.data(), d_tv.p, mm_ * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-        tr.mark("ss: Q + its tridiagonal form on the device, download");
-        h0 = now_ms();
-        Vq.assign((size_t)m * kq, 0.0);
-        Sq.assign(m, 0.0);
-        if (!nleh::eigen_decomposition_top_reduced(m, NLE_EPS, kq, tv.data(), td.data(), td.data() + m, td.data() + 2 * m,
-                                                   Vq.data(), Sq.data(), &rq))
-            throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Q"};
-    } else {
-        std::vector<double> Qm(mm_);
-        HIP_OK(hipMemcpyAsync(Qm.data(), d_Qm.p, mm_ * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-        tr.mark("ss: Q on the device + download");
-        // ---- host: top eigenpairs of Qt
-        h0 = now_ms();
-        if (!chol_form)
-            for (int k = 0; k < m; ++k) Qm[(size_t)k * m + k] += l2_kept[k];
-        top_eigenpairs(Qm, m, n_eig, c->topk_solver, &Vq, &Sq, &rq);
-    }
-    const int K = std::min(n_eig, rq);  // :314
-    if (K <= 0) throw Fail{NLE_ERR_NUMERIC, "Q has no eigenvalue >= 1e-10"};
-    o.K = K;
-    o.r_q = rq;
-    o.Sq.assign(Sq.begin(), Sq.begin() + K);
-    std::vector<double> sv(K);
-    for (int k = 0; k < K; ++k) sv[k] = std::sqrt(recip0(Sq[k]));  // :319-321
-    *host_ms += now_ms() - h0;
-    tr.mark(dev_eig ? "ss: eigenvectors of Q (inverse iteration on the host, back-transformation enqueued)" : "ss: eig(Q) (host)");
-    // ---- device: T2 = F Vt Sq^-1/2, D = P[:, :q] diag(rA) T2, Vrows = [Wa T2; diag(cA_B) Kr_B D]
-    DevBuf<double> d_sv(K), d_T2((size_t)q * K), d_D((size_t)p * K), d_Vr((size_t)p * K);
-    if (!dev_eig) {
-        d_Vq.alloc((size_t)m * K);
-        HIP_OK(hipMemcpyAsync(d_Vq.p, Vq.data(), (size_t)m * K * sizeof(double), hipMemcpyHostToDevice, st));
-    }
-    HIP_OK(hipMemcpyAsync(d_sv.p, sv.data(), K * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_OK(nlek::gemm64s(st, q, K, m, d_F.p, 1, q, d_Vq.p, 1, m, d_T2.p, 1, q, nullptr, nullptr, d_sv.p));
-    if (r < p) {
-        HIP_OK(nlek::gemm64s(st, p, K, q, d_P.p, 1, p, d_T2.p, 1, q, d_D.p, 1, p, nullptr, d_rA.p));  // first q columns of P
-    } else {  // P = I, q == p: D = diag(rA) T2
-        HIP_OK(hipMemcpyAsync(d_D.p, d_T2.p, (size_t)q * K * sizeof(double), hipMemcpyDeviceToDevice, st));
-        HIP_OK(nlek::scale_rows64(st, d_D.p, p, K, d_rA.p));
-    }
-    HIP_OK(nlek::gemm64s(st, q, K, q, d_Wa.p, 1, q, d_T2.p, 1, q, d_Vr.p, 1, p));  // top block of :327
-    if (q < p)
-        HIP_OK(nlek::gemm64s(st, p - q, K, p, d_Kr.p + q, 1, p, d_D.p, 1, p, d_Vr.p + q, 1, p, d_cA.p + q));
-    o.D.resize((size_t)p * K);
-    o.Vrows.resize((size_t)p * K);
-    HIP_OK(hipMemcpyAsync(o.D.data(), d_D.p, o.D.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(o.Vrows.data(), d_Vr.p, o.Vrows.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
-    tr.mark("ss: D, Vrows on the device");
-}
-
 // unpack the upper-triangular 32x32 tile list of gram()/gram_fused() into a symmetric n x n matrix
 std::vector<double> unpack_tiles(const std::vector<double>& tiles, int ld, int n, int ts) {
     std::vector<double> G((size_t)n * n, 0.0);
@@ -1934,382 +1200,6 @@ void layer_resp(const double* ev, int K, int L, double* out) {
 // ------------------------------------------------------------------------------ C ABI
 extern "C" {
 
-int nle_ld(int n) { return ld4(n); }
-
-size_t nle_comm_len(int n_samples) {
-    const int ld = ld4(n_samples);
-    return std::max(std::max((size_t)nlek::gram_num_tiles(ld) * 1024, (size_t)nlek::gram64_num_tiles(n_samples) * 256),
-                    (size_t)n_samples * n_samples) +
-           8 * (size_t)nlek::sink_pass_ld(n_samples);
-}
-
-int nle_ctx_create(int device, void* stream, nle_ctx** out) {
-    if (!out) return NLE_ERR_INVALID;
-    *out = nullptr;
-    return guard(nullptr, [&] {
-        int ndev = 0;
-        HIP_OK(hipGetDeviceCount(&ndev));
-        if (ndev <= 0) throw Fail{NLE_ERR_HIP, "no HIP device (this library has no CPU fallback)"};
-        if (device < 0 || device >= ndev) throw Fail{NLE_ERR_INVALID, "device index out of range"};
-        HIP_OK(hipSetDevice(device));
-        auto c = new nle_ctx();
-        c->device = device;
-        if (const char* e = std::getenv("NLE_Q_SOLVER")) c->topk_solver = (std::string(e) == "lanczos") ? 1 : 0;
-        if (stream) {
-            c->stream = reinterpret_cast<hipStream_t>(stream);
-        } else {
-            hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-            if (e != hipSuccess) {
-                delete c;
-                throw Fail{NLE_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)};
-            }
-            c->own_stream = true;
-        }
-        *out = c;
-    });
-}
-
-void nle_ctx_destroy(nle_ctx* ctx) {
-    if (!ctx) return;
-    for (auto& r : ctx->prof_pending) {
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
-    }
-    for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->comm && ctx->own_comm) (void)rccl().CommDestroy(ctx->comm);
-    for (auto* f : ctx->filters) f->ctx = nullptr;  // their V is freed directly when they are destroyed
-    if (ctx->d_lut) (void)hipFree(ctx->d_lut);
-    for (auto e : ctx->copy_ev)
-        if (e) (void)hipEventDestroy(e);
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-    if (ctx->aux_stream) {
-        (void)hipStreamSynchronize(ctx->aux_stream);
-        (void)hipStreamDestroy(ctx->aux_stream);
-        if (ctx->aux_ev) (void)hipEventDestroy(ctx->aux_ev);
-    }
-    if (ctx->copy_stream) {
-        (void)hipStreamSynchronize(ctx->copy_stream);
-        (void)hipStreamDestroy(ctx->copy_stream);
-    }
-    for (auto& kv : ctx->arena_free) (void)hipFree(kv.second);
-    ctx->arena_free.clear();
-    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
-}
-
-const char* nle_last_error(const nle_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
-
-int nle_ctx_synchronize(nle_ctx* ctx) {
-    if (!ctx) return NLE_ERR_INVALID;
-    return guard(ctx, [&] { HIP_OK(hipStreamSynchronize(ctx->stream)); });
-}
-
-int nle_dev_alloc(nle_ctx* ctx, size_t bytes, void** d_ptr) {
-    if (!ctx || !d_ptr) return NLE_ERR_INVALID;
-    *d_ptr = nullptr;
-    return guard(ctx, [&] {
-        HIP_OK(hipSetDevice(ctx->device));
-        HIP_OK(hipMalloc(d_ptr, bytes ? bytes : 1));
-    });
-}
-
-void nle_dev_free(nle_ctx* ctx, void* d_ptr) {
-    if (!ctx || !d_ptr) return;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_ptr);
-}
-
-int nle_host_alloc(nle_ctx* ctx, size_t bytes, void** h_ptr) {
-    if (!ctx || !h_ptr) return NLE_ERR_INVALID;
-    *h_ptr = nullptr;
-    return guard(ctx, [&] {
-        HIP_OK(hipSetDevice(ctx->device));
-        HIP_OK(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
-    });
-}
-
-void nle_host_free(nle_ctx* ctx, void* h_ptr) {
-    if (!ctx || !h_ptr) return;
-    (void)hipSetDevice(ctx->device);
-    (void)hipHostFree(h_ptr);
-}
-
-int nle_dev_upload(nle_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
-    if (!ctx || (bytes && (!d_dst || !h_src))) return NLE_ERR_INVALID;
-    return guard(ctx, [&] {
-        HIP_OK(hipSetDevice(ctx->device));
-        HIP_OK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
-        HIP_OK(hipStreamSynchronize(ctx->stream));
-    });
-}
-
-int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
-    if (!ctx || (bytes && (!h_dst || !d_src))) return NLE_ERR_INVALID;
-    return guard(ctx, [&] {
-        HIP_OK(hipSetDevice(ctx->device));
-        HIP_OK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_OK(hipStreamSynchronize(ctx->stream));
-    });
-}
-
-namespace {
-const double* colour_lut(nle_ctx* c) {  // sRGB decode of i/255, uploaded once per ctx
-    if (!c->d_lut) {
-        double lut[256];
-        for (int i = 0; i < 256; ++i) {
-            const double v = i / 255.0;
-            lut[i] = v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4);
-        }
-        HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->d_lut), sizeof lut));
-        HIP_OK(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
-    }
-    return c->d_lut;
-}
-}  // namespace
-
-int nle_bgr2lab8(nle_ctx* ctx, const unsigned char* d_bgr, long long n, unsigned char* d_lab, float* d_L) {
-    if (!ctx || !d_bgr || n < 0 || (!d_lab && !d_L)) return NLE_ERR_INVALID;
-    return guard(ctx, [&] {
-        HIP_OK(hipSetDevice(ctx->device));
-        HIP_OK(nlek::bgr2lab8(ctx->stream, d_bgr, n, colour_lut(ctx), d_lab, d_L));
-        HIP_OK(hipStreamSynchronize(ctx->stream));
-    });
-}
-
-int nle_lab2bgr8(nle_ctx* ctx, const unsigned char* d_lab, const float* d_L, long long n, unsigned char* d_bgr) {
-    return nle_lab2bgr8_planes(ctx, d_lab, d_L, nullptr, nullptr, n, d_bgr);
-}
-
-int nle_lab2bgr8_planes(nle_ctx* ctx, const unsigned char* d_lab, const float* d_L, const float* d_a, const float* d_b,
-                        long long n, unsigned char* d_bgr) {
-    if (!ctx || !d_lab || !d_bgr || n < 0) return NLE_ERR_INVALID;
-    return guard(ctx, [&] {
-        HIP_OK(hipSetDevice(ctx->device));
-        HIP_OK(nlek::lab2bgr8(ctx->stream, d_lab, d_L, d_a, d_b, n, d_bgr));
-        HIP_OK(hipStreamSynchronize(ctx->stream));
-    });
-}
-
-int nle_lab8_channel(nle_ctx* ctx, const unsigned char* d_lab, long long n, int channel, float* d_out) {
-    if (!ctx || !d_lab || !d_out || n < 0 || channel < 0 || channel > 2) return NLE_ERR_INVALID;
-    return guard(ctx, [&] {
-        HIP_OK(hipSetDevice(ctx->device));
-        HIP_OK(nlek::channel8(ctx->stream, d_lab, n, channel, d_out));
-        HIP_OK(hipStreamSynchronize(ctx->stream));
-    });
-}
-
-int nle_bilateral_tables(double sigma_color, double sigma_space, int* radius, float* h_space_w, float* h_colour_w) {
-    // cv::bilateralFilter with d <= 0 (the reference passes -1, src/filter.cpp:366,371,535)
-    if (!radius) return NLE_ERR_INVALID;
-    if (sigma_color <= 0) sigma_color = 1;
-    if (sigma_space <= 0) sigma_space = 1;
-    const double cc = -0.5 / (sigma_color * sigma_color), sc = -0.5 / (sigma_space * sigma_space);
-    const int r = std::max((int)std::lrint(sigma_space * 1.5), 1);
-    *radius = r;
-    if (!h_space_w && !h_colour_w) return NLE_OK;
-    if (!h_space_w || !h_colour_w) return NLE_ERR_INVALID;
-    for (int i = 0; i < 256; ++i) h_colour_w[i] = (float)std::exp((double)i * i * cc);
-    const int d = 2 * r + 1;
-    for (int i = -r; i <= r; ++i)
-        for (int j = -r; j <= r; ++j) {
-            const double rr = std::sqrt((double)i * i + (double)j * j);
-            h_space_w[(i + r) * d + (j + r)] = rr > r ? 0.f : (float)std::exp(rr * rr * sc);
-        }
-    return NLE_OK;
-}
-
-int nle_bilateral8(nle_ctx* ctx, const float* d_src, int H, int W, double sigma_color, double sigma_space, float* d_dst) {
-    if (!ctx || !d_src || !d_dst || H < 1 || W < 1 || d_src == d_dst) return NLE_ERR_INVALID;
-    return guard(ctx, [&] {
-        HIP_OK(hipSetDevice(ctx->device));
-        int r = 0;
-        nle_bilateral_tables(sigma_color, sigma_space, &r, nullptr, nullptr);
-        if (r > nlek::bilateral8_max_radius())
-            throw Fail{NLE_ERR_INVALID, "bilateral filter: sigma_space above 42 (radius > 64) is not supported"};
-        const int d = 2 * r + 1;
-        std::vector<float> sw((size_t)d * d), cw(256);
-        nle_bilateral_tables(sigma_color, sigma_space, &r, sw.data(), cw.data());
-        // the kernel indexes its 256-entry colour table with |v - v0|: the plane must hold integers 0..255 (CV_8UC1)
-        DevBuf<int> d_flag(1);
-        int flag = 1;
-        HIP_OK(nlek::check_levels(ctx->stream, d_src, (long long)H * W, d_flag.p));
-        HIP_OK(hipMemcpyAsync(&flag, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_OK(hipStreamSynchronize(ctx->stream));
-        if (flag != 0) throw Fail{NLE_ERR_INVALID, "bilateral filter: the plane must be integer valued in [0, 255] (CV_8UC1)"};
-        DevBuf<float> d_sw(sw.size()), d_cw(cw.size());
-        HIP_OK(hipMemcpyAsync(d_sw.p, sw.data(), sw.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        HIP_OK(hipMemcpyAsync(d_cw.p, cw.data(), cw.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        HIP_OK(nlek::bilateral8(ctx->stream, d_src, H, W, r, d_sw.p, d_cw.p, d_dst));
-        HIP_OK(hipStreamSynchronize(ctx->stream));
-    });
-}
-
-int nle_ctx_trim(nle_ctx* ctx) {
-    if (!ctx) return NLE_ERR_INVALID;
-    return guard(ctx, [&] {
-        HIP_OK(hipSetDevice(ctx->device));
-        HIP_OK(hipStreamSynchronize(ctx->stream));
-        for (auto& kv : ctx->arena_free) (void)hipFree(kv.second);
-        ctx->arena_free.clear();
-        ctx->arena_bytes = 0;
-    });
-}
-
-int nle_eigen_decomposition_top(const double* h_M, int n, double eps, int kmax, double* h_U, double* h_D, int* r) {
-    if (!h_M || !h_U || !h_D || !r || n < 1 || kmax < 1) return NLE_ERR_INVALID;
-    return nleh::eigen_decomposition_top(h_M, n, eps, kmax, h_U, h_D, r) ? NLE_OK : NLE_ERR_NUMERIC;
-}
-
-int nle_eigen_decomposition_top_device(nle_ctx* ctx, const double* h_M, int n, double eps, int kmax, double* h_U, double* h_D,
-                                       int* r) {
-    if (!ctx || !h_M || !h_U || !h_D || !r || n < 2 || kmax < 1) return NLE_ERR_INVALID;
-    return guard(ctx, [&] {
-        if (n > nlek::tridiag_max_n()) throw Fail{NLE_ERR_INVALID, "nle_eigen_decomposition_top_device: n exceeds 224"};
-        HIP_OK(hipSetDevice(ctx->device));
-        const size_t nn = (size_t)n * n;
-        DevBuf<double> d_M(nn), d_V(nn), d_t((size_t)3 * n);
-        HIP_OK(hipMemcpyAsync(d_M.p, h_M, nn * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIP_OK(nlek::tridiag(ctx->stream, n, d_M.p, nullptr, d_V.p, d_t.p, d_t.p + n, d_t.p + 2 * n));
-        std::vector<double> V(nn), t((size_t)3 * n);
-        HIP_OK(hipMemcpyAsync(V.data(), d_V.p, nn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_OK(hipMemcpyAsync(t.data(), d_t.p, t.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_OK(hipStreamSynchronize(ctx->stream));
-        if (!nleh::eigen_decomposition_top_reduced(n, eps, std::min(kmax, n), V.data(), t.data(), t.data() + n, t.data() + 2 * n,
-                                                   h_U, h_D, r))
-            throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge"};
-    });
-}
-
-int nle_topk_eigen_decomposition(const double* h_M, int n, int n_largest, double eps, double* h_U, double* h_D, int* r) {
-    if (!h_M || !h_U || !h_D || !r || n < 2 || n_largest < 1) return NLE_ERR_INVALID;
-    const int nev = std::min(n_largest, n - 1);  // :172
-    const int nconv = nleh::lanczos_topk(h_M, n, nev, NLE_EPS, 1000, h_U, h_D, nullptr);
-    if (nconv < 0) return NLE_ERR_NUMERIC;
-    int k = 0;
-    while (k < nconv && h_D[k] >= eps) ++k;  // :186-196
-    *r = k;
-    return NLE_OK;
-}
-
-int nle_ctx_set_slab_input(nle_ctx* ctx, int on) {
-    if (!ctx) return NLE_ERR_INVALID;
-    ctx->slab_input = on != 0;
-    return NLE_OK;
-}
-
-int nle_ctx_set_topk_solver(nle_ctx* ctx, int solver) {
-    if (!ctx || solver < 0 || solver > 1) return NLE_ERR_INVALID;
-    ctx->topk_solver = solver;
-    return NLE_OK;
-}
-
-int nle_ctx_set_nystrom_bf16x3(nle_ctx* ctx, int on) {
-    if (!ctx) return NLE_ERR_INVALID;
-    ctx->nystrom_bf16x3 = on != 0;
-    return NLE_OK;
-}
-
-int nle_ctx_set_mode(nle_ctx* ctx, int mode) {
-    if (!ctx || mode < 0 || mode > NLE_MODE_STREAMED_F64) return NLE_ERR_INVALID;
-    ctx->mode = mode;
-    return NLE_OK;
-}
-
-int nle_rccl_unique_id(void* h_id, size_t size) {
-    if (!h_id || size < NCCL_UNIQUE_ID_BYTES) return NLE_ERR_INVALID;
-    return guard(nullptr, [&] {
-        ncclUniqueId id;
-        RCCL_OK(rccl().GetUniqueId(&id));
-        std::memcpy(h_id, id.internal, NCCL_UNIQUE_ID_BYTES);
-    });
-}
-
-int nle_ctx_init_rccl(nle_ctx* ctx, int rank, int world, const void* h_id, size_t size) {
-    if (!ctx || !h_id || size < NCCL_UNIQUE_ID_BYTES) return NLE_ERR_INVALID;
-    return guard(ctx, [&] {
-        if (world < 1 || rank < 0 || rank >= world) throw Fail{NLE_ERR_INVALID, "bad rank/world"};
-        HIP_OK(hipSetDevice(ctx->device));
-        if (ctx->comm && ctx->own_comm) (void)rccl().CommDestroy(ctx->comm);
-        ctx->comm = nullptr;
-        ncclUniqueId id;
-        std::memcpy(id.internal, h_id, NCCL_UNIQUE_ID_BYTES);
-        ncclComm_t comm = nullptr;
-        RCCL_OK(rccl().CommInitRank(&comm, world, id, rank));
-        ctx->comm = comm;
-        ctx->own_comm = true;
-        ctx->rank = rank;
-        ctx->world = world;
-        ctx->allreduce = nullptr;
-    });
-}
-
-int nle_ctx_set_rccl_comm(nle_ctx* ctx, int rank, int world, void* comm) {
-    if (!ctx || !comm) return NLE_ERR_INVALID;
-    return guard(ctx, [&] {
-        if (world < 1 || rank < 0 || rank >= world) throw Fail{NLE_ERR_INVALID, "bad rank/world"};
-        (void)rccl();  // the all-reduce goes through the loaded library
-        if (ctx->comm && ctx->own_comm) (void)rccl().CommDestroy(ctx->comm);
-        ctx->comm = reinterpret_cast<ncclComm_t>(comm);
-        ctx->own_comm = false;
-        ctx->rank = rank;
-        ctx->world = world;
-        ctx->allreduce = nullptr;
-    });
-}
-
-int nle_ctx_set_shard(nle_ctx* ctx, int rank, int world, nle_allreduce_fn allreduce, void* user,
-                      double* d_comm, size_t comm_len) {
-    if (!ctx) return NLE_ERR_INVALID;
-    return guard(ctx, [&] {
-        if (world < 1 || rank < 0 || rank >= world) throw Fail{NLE_ERR_INVALID, "bad rank/world"};
-        if (world > 1 && (!allreduce || !d_comm || comm_len == 0))
-            throw Fail{NLE_ERR_INVALID, "world > 1 needs an all-reduce callback and a comm buffer"};
-        ctx->rank = rank;
-        ctx->world = world;
-        ctx->allreduce = allreduce;
-        ctx->ar_user = user;
-        ctx->d_comm = d_comm;
-        ctx->comm_len = comm_len;
-    });
-}
-
-int nle_sample_grid(int H, int W, int n_row_samples, int n_col_samples, int* row_step, int* row_off,
-                    int* n_sel_rows, int* col_step, int* col_off, int* n_sel_cols) {
-    GridSpec gs;
-    if (!make_grid(H, W, n_row_samples, n_col_samples, &gs)) return NLE_ERR_INVALID;
-    if (row_step) *row_step = gs.rowStep;
-    if (row_off) *row_off = gs.rowOff;
-    if (n_sel_rows) *n_sel_rows = gs.nSelRows;
-    if (col_step) *col_step = gs.colStep;
-    if (col_off) *col_off = gs.colOff;
-    if (n_sel_cols) *n_sel_cols = gs.nSelCols;
-    return NLE_OK;
-}
-
-int nle_slab_rows(int H, int rank, int world, int* row0, int* row1) {
-    if (H <= 0 || world < 1 || rank < 0 || rank >= world || !row0 || !row1) return NLE_ERR_INVALID;
-    slab(H, rank, world, row0, row1);
-    return NLE_OK;
-}
-
-int nle_eigen_decomposition(const double* h_M, int n, double eps, double* h_U, double* h_D, int* r) {
-    if (!h_M || n <= 0 || !h_U || !h_D || !r) return NLE_ERR_INVALID;
-    return nleh::eigen_decomposition(h_M, n, eps, h_U, h_D, r) ? NLE_OK : NLE_ERR_NUMERIC;
-}
-
-int nle_transform_eigenvalues(const double* h_eigvals, int K, const double* h_weights, int L, double* h_fS) {
-    if (!h_eigvals || !h_weights || !h_fS || K < 0 || L < 1) return NLE_ERR_INVALID;
-    for (int i = 0; i < K; ++i) {  // reference src/filter.cpp:338-344
-        double v = h_weights[0];
-        for (int k = 1; k < L; ++k) v += (h_weights[k] - h_weights[k - 1]) * std::pow(h_eigvals[i], (double)k);
-        h_fS[i] = v;
-    }
-    return NLE_OK;
-}
-
 int nle_layer_responses(const double* h_eigvals, int K, int L, double* h_resp) {
     if (!h_eigvals || !h_resp || K < 0 || L < 1) return NLE_ERR_INVALID;
     layer_resp(h_eigvals, K, L, h_resp);
@@ -2716,37 +1606,6 @@ int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, 
         std::vector<double> resp((size_t)L * f->K);
         layer_resp(f->eigvals.data(), f->K, L, resp.data());
         apply_host_common(f, h_x, H, W, resp.data(), L, h_y);
-    });
-}
-
-static const char* const kKernelNames[NLE_KERNEL_COUNT] = {
-    "affinity", "nystrom_extend", "sinkhorn_pass", "reduce_partials", "gram",
-    "project",  "apply_reduce",   "apply_expand",  "small",           "sink_tables", "gram_rows",
-    "gram_gemm"};
-
-const char* nle_kernel_name(int kid) { return (kid >= 0 && kid < NLE_KERNEL_COUNT) ? kKernelNames[kid] : ""; }
-
-int nle_ctx_profile(nle_ctx* ctx, int enable) {
-    if (!ctx) return NLE_ERR_INVALID;
-    return guard(ctx, [&] {
-        HIP_OK(hipStreamSynchronize(ctx->stream));
-        prof_flush(ctx);
-        ctx->profiling = enable != 0;
-        ctx->profile_all = enable >= 2;
-        for (int k = 0; k < NLE_KERNEL_COUNT; ++k) {
-            ctx->prof_launches[k] = 0;
-            ctx->prof_ms[k] = 0.0;
-        }
-    });
-}
-
-int nle_ctx_kernel_stats(nle_ctx* ctx, int kid, long long* launches, double* total_ms) {
-    if (!ctx || kid < 0 || kid >= NLE_KERNEL_COUNT) return NLE_ERR_INVALID;
-    return guard(ctx, [&] {
-        HIP_OK(hipStreamSynchronize(ctx->stream));
-        prof_flush(ctx);
-        if (launches) *launches = ctx->prof_launches[kid];
-        if (total_ms) *total_ms = ctx->prof_ms[kid];
     });
 }
 

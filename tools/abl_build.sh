@@ -11,7 +11,7 @@ cp -r $PKG/csrc $TMP/csrc
 patch -s -p1 -d $TMP/csrc < $ROOT/tools/micro/sorted_pass_ablation.patch
 for v in "$@"; do
   objs=""
-  for f in kernels tsgemm_bf16x3 fused sorted generic64 tridiag dense64 colour pipeline devsolve; do
+  for f in kernels tsgemm_bf16x3 fused sorted generic64 tridiag dense64 colour pipeline ortho abi_ctx devsolve; do
     /opt/rocm/bin/hipcc -x hip -O3 -std=c++17 --offload-arch=gfx950 -fPIC -DNLE_ABL_$v -I $ROOT/include -c $TMP/csrc/$f.hip -o $TMP/$f.$v.o &
     objs="$objs $TMP/$f.$v.o"
   done
