@@ -458,7 +458,8 @@ void train_generic64(nle_ctx* c, nle_filter* f, const float* d_lum, const Sample
     tm_s.start();
     const size_t phi_elems = (size_t)std::max<long long>(M, 1) * ny.ldr;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && phi_elems * sizeof(double) > free_b + c->arena_bytes)
+    const bool no_fit = hipMemGetInfo(&free_b, &total_b) == hipSuccess && phi_elems * sizeof(double) > free_b + c->arena_bytes;
+    if (ranks_where(c, no_fit) > 0)  // refused on every rank if it does not fit on one (nobody is left in a collective)
         throw Fail{NLE_ERR_INVALID, "fp64 formulation: Phi (N x r doubles) does not fit in device memory; use an integer-valued "
                                     "luminance plane with a sample grid of at most 32 x 36 (table formulation) or NLE_MODE_MATERIALISED"};
     DevBuf<double> d_phi(phi_elems);
@@ -1106,13 +1107,14 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum_in, int H, int W, int nRow
         };
         tm_a.stop();
         // auto mode's fp64 fallback holds Phi (N x r doubles) when that fits comfortably (a pass reads it once); otherwise
-        // -- and when asked for -- the streamed form, which holds nothing N x r (ranks decide alike: slabs are equal)
+        // -- and when asked for -- the streamed form, which holds nothing N x r (the ranks agree on it: ranks_where)
         bool stream64 = c->mode == NLE_MODE_STREAMED_F64;
         if (!fuse && c->mode == NLE_MODE_AUTO) {
             size_t free_b = 0, total_b = 0;
             const size_t need = (size_t)std::max<long long>(M, 1) * ld4(ss.p) * sizeof(double);
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (free_b + c->arena_bytes) / 2) stream64 = true;
             if (std::getenv("NLE_AUTO_STREAM64")) stream64 = true;
+            if (c->world > 1) stream64 = ranks_where(c, stream64) > 0;  // one rank short of memory: everybody streams
         }
         if (fuse) {
             train_sample_space(c, f, d_lum, ss, [&] { return solve(true); }, hx, hy, T, n_eig, pix0, M, &sm);

@@ -372,6 +372,22 @@ inline void all_reduce(nle_ctx* c, double* d, size_t n) {
     HIP_OK(hipMemcpyAsync(d, c->d_comm, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
 }
 
+// A rank-local verdict that the collectives after it depend on (does Phi fit HERE?  which formulation?) is agreed over the
+// ranks before anything acts on it: the number of ranks on which `flag` holds.  Without this a rank that refuses (or picks
+// another formulation) leaves its peers blocked in their next all-reduce.  One 8-byte all-reduce; nothing when world == 1.
+// NLE_FAULT_RANK=<r> (fault injection for the tests) makes rank r answer "true" whatever it found.
+inline int ranks_where(nle_ctx* c, bool flag) {
+    if (const char* e = std::getenv("NLE_FAULT_RANK"))
+        if (c->world > 1 && std::atoi(e) == c->rank) flag = true;
+    if (c->world <= 1 && !c->comm) return flag ? 1 : 0;
+    DevBuf<double> d(1);
+    double v = flag ? 1.0 : 0.0;
+    HIP_OK(hipMemcpyAsync(d.p, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
+    all_reduce(c, d.p, 1);
+    HIP_OK(hipMemcpyAsync(&v, d.p, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return (int)(v + 0.5);
+}
 
 // Page-locked staging memory of the ctx for the solvers' larger transfers, handed out bump-style within one train call
 // (large copies from / to pageable memory leave the runtime with milliseconds of clean-up at a later synchronisation).

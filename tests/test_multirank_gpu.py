@@ -202,3 +202,55 @@ def test_native_rccl_reinit_and_lifetimes(nle, oracle):
     assert np.array_equal(fc.apply_layers(x, L).cpu().numpy(), Ya)
     fc.close()
     cc.close()
+
+
+def _fault_worker(rank, world, port, mode, outdir):
+    """rank 1 is made to answer "Phi does not fit here" (NLE_FAULT_RANK): what do BOTH ranks do?"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["NLE_FAULT_RANK"] = "1"
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    nle = entry.load_package()
+    synth = entry._load("nle_amd_synthetic", os.path.join(entry.PKG_DIR, "synthetic.py"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, W, nr, nc, hx, hy, T, K, L = 96, 128, 6, 8, 32.0, 30.0, 6, 10, 3
+        x = synth.synthetic_luminance(H, W).astype(np.float32) + (0.25 if mode == 0 else 0.0)   # mode 0: a non-integer plane
+        ctx = nle.Context(0)
+        ctx.set_mode(mode)
+        g = nle.sample_grid(H, W, nr, nc)
+        ctx.set_shard(rank, world, g["n_sel_rows"] * g["n_sel_cols"], lambda t: dist.all_reduce(t))
+        try:
+            f = nle.NLEFilter(ctx).train_filter(x, nr, nc, hx, hy, T, K)
+            Y = f.apply_layers(x, L).cpu().numpy()
+            np.savez(os.path.join(outdir, f"rank{rank}.npz"), Y=Y, form=f.diag()["formulation"], code=0)
+            f.close()
+        except nle.NLEError as e:
+            np.savez(os.path.join(outdir, f"rank{rank}.npz"), code=e.code)
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_refusal_on_one_rank_is_a_refusal_on_all(nle, tmp_path):
+    """a rank that finds Phi does not fit used to throw alone and leave its peer in the next all-reduce for
+    ever.  The verdict is now agreed first (ranks_where): with rank 1 forced to say "does not fit", BOTH ranks return
+    NLE_ERR_INVALID from the materialised fp64 mode -- and the run ends."""
+    import torch.multiprocessing as mp
+    mp.spawn(_fault_worker, args=(2, _free_port(), nle.MODE_MATERIALISED_F64, str(tmp_path)), nprocs=2, join=True)
+    codes = [int(np.load(tmp_path / f"rank{r}.npz")["code"]) for r in range(2)]
+    assert codes == [nle.NLE_ERR_INVALID, nle.NLE_ERR_INVALID], codes
+
+
+def test_one_rank_short_of_memory_makes_every_rank_stream(nle, tmp_path):
+    """auto mode's fp64 fallback: the choice between holding Phi and the streamed form depends on the free memory of each
+    rank; the ranks agree on it (if one must stream, all do), so their collectives still pair up"""
+    import torch.multiprocessing as mp
+    mp.spawn(_fault_worker, args=(2, _free_port(), nle.MODE_AUTO, str(tmp_path)), nprocs=2, join=True)
+    recs = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    assert [int(r["code"]) for r in recs] == [0, 0]
+    assert [int(r["form"]) for r in recs] == [nle.MODE_STREAMED_F64] * 2
+    assert all(np.isfinite(r["Y"]).all() for r in recs)
