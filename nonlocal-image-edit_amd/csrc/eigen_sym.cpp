@@ -804,15 +804,23 @@ bool tridiag_inverse_iteration(int n, const double* d, const double* e, const do
         onenrm = std::max(onenrm, std::fabs(d[i]) + (i > 0 ? std::fabs(e[i]) : 0.0) + (i + 1 < n ? std::fabs(e[i + 1]) : 0.0));
     if (onenrm == 0.0) onenrm = 1.0;
     const double ortol = 1e-3 * onenrm, tiny = eps * onenrm;
+    // Clusters (eigenvalues closer than ortol to their neighbour; their vectors are re-orthogonalised against each other)
+    // are independent of one another: the shift perturbation below never reaches across a gap > ortol, and every vector
+    // starts from its own pseudo-random vector (seeded by its index, so the result does not depend on who computes it).
+    // With many vectors the clusters are dealt to a few threads.
+    std::vector<int> starts;
+    for (int j = 0; j < k; ++j)
+        if (j == 0 || std::fabs(lam[j] - lam[j - 1]) > ortol) starts.push_back(j);
+    starts.push_back(k);
+    const int ngroups = (int)starts.size() - 1;
+    auto do_group = [&](int gp, int gend) -> bool {
     std::vector<double> a(n), ra(n), b(n), c(n), dd(n), x(n), y(n);
     std::vector<char> piv(n);
-    int gp = 0;  // first vector of the current cluster
     double prev = 0.0;
-    unsigned long long seed = 0x2545F4914F6CDD1Dull;
-    for (int j = 0; j < k; ++j) {
+    for (int j = gp; j < gend; ++j) {
+        unsigned long long seed = 0x2545F4914F6CDD1Dull ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(j + 1));
         double xj = lam[j];
-        if (j > 0) {
-            if (std::fabs(lam[j] - lam[j - 1]) > ortol) gp = j;
+        if (j > gp) {
             const double pertol = 10.0 * eps * std::max(std::fabs(xj), tiny);
             if (prev - xj < pertol) xj = prev - pertol;  // keep the shifts distinct (descending order)
         }
@@ -889,6 +897,44 @@ bool tridiag_inverse_iteration(int n, const double* d, const double* e, const do
         if (!ok) return false;
         std::copy(x.begin(), x.end(), z);
     }
+    return true;
+    };
+    // work of a cluster of m vectors ~ m n (8 + m) (solves + re-orthogonalisation), ~2.6 ns per unit on the GPU box's cores;
+    // threads (~0.1 ms to start and join) pay off from ~0.8 ms of it
+    double work = 0.0;
+    for (int g = 0; g < ngroups; ++g) {
+        const double m = starts[g + 1] - starts[g];
+        work += m * n * (8.0 + m);
+    }
+    int nthreads = (ngroups >= 2 && work > 3e5) ? std::min(4, ngroups) : 1;
+    if (const char* ev = std::getenv("NLE_EIG_THREADS")) nthreads = std::max(1, std::min(std::atoi(ev), ngroups));
+    if (nthreads <= 1) {
+        for (int g = 0; g < ngroups; ++g)
+            if (!do_group(starts[g], starts[g + 1])) return false;
+        return true;
+    }
+    // contiguous runs of clusters of about equal work per thread
+    std::vector<int> cut(nthreads + 1, ngroups);
+    cut[0] = 0;
+    {
+        double acc = 0.0;
+        int t = 1;
+        for (int g = 0; g < ngroups && t < nthreads; ++g) {
+            const double m = starts[g + 1] - starts[g];
+            acc += m * n * (8.0 + m);
+            if (acc >= work * t / nthreads) cut[t++] = g + 1;
+        }
+    }
+    std::vector<char> okv(nthreads, 1);
+    run_split(nthreads, nthreads, [&](int t) {
+        for (int g = cut[t]; g < cut[t + 1]; ++g)
+            if (!do_group(starts[g], starts[g + 1])) {
+                okv[t] = 0;
+                return;
+            }
+    });
+    for (char v : okv)
+        if (!v) return false;
     return true;
 }
 

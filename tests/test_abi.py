@@ -204,6 +204,9 @@ def test_leading_eigenvectors_by_inverse_iteration(nle):
     lam = np.sort(np.concatenate([[0.9] * 4, [0.7] * 3, rng.uniform(0, 0.5, 93)]))[::-1]
     cases.append(("repeated", 100, 20, lam))
     cases.append(("wa", 200, 60, 1.5e-5 * 0.9 ** np.arange(200)))
+    # enough vectors in enough separate clusters that the clusters are dealt to threads (csrc/eigen_sym.cpp)
+    lam = np.sort(np.concatenate([np.linspace(1.0, 0.3, 60), 0.25 - 1e-9 * np.arange(30), rng.uniform(0, 0.2, 810)]))[::-1]
+    cases.append(("threads", 900, 100, lam))
     for name, n, k, lam in cases:
         X = np.linalg.qr(rng.standard_normal((n, n)))[0]
         A = (X * lam) @ X.T
