@@ -208,7 +208,7 @@ int nle_bilateral8(nle_ctx* ctx, const float* d_src, int H, int W, double sigma_
         std::vector<float> sw((size_t)d * d), cw(256);
         nle_bilateral_tables(sigma_color, sigma_space, &r, sw.data(), cw.data());
         // the kernel indexes its 256-entry colour table with |v - v0|: the plane must hold integers 0..255 (CV_8UC1)
-        DevBuf<int> d_flag(1);
+        DevBuf<int> d_flag(2);  // verdict, level tiles (unused here)
         int flag = 1;
         HIP_OK(nlek::check_levels(ctx->stream, d_src, (long long)H * W, d_flag.p));
         HIP_OK(hipMemcpyAsync(&flag, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

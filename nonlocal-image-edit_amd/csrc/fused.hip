@@ -807,15 +807,24 @@ __device__ __forceinline__ bool wave_group_levels(bool active, int x, G&& groupe
 __global__ __launch_bounds__(256) void k_check_levels(const float* __restrict__ lum, long long n,
                                                       int* __restrict__ flag) {
     bool bad = false;
+    unsigned tiles = 0;  // bit t: some pixel has a level in [16 t, 16 t + 16)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float v = lum[i];
-        bad = bad || !(v >= 0.f && v <= (float)(kLevels - 1) && v == floorf(v));
+        const bool ok = v >= 0.f && v <= (float)(kLevels - 1) && v == floorf(v);
+        bad = bad || !ok;
+        if (ok) tiles |= 1u << ((int)v >> 4);
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tiles |= __shfl_xor(tiles, off);
+    if ((threadIdx.x & 63) == 0) {
+        if (__any(bad)) atomicOr(flag, 1);
+        atomicOr(flag + 1, (int)tiles);
+    }
 }
 
+// d_flag: 2 ints.  [0] != 0: the plane is not integer valued in [0, 255]; [1]: which 16-level tiles occur (bit t)
 hipError_t check_levels(hipStream_t s, const float* d_lum, long long n, int* d_flag) {
-    hipError_t e = hipMemsetAsync(d_flag, 0, sizeof(int), s);
+    hipError_t e = hipMemsetAsync(d_flag, 0, 2 * sizeof(int), s);
     if (e != hipSuccess) return e;
     long long g = (n + 255) / 256;
     if (g > 2048) g = 2048;
@@ -955,7 +964,9 @@ hipError_t sink_hist(hipStream_t s, int mode, const float* d_lum, GridSpec gs, i
 // MFMA: a wave keeps the WE operands of its 16 columns in registers (nR <= 32: 8 k-steps of 4) and walks
 // down `tiles_per_wave` 16-row tiles -- five loads, five MFMAs and one 16 x 16 store per tile at cfg4, so
 // the kernel runs at the speed of its 8 B/element output stream.
-__global__ __launch_bounds__(256) void k_hist_g(GridSpec gs, int p, int nrows, int tiles_per_wave,
+// lev_t0, lev_nt: the 16-level tiles [lev_t0, lev_t0 + lev_nt) that occur in the image -- columns of other levels are never
+// read by anybody and are not made.
+__global__ __launch_bounds__(256) void k_hist_g(GridSpec gs, int p, int nrows, int tiles_per_wave, int lev_t0, int lev_nt,
                                                 const double* __restrict__ er, const double* __restrict__ Ep,
                                                 const double* __restrict__ w, double* __restrict__ g) {
     // the er rows of this workgroup's row range, staged once (coalesced) -- a per-tile global load of the A operand put
@@ -967,10 +978,10 @@ __global__ __launch_bounds__(256) void k_hist_g(GridSpec gs, int p, int nrows, i
     const int t0 = blockIdx.y * tiles_per_wave, ntiles = (nrows + 15) >> 4;
     const int rbase = t0 * 16, rcount = min(nrows - rbase, tiles_per_wave * 16);
     for (int i = tid; i < rcount * nR; i += 256) sEr[i] = er[(size_t)rbase * nR + i];
-    const int n0 = (blockIdx.x * 4 + wave) * 16;
-    const int col = n0 + l15;
-    const bool col_ok = col < n;
-    const int b = col_ok ? col / kLevels : 0, x = col & (kLevels - 1);  // table columns are b-major: col = b*256 + x
+    const int q = blockIdx.x * 4 + wave;  // column tile: sample column b = q / lev_nt, level tile lev_t0 + q % lev_nt
+    const bool col_ok = q < nC * lev_nt;
+    const int b = col_ok ? q / lev_nt : 0, x = (lev_t0 + (col_ok ? q % lev_nt : 0)) * 16 + l15;
+    const int col = b * kLevels + x;  // table columns are b-major: col = b*256 + x
     double bop[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -978,7 +989,7 @@ __global__ __launch_bounds__(256) void k_hist_g(GridSpec gs, int p, int nrows, i
         bop[ks] = (col_ok && a < nR) ? w[a * nC + b] * Ep[(size_t)x * p + a * nC + b] : 0.0;
     }
     __syncthreads();
-    if (n0 >= n) return;  // wave-uniform (after the barrier)
+    if (!col_ok) return;  // wave-uniform (after the barrier)
     const int ksteps = (nR + 3) >> 2;
     for (int t = t0; t < min(ntiles, t0 + tiles_per_wave); ++t) {
         const int rl = (t - t0) * 16 + l15;  // row within the staged range
@@ -1003,9 +1014,9 @@ __global__ __launch_bounds__(256) void k_hist_g(GridSpec gs, int p, int nrows, i
 }
 
 static hipError_t launch_hist_g(hipStream_t s, GridSpec gs, int p, int nrows_local, const double* d_er, const double* d_Ep,
-                                const double* d_w, double* d_g) {
-    const int n = kLevels * gs.nSelCols, ntiles = (nrows_local + 15) / 16;
-    const int gx = (n / 16 + 3) / 4;
+                                const double* d_w, double* d_g, int lev_t0 = 0, int lev_nt = kLevels / 16) {
+    const int ntiles = (nrows_local + 15) / 16;
+    const int gx = (gs.nSelCols * lev_nt + 3) / 4;
     // ~2560 waves on the chip (or one row tile per wave if the slab is short); at most 16 tiles (256 rows x nR <= 32
     // doubles = 64 KB of LDS) per workgroup
     const int cap = gs.nSelRows > 24 ? 8 : 16;  // the staged er rows: <= 32 KB of LDS per workgroup (cfg5: -3 % on the Sinkhorn stage)
@@ -1018,7 +1029,7 @@ static hipError_t launch_hist_g(hipStream_t s, GridSpec gs, int p, int nrows_loc
         if (ea != hipSuccess) return ea;
     }
     hipLaunchKernelGGL(k_hist_g, dim3((unsigned)gx, (unsigned)((ntiles + tpw - 1) / tpw)), dim3(256), shm, s, gs, p,
-                       nrows_local, tpw, d_er, d_Ep, d_w, d_g);
+                       nrows_local, tpw, lev_t0, lev_nt, d_er, d_Ep, d_w, d_g);
     return hipGetLastError();
 }
 
@@ -1206,9 +1217,9 @@ __global__ void k_scatter_samples(int p, int L, const long long* __restrict__ lo
 // 16 levels with Ep on the spot: zpart[slab][x tile][a, b] = sum_{x in tile} Ep[x][a, b] HH[a][b, x]; a fixed-order reduce
 // over the slabs and the 16 level tiles (reduce_partials) then gives z.  26 MB of HH written and read per pass become
 // < 1 MB of partials, and one launch goes away.
-__global__ __launch_bounds__(256) void k_hist_hh(int nC, int nR, int nrows, int slab_rows, const double* __restrict__ er,
-                                                 const double* __restrict__ h, const double* __restrict__ Ep, int p, int ldp,
-                                                 double* __restrict__ zpart) {
+__global__ __launch_bounds__(256) void k_hist_hh(int nC, int nR, int nrows, int slab_rows, int lev_t0, int lev_nt,
+                                                 const double* __restrict__ er, const double* __restrict__ h,
+                                                 const double* __restrict__ Ep, int p, int ldp, double* __restrict__ zpart) {
     // the slab's er rows, staged once for the four waves (they were re-read from global memory inside the MFMA loop: a
     // second dependent latency per 32 rows), and all of a lane's h loads of a 64-row half slab in flight together
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1217,13 +1228,14 @@ __global__ __launch_bounds__(256) void k_hist_hh(int nC, int nR, int nrows, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int r0 = blockIdx.y * slab_rows, rcount = min(nrows - r0, slab_rows);
     for (int i = tid; i < rcount * nR; i += 256) sEr[i] = er[(size_t)r0 * nR + i];
-    const int n0 = (blockIdx.x * 4 + wave) * 16;
-    const int col = n0 + l15;
-    const bool col_ok = col < n;
+    const int q = blockIdx.x * 4 + wave;  // column tile, as in k_hist_g: only the level tiles that occur
+    const bool col_ok = q < nC * lev_nt;
+    const int b = col_ok ? q / lev_nt : 0, xt = lev_t0 + (col_ok ? q % lev_nt : 0), x = xt * 16 + l15;
+    const int col = b * kLevels + x;
     const bool two = nR > 16;
     f64x4 acc0 = f64x4{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
     __syncthreads();
-    if (n0 >= n) return;  // wave-uniform (after the barrier)
+    if (!col_ok) return;  // wave-uniform (after the barrier)
     for (int k0 = 0; k0 < slab_rows; k0 += 64) {
         double bop[16];
 #pragma unroll
@@ -1245,7 +1257,6 @@ __global__ __launch_bounds__(256) void k_hist_hh(int nC, int nR, int nrows, int 
     }
     // table columns are b-major (col = b * 256 + x) and a wave's 16 columns share b: lane (l15, kq) holds, for its level
     // x = x0 + l15, the sums of sample rows a = kq + 4 e (and 16 + kq + 4 e)
-    const int b = n0 / kLevels, x = (n0 & (kLevels - 1)) + l15, xt = (n0 & (kLevels - 1)) >> 4;
     double v[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1258,7 +1269,7 @@ __global__ __launch_bounds__(256) void k_hist_hh(int nC, int nR, int nrows, int 
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += __shfl_xor(v[e], off);
     if (l15 == 0 && col_ok) {
-        double* out = zpart + ((size_t)blockIdx.y * (kLevels / 16) + xt) * ldp;
+        double* out = zpart + ((size_t)blockIdx.y * lev_nt + (xt - lev_t0)) * ldp;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int a0 = kq + 4 * e, a1 = 16 + kq + 4 * e;
@@ -1323,15 +1334,18 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
     double* d_g = d_ws;
     double* d_h = d_g + (size_t)nrows_local * n;
     double* d_HH = d_h + (size_t)nrows_local * n;
+    // the 16-level tiles that occur in the image (known with the sorted rows): the tables' other columns are neither made
+    // (k_hist_g), stored (pass kernel) nor contracted (k_hist_hh)
+    const int lev_t0 = sorted ? sorted->lev_t0 : 0, lev_nt = sorted ? sorted->lev_nt : kLevels / 16;
     if (mode == ROWPASS_RECIP) {
         Scope sc(obs, SUB_HIST_G);
-        hipError_t eg = launch_hist_g(s, gs, p, nrows_local, d_er, d_Ep, d_w, d_g);
+        hipError_t eg = launch_hist_g(s, gs, p, nrows_local, d_er, d_Ep, d_w, d_g, lev_t0, lev_nt);
         if (eg != hipSuccess) return eg;
     }
     if (sorted != nullptr) {
         Scope sc(obs, SUB_HIST_PIX);
         hipError_t ep = sorted_pass(s, mode, gs, row0, nrows_local, sorted->scol, sorted->desc, sorted->first, sorted->E, d_g,
-                                    eps, d_ybuf, d_h, d_cvec, d_xvec, sorted->rec, sorted->kappa);
+                                    eps, d_ybuf, d_h, d_cvec, d_xvec, sorted->rec, sorted->kappa, lev_t0, lev_nt);
         if (ep != hipSuccess) return ep;
     } else {
         Scope sc(obs, SUB_HIST_PIX);
@@ -1370,10 +1384,10 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_hh);
             if (ea != hipSuccess) return ea;
         }
-        hipLaunchKernelGGL(k_hist_hh, dim3((unsigned)((n / 16 + 3) / 4), (unsigned)nslabs), dim3(256), shm_hh, s, nC, nR,
-                           nrows_local, slab_rows, d_er, d_h, d_Ep, p, ldp, d_HH);
+        hipLaunchKernelGGL(k_hist_hh, dim3((unsigned)((nC * lev_nt + 3) / 4), (unsigned)nslabs), dim3(256), shm_hh, s, nC, nR,
+                           nrows_local, slab_rows, lev_t0, lev_nt, d_er, d_h, d_Ep, p, ldp, d_HH);
     }
-    hipLaunchKernelGGL(k_z_reduce, dim3((unsigned)((ldp + 7) / 8)), dim3(256), 0, s, d_HH, nslabs * (kLevels / 16), p, ldp, d_z);
+    hipLaunchKernelGGL(k_z_reduce, dim3((unsigned)((ldp + 7) / 8)), dim3(256), 0, s, d_HH, nslabs * lev_nt, p, ldp, d_z);
     return hipGetLastError();
 }
 
@@ -1398,7 +1412,8 @@ hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int
     const size_t n = (size_t)kLevels * nC, gstride = (size_t)nrows_local * n;
     if (obs) obs->begin(SUB_HIST_G);
     for (int l = 0; l < nl; ++l) {
-        hipError_t eg = launch_hist_g(s, gs, p, nrows_local, d_er, d_Ep, d_wl + (size_t)l * ldw, d_ws + (size_t)l * gstride);
+        hipError_t eg = launch_hist_g(s, gs, p, nrows_local, d_er, d_Ep, d_wl + (size_t)l * ldw, d_ws + (size_t)l * gstride,
+                                      use_sorted ? sorted->lev_t0 : 0, use_sorted ? sorted->lev_nt : kLevels / 16);
         if (eg != hipSuccess) return eg;
     }
     if (obs) obs->end(), obs->begin(SUB_HIST_PIX);

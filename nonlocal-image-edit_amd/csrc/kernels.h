@@ -132,7 +132,7 @@ hipError_t project64(hipStream_t s, const float* d_lum, GridSpec gs, const Sampl
 
 // ---- quantised-luminance (integer 0..255) Sinkhorn pass: table look-ups instead of exponentials ----
 int sink_hist_max_cols();
-hipError_t check_levels(hipStream_t s, const float* d_lum, long long n, int* d_flag);  // flag != 0: not quantised
+hipError_t check_levels(hipStream_t s, const float* d_lum, long long n, int* d_flag);  // 2 ints: [0] != 0: not quantised, [1]: 16-level tiles that occur (bit t)
 hipError_t hist_tables(hipStream_t s, GridSpec gs, const Sample4* d_samples, int p, double hx, double hy, int row0,
                        int nrows_local, double* d_er, double* d_ecT, double* d_Ep);
 // partial: [nrows_local][ldp] doubles (one row per image row); d_ybuf as in sink_pass
@@ -209,6 +209,7 @@ struct SortedRows {
     double kappa;                 // exp(-2 colStep^2 / hx^2)
     const double* E2 = nullptr;   // [W + 1] exp(-2 d^2 / hx^2): set (with hx) where the Gram runs on index sums (sorted_gsum_ok)
     double hx = 0.0;
+    int lev_t0 = 0, lev_nt = 16;  // the 16-level tiles [lev_t0, lev_t0 + lev_nt) that occur in the image (check_levels)
 };
 // Gram by index sums (sorted.hip: k_sorted_gsum): S_r[t][x] = sum c_i^2 G_t(col_i), t < 2 nC - 1; layout [row][t][level]
 bool sorted_gsum_ok(GridSpec gs, double hx);
@@ -230,7 +231,8 @@ hipError_t sort_rows(hipStream_t s, const float* d_lum, GridSpec gs, int row0, i
                      uint2* d_desc, unsigned short* d_first);
 hipError_t sorted_pass(hipStream_t s, int mode, GridSpec gs, int row0, int nrows_local, const unsigned short* d_scol,
                        const uint2* d_desc, const unsigned short* d_first, const double* d_E, const double* d_g, double eps,
-                       double* d_ybuf, double* d_h, const double* d_cvec, const float* d_xvec, bool rec, double kappa);
+                       double* d_ybuf, double* d_h, const double* d_cvec, const float* d_xvec, bool rec, double kappa,
+                       int lev_t0 = 0, int lev_nt = 16);  // table columns of the level tiles [lev_t0, +lev_nt) only
 hipError_t sorted_gram_rows(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
                             const unsigned short* d_first, const double* d_E, const double* d_cvec, double* d_Aout, bool rec,
                             double kappa);

@@ -16,6 +16,7 @@ struct SampleSet {
     std::vector<float> val;         // luminance
     std::vector<float4> packed;     // {row, col, lum, 0}
     bool quantised = false;         // whole plane integer valued in [0, 255] (checked on request)
+    unsigned level_tiles = 0xffffu; // then: which 16-level tiles occur in this rank's part of the plane (bit t)
 };
 
 // d_lum: base of the FULL plane -- real, or virtual when the ctx takes slab input (only rows [row0, row1) of this rank
@@ -27,16 +28,18 @@ SampleSet fetch_samples(nle_ctx* c, const float* d_lum, const GridSpec& gs, bool
     s.p = gs.p();
     s.val.resize(s.p);
     int flag = 1;
+    int fl2[2] = {1, 0xffff};  // check_levels: [0] verdict, [1] level tiles
     if (slab_plane) {
         int row0, row1;
         slab(gs.H, c->rank, c->world, &row0, &row1);
         DevBuf<double> d_v((size_t)s.p + 1);
         PROFILED(c, NLE_K_SMALL, nlek::gather_samples_slab(c->stream, d_lum, gs, row0, row1, d_v.p));
         if (check_quantised) {
-            DevBuf<int> d_flag(1);
+            DevBuf<int> d_flag(2);
             PROFILED(c, NLE_K_SMALL, nlek::check_levels(c->stream, d_lum + (size_t)row0 * gs.W, (long long)(row1 - row0) * gs.W, d_flag.p));
-            HIP_OK(hipMemcpyAsync(&flag, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(hipMemcpyAsync(fl2, d_flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIP_OK(hipStreamSynchronize(c->stream));
+            flag = fl2[0];
         }
         const double fl = flag != 0 ? 1.0 : 0.0;
         HIP_OK(hipMemcpyAsync(d_v.p + s.p, &fl, sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -48,16 +51,18 @@ SampleSet fetch_samples(nle_ctx* c, const float* d_lum, const GridSpec& gs, bool
         flag = v[s.p] > 0.0 ? 1 : 0;
     } else {
         DevBuf<float> d_val(s.p);
-        DevBuf<int> d_flag(1);
+        DevBuf<int> d_flag(2);
         PROFILED(c, NLE_K_SMALL, nlek::gather_samples(c->stream, d_lum, gs, d_val.p));
         if (check_quantised) {
             PROFILED(c, NLE_K_SMALL, nlek::check_levels(c->stream, d_lum, (long long)gs.H * gs.W, d_flag.p));
-            HIP_OK(hipMemcpyAsync(&flag, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(hipMemcpyAsync(fl2, d_flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         }
         HIP_OK(hipMemcpyAsync(s.val.data(), d_val.p, s.p * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
+        if (check_quantised) flag = fl2[0];
     }
     s.quantised = check_quantised && flag == 0;
+    if (s.quantised && (fl2[1] & 0xffff) != 0) s.level_tiles = (unsigned)fl2[1] & 0xffffu;
     s.pix.resize(s.p);
     s.packed.resize(s.p);
     for (int k = 0; k < s.p; ++k) {
@@ -621,6 +626,13 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         HIP_OK(hipMemsetAsync(d_cbuf.p, 0, d_cbuf.n * sizeof(double), c->stream));  // sample pixels are never visited
         sr = nlek::SortedRows{d_scol.p, d_desc.p, d_first.p, d_E.p, false, 0.0};
         sr.rec = nlek::sorted_recurrence(ss.gs, hx, &sr.kappa);
+        if (std::getenv("NLE_ALL_LEVEL_TILES") == nullptr) {  // the tables' columns of level tiles that do not occur are skipped
+            int t0 = 0, t1 = 16;
+            while (t0 < 15 && !((ss.level_tiles >> t0) & 1u)) ++t0;
+            while (t1 > t0 + 1 && !((ss.level_tiles >> (t1 - 1)) & 1u)) --t1;
+            sr.lev_t0 = t0;
+            sr.lev_nt = t1 - t0;
+        }
         if (nlek::sorted_gsum_ok(ss.gs, hx)) {  // the Gram on index sums: one more distance table, exp(-2 d^2 / hx^2)
             d_E2.alloc((size_t)ss.gs.W + 1);
             PROFILED(c, NLE_K_SMALL, nlek::dist_table(c->stream, ss.gs.W, hx / std::sqrt(2.0), d_E2.p));
@@ -801,6 +813,8 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         if (sorted) {
             f->has_sorted = true;
             f->sorted = nlek::SortedRows{own(d_scol), own(d_desc), own(d_first), own(d_E), sr.rec, sr.kappa};
+            f->sorted.lev_t0 = sr.lev_t0;
+            f->sorted.lev_nt = sr.lev_nt;
         }
         f->h_Vrows = o.Vrows;
         f->h_sample_pix = ss.pix;

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
                                                     GridSpec gs, int row0, int nrows, const double* __restrict__ Etab,
                                                     const double* __restrict__ g, double eps, double* __restrict__ ybuf,
                                                     double* __restrict__ hout, const double* __restrict__ cvec,
-                                                    const float* __restrict__ xvec, double kappa) {
+                                                    const float* __restrict__ xvec, double kappa, int lev_t0, int lev_nt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int n = kLevels * NC;
     constexpr int SL = NC < 11 ? NC : 11;  // sums combined per tree (slices of the nC sums when nC > 11)
@@ -485,8 +485,12 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
                 if (has_next && tid < 258) sfirst[(par ^ 1) * 260 + tid] = sf_n;
             }
             const int ns = (NC - s0 < SL) ? NC - s0 : SL;
-            for (int i = tid; i < ns * kLevels; i += kT) {
-                const int bb = i / kLevels, xx = i & (kLevels - 1);
+            // only the level tiles that occur anywhere in the image are stored (k_hist_hh reads no others)
+            const int nlev = lev_nt * 16, xlo = lev_t0 * 16;
+            const float inv_nlev = 1.0f / (float)nlev;
+            for (int i = tid; i < ns * nlev; i += kT) {
+                const int bb = (int)(((float)i + 0.5f) * inv_nlev);  // i / nlev, exact: i < 12 * 256, (i + 0.5) / nlev is >= 1 / 512 off an integer
+                const int xx = xlo + (i - bb * nlev);
                 const int f0 = sfc[xx];
                 hrow[(size_t)(s0 + bb) * kLevels + xx] = sfc[xx + 1] > f0 ? sP[f0 * PS + bb] : 0.0;
             }
@@ -531,9 +535,11 @@ bool sorted_recurrence(GridSpec gs, double hx, double* kappa) {
 
 hipError_t sorted_pass(hipStream_t s, int mode, GridSpec gs, int row0, int nrows_local, const unsigned short* d_scol,
                        const uint2* d_desc, const unsigned short* d_first, const double* d_E, const double* d_g, double eps,
-                       double* d_ybuf, double* d_h, const double* d_cvec, const float* d_xvec, bool rec, double kappa) {
+                       double* d_ybuf, double* d_h, const double* d_cvec, const float* d_xvec, bool rec, double kappa,
+                       int lev_t0, int lev_nt) {
     const int nC = gs.nSelCols;
-    if (nC < 1 || nC > 36 || gs.W > sorted_max_width()) return hipErrorInvalidValue;
+    if (nC < 1 || nC > 36 || gs.W > sorted_max_width() || lev_t0 < 0 || lev_nt < 1 || lev_t0 + lev_nt > kLevels / 16)
+        return hipErrorInvalidValue;
     if (nrows_local <= 0) return hipSuccess;
     const size_t shm = sorted_lds_bytes(gs.W, (nC < 11 ? nC : 11) | 1);
     const int grid = sorted_grid(nrows_local);
@@ -545,7 +551,8 @@ hipError_t sorted_pass(hipStream_t s, int mode, GridSpec gs, int row0, int nrows
             if (ea != hipSuccess) return ea;                                                                              \
         }                                                                                                                 \
         hipLaunchKernelGGL((k_sorted_pass<NCV, RECV>), dim3((unsigned)grid), dim3(kT), shm, s, mode, d_scol, d_desc,       \
-                           d_first, gs, row0, nrows_local, d_E, d_g, eps, d_ybuf, d_h, d_cvec, d_xvec, kappa);            \
+                           d_first, gs, row0, nrows_local, d_E, d_g, eps, d_ybuf, d_h, d_cvec, d_xvec, kappa, lev_t0,     \
+                           lev_nt);                                                                                       \
     }
 #define NLE_SP(NCV)                                                                                                       \
     case NCV:                                                                                                             \

@@ -491,6 +491,43 @@ def test_gram_by_index_sums_equals_the_pair_table_form(nle, oracle, ctx, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("levels", [(96, 111), (120, 135), (0, 255), (3, 40), (250, 255), (77, 77)],
+                         ids=["one tile", "across two tiles", "full range", "low", "top tile", "flat"])
+def test_level_tiles_that_do_not_occur_are_skipped_exactly(nle, oracle, ctx, levels):
+    """The g / h tables of the Sinkhorn and apply passes have a column per (sample column, level); the columns of 16-level
+    tiles that occur nowhere in the image are neither made, stored nor contracted (check_levels reports the tiles).  Same
+    result as with all 16 tiles (NLE_ALL_LEVEL_TILES=1), to rounding, whatever the range -- and the oracle's."""
+    H, W, nr, nc, hx, hy, T, K, L = 96, 160, 6, 8, 40.0, 12.0, 8, 10, 3
+    lo, hi = levels
+    if hi - lo > 100:
+        hy = 40.0   # a photometric bandwidth in proportion to the range (12 on 0..255 is a numerically wild example)
+    base = oracle.synthetic_luminance(H, W)
+    if hi > lo:
+        x = np.rint(lo + (base - base.min()) * ((hi - lo) / max(base.max() - base.min(), 1.0)))
+        x[0, 0], x[-1, -1] = lo, hi
+    else:
+        x = np.full((H, W), float(lo))
+    V_o, S_o = oracle.train_filter(x, nr, nc, hx, hy, T, K)
+    Y_o = oracle.apply_layers(V_o, S_o, x, L).reshape(L, -1)
+    f1, Y1 = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
+    os.environ["NLE_ALL_LEVEL_TILES"] = "1"
+    try:
+        f2, Y2 = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
+    finally:
+        del os.environ["NLE_ALL_LEVEL_TILES"]
+    assert f1.diag() == f2.diag() and f1.diag()["formulation"] == nle.MODE_PHI_FREE
+    assert f1.eigvals.size == S_o.size
+    assert rel_l2(f1.eigvals, f2.eigvals) < 1e-11
+    assert rel_l2(f1.eigvals, S_o) < 1e-8
+    for j in range(L):
+        assert rel_l2(Y1[j], Y2[j]) < 1e-7, (j, rel_l2(Y1[j], Y2[j]))
+        if np.linalg.norm(Y_o[j]) > 1e-9:
+            assert rel_l2(Y1[j], Y_o[j]) < 1e-4, (j, rel_l2(Y1[j], Y_o[j]))
+    f1.close()
+    f2.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["non-integer", "wide grid", "many eigenvectors"])
 def test_streamed_fp64_form_takes_what_does_not_fit(nle, oracle, ctx, kind):
     """NLE_MODE_STREAMED_F64: the fp64 fallback WITHOUT the N x r matrix (affinity rows regenerated chunk by chunk, bounded
