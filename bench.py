@@ -47,7 +47,16 @@ FP64_MFMA_PEAK_TF = 78.6    # MI355X FP64 matrix peak (spec; SURVEY.md section 8
 LDS_F64_ATOMIC_PEAK = 1.49e12  # measured: tools/micro/lds_atomic_bench.hip, ds_add_f64 on a 256 x 11 histogram, random levels
 
 
-def roofline_models(info, L, form, grid, lazy=False):
+def gram_on_index_sums(grid, W, hx):
+    """mirror of sorted_gsum_ok (csrc/sorted.hip): on the equispaced sample grid the Gram stage runs on 2 nC - 1 index-sum
+    tables per image row and 2 nR - 1 GEMM rows instead of nC (nC + 1) / 2 and nR (nR + 1) / 2"""
+    if os.environ.get("NLE_GRAM_PAIRS") or W > 8192:
+        return False
+    cs, nC = float(grid["col_step"]), float(grid["n_sel_cols"])
+    return 2.0 * W * W / (hx * hx) < 600.0 and (2.0 * cs * W + 2.0 * nC * cs * cs) / (hx * hx) < 600.0
+
+
+def roofline_models(info, L, form, grid, lazy=False, gsum=False):
     """kernel name -> (bound, algorithmic units per launch, peak) for this rank (n = pixels of its slab).
 
     Per-unit figures are SURVEY.md section 8(d)'s (fp32 storage, s = 4 B) where the kernel still does the
@@ -87,8 +96,12 @@ def roofline_models(info, L, form, grid, lazy=False):
             # + 516 B) instead of 4 B of luminance
             srt = n * 2.0 + rows * (512 * 8.0 + 516.0)
             m["sinkhorn_pass"] = ("hbm", srt + 2.0 * tab, HBM_PEAK_GBS)  # sorted row + g in + h out
-            m["gram_rows"] = ("hbm", srt + n * 8.0 + rows * 256.0 * npair * 8.0, HBM_PEAK_GBS)
-            m["gram_gemm"] = ("mfma", 2.0 * ldm * 256.0 * npair * rows, FP64_MFMA_PEAK_TF)
+            if gsum:  # index sums: 2 nC - 1 tables per image row, GEMM with 2 nR - 1 (padded to 16) rows
+                ntab, ldm = 2.0 * nC - 1.0, ((2 * nR - 1) + 15) // 16 * 16
+            else:
+                ntab = npair
+            m["gram_rows"] = ("hbm", srt + n * 8.0 + rows * 256.0 * ntab * 8.0, HBM_PEAK_GBS)
+            m["gram_gemm"] = ("mfma", 2.0 * ldm * 256.0 * ntab * rows, FP64_MFMA_PEAK_TF)
             if lazy:  # V stays implicit: apply runs on the tables too (bytes the two kernels really move)
                 m["apply_reduce"] = ("hbm", srt + n * (8.0 + s) + tab, HBM_PEAK_GBS)      # sorted row, c, x in; h out
                 lb = max(1, min(L, 4, (144 * 1024) // (256 * (nC | 1) * 8)))             # layers per expand launch
@@ -124,7 +137,7 @@ def kernel_symbols(form, lazy):
         sym.update({"sinkhorn_pass": ("k_sink_pass",), "gram": ("k_gram64",)})
     else:
         sym.update({"sinkhorn_pass": ("k_sorted_pass", "k_hist_pix"), "sink_tables": ("k_hist_g",),
-                    "gram_rows": ("k_sorted_gram", "k_ghist_rows"), "gram_gemm": ("k_ghist_gemm",)})
+                    "gram_rows": ("k_sorted_gsum", "k_sorted_gram", "k_ghist_rows"), "gram_gemm": ("k_ghist_gemm",)})
         if lazy:  # the apply's reduce half is the pass kernel in its XVEC mode: same symbol as the Sinkhorn pass
             sym.update({"apply_expand": ("k_sorted_expand", "k_hist_dot"), "apply_reduce": ("k_sorted_pass", "k_hist_pix")})
     return sym
@@ -452,7 +465,8 @@ def main():
     form_label = {1: "materialised_f32", 2: "phi_free_tables", 3: "phi_free_exp_f32", 4: "materialised_f64",
                   5: "streamed_f64 (no N x r matrix: fp64 affinity rows regenerated chunk by chunk)"}.get(flt.diag()["formulation"], form)
     lazy = form == "phi_free_tables" and "project" not in ran
-    models = roofline_models(info, L, form, g, lazy)
+    gsum = form == "phi_free_tables" and gram_on_index_sums(g, W, cfg["hx"])
+    models = roofline_models(info, L, form, g, lazy, gsum)
     # (the committed PMC summary was collected at N = 1 on the default config: per-launch bytes of a row slab or of
     # another config differ, so `traffic` is only attached to that case)
     traffic = load_traffic() if (world == 1 and args.config == "cfg4" and args.simulate_world <= 1) else {}
@@ -473,9 +487,10 @@ def main():
                 rec["hbm_equivalent_GBs"] = info["n_local"] * info["r"] * 4.0 / (avg_ms * 1e-3) / 1e9
             if form == "phi_free_tables" and name in ("sinkhorn_pass", "apply_reduce", "gram_rows"):
                 # what bounds the level-sorted pixel kernels: fp64 multiply-adds on the vector pipe (2 nC per pixel
-                # for a pass + the reciprocal, nC(nC+1)/2 + nC for the Gram) and nC LDS table reads per pixel
+                # for a pass + the reciprocal; for the Gram nC(nC+1)/2 + nC in the pair form, a recurrence step + an add per
+                # index-sum table otherwise) and nC LDS table reads per pixel
                 nc_ = g["n_sel_cols"]
-                fma = (2 * nc_ + 8) if name != "gram_rows" else (nc_ * (nc_ + 1) // 2 + nc_)
+                fma = (2 * nc_ + 8) if name != "gram_rows" else ((2 * (2 * nc_ - 1) + 2) if gsum else (nc_ * (nc_ + 1) // 2 + nc_))
                 rec["valu_f64"] = {"achieved": 2.0 * fma * info["n_local"] / (avg_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TF,
                                    "unit": "TFLOP/s (fp64 vector == matrix peak)",
                                    "frac": 2.0 * fma * info["n_local"] / (avg_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF}
