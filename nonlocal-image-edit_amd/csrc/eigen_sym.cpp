@@ -899,18 +899,159 @@ bool tridiag_inverse_iteration(int n, const double* d, const double* e, const do
     }
     return true;
     };
+    // A LARGE cluster (the ~100 eigenvalues the 1e-10 cut drops from a 900 x 900 Wa, all within ortol of each other) spends
+    // its time in the vector-by-vector re-orthogonalisation, a chain nothing can be overlapped with.  Its eigenvalues are
+    // known to ~eps ||T|| while they differ by far more, so plain inverse iteration (no orthogonalisation, every vector
+    // independent of the others: threads) already isolates each vector to ~eps ||T|| / gap; ONE Cholesky-QR of the block
+    // (two level-3 products) then makes it orthonormal to rounding, moving every vector by that same small amount inside
+    // the cluster's invariant subspace.  Numerically repeated eigenvalues give (random, independent) vectors of their
+    // eigenspace -- a worse conditioned block: then a second Cholesky-QR, and if the Gram matrix does not factor at all the
+    // cluster goes through the sequential path.  Residuals are checked against the same bound as there.
+    constexpr int kBlockMin = 24;
+    auto do_group_block = [&](int gp, int gend) -> bool {
+        const int mc = gend - gp;
+        std::vector<double> shift(mc);
+        {
+            double prev = 0.0;
+            for (int j = gp; j < gend; ++j) {
+                double xj = lam[j];
+                if (j > gp) {
+                    const double pertol = 10.0 * eps * std::max(std::fabs(xj), tiny);
+                    if (prev - xj < pertol) xj = prev - pertol;
+                }
+                prev = xj;
+                shift[j - gp] = xj;
+            }
+        }
+        double* Zg = Z + (size_t)gp * n;
+        const int nt = std::min(4, std::max(1, mc / 8));
+        std::vector<char> okv(nt, 1);
+        run_split(nt, nt, [&](int t) {
+            std::vector<double> a(n), ra(n), b(n), c(n), dd(n), x(n), y(n);
+            std::vector<char> piv(n);
+            for (int jj = (int)((long long)mc * t / nt); jj < (int)((long long)mc * (t + 1) / nt); ++jj) {
+                const int j = gp + jj;
+                const double xj = shift[jj];
+                unsigned long long seed = 0x2545F4914F6CDD1Dull ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(j + 1));
+                for (int i = 0; i < n; ++i) {
+                    a[i] = d[i] - xj;
+                    b[i] = (i + 1 < n) ? e[i + 1] : 0.0;
+                    c[i] = (i + 1 < n) ? e[i + 1] : 0.0;
+                    dd[i] = 0.0;
+                }
+                for (int i = 0; i + 1 < n; ++i) {
+                    if (std::fabs(a[i]) >= std::fabs(c[i])) {
+                        if (std::fabs(a[i]) < tiny) a[i] = std::copysign(tiny, a[i] == 0.0 ? 1.0 : a[i]);
+                        const double mult = c[i] / a[i];
+                        a[i + 1] -= mult * b[i];
+                        c[i] = mult;
+                        piv[i] = 0;
+                    } else {
+                        const double mult = a[i] / c[i];
+                        a[i] = c[i];
+                        const double tt = a[i + 1];
+                        a[i + 1] = b[i] - mult * tt;
+                        if (i + 2 < n) {
+                            dd[i] = b[i + 1];
+                            b[i + 1] = -mult * dd[i];
+                        }
+                        b[i] = tt;
+                        c[i] = mult;
+                        piv[i] = 1;
+                    }
+                }
+                if (std::fabs(a[n - 1]) < tiny) a[n - 1] = std::copysign(tiny, a[n - 1] == 0.0 ? 1.0 : a[n - 1]);
+                for (int i = 0; i < n; ++i) ra[i] = 1.0 / a[i];
+                for (int i = 0; i < n; ++i) {
+                    seed ^= seed << 13, seed ^= seed >> 7, seed ^= seed << 17;
+                    x[i] = (double)(seed >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+                }
+                for (int it = 0; it < 3; ++it) {
+                    double s1 = 0.0;
+                    for (int i = 0; i < n; ++i) s1 += std::fabs(x[i]);
+                    const double scl = n * onenrm * std::max(eps, std::fabs(a[n - 1])) / std::max(s1, 1e-300);
+                    for (int i = 0; i < n; ++i) y[i] = x[i] * scl;
+                    for (int i = 0; i + 1 < n; ++i) {
+                        if (piv[i]) std::swap(y[i], y[i + 1]);
+                        y[i + 1] -= c[i] * y[i];
+                    }
+                    for (int i = n - 1; i >= 0; --i) {
+                        double tt = y[i];
+                        if (i + 1 < n) tt -= b[i] * x[i + 1];
+                        if (i + 2 < n) tt -= dd[i] * x[i + 2];
+                        x[i] = tt * ra[i];
+                    }
+                    double nrm = 0.0;
+                    for (int i = 0; i < n; ++i) nrm += x[i] * x[i];
+                    nrm = std::sqrt(nrm);
+                    if (!(nrm > 0.0) || !std::isfinite(nrm)) {
+                        okv[t] = 0;
+                        return;
+                    }
+                    for (int i = 0; i < n; ++i) x[i] /= nrm;
+                }
+                std::copy(x.begin(), x.end(), Zg + (size_t)jj * n);
+            }
+        });
+        for (char v : okv)
+            if (!v) return false;
+        // Cholesky-QR: G = Z^T Z = L L^T, Z <- Z L^-T; again if the block was far from orthonormal
+        std::vector<double> Zt((size_t)mc * n), G((size_t)mc * mc), Li((size_t)mc * mc), Zn((size_t)n * mc);
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int j = 0; j < mc; ++j)
+                for (int i = 0; i < n; ++i) Zt[(size_t)i * mc + j] = Zg[(size_t)j * n + i];
+            gemm_nn_cols(Zt.data(), Zg, G.data(), mc, n, mc, 0, mc);  // (mc x n) (n x mc)
+            double off = 0.0;
+            for (int j = 0; j < mc; ++j)
+                for (int i = 0; i < mc; ++i)
+                    if (i != j) off = std::max(off, std::fabs(G[(size_t)j * mc + i]));
+            if (pass == 1 && off < 1e-13) break;  // already orthonormal to rounding
+            for (int j = 0; j < mc; ++j)
+                for (int i = 0; i < j; ++i) G[(size_t)j * mc + i] = 0.0;  // lower triangle only
+            if (!cholesky_lower(mc, G.data(), 1e-10)) return false;  // (nearly) dependent vectors: the sequential path
+            lower_inverse(mc, G.data(), Li.data());
+            gemm_nt_cols(Zg, Li.data(), Zn.data(), n, mc, mc, 0, mc);  // Z L^-T
+            std::copy(Zn.begin(), Zn.end(), Zg);
+            if (pass == 0 && off < 1e-5) break;  // one pass leaves an error ~ eps (1 + off^2 ...): enough
+        }
+        for (int jj = 0; jj < mc; ++jj) {  // residual ||(T - lam I) x||_2 against the ORIGINAL eigenvalue
+            const double* x = Zg + (size_t)jj * n;
+            const double lj = lam[gp + jj];
+            double res = 0.0;
+            for (int i = 0; i < n; ++i) {
+                double tt = (d[i] - lj) * x[i];
+                if (i > 0) tt += e[i] * x[i - 1];
+                if (i + 1 < n) tt += e[i + 1] * x[i + 1];
+                res += tt * tt;
+            }
+            if (!(std::sqrt(res) <= 1e3 * eps * onenrm)) return false;
+        }
+        return true;
+    };
+    static const bool no_block = std::getenv("NLE_EIG_NO_BLOCK") != nullptr;
+    std::vector<char> done_group(ngroups, 0);
+    if (!no_block)
+        for (int g = 0; g < ngroups; ++g)
+            if (starts[g + 1] - starts[g] >= kBlockMin) {
+                const bool blk = do_group_block(starts[g], starts[g + 1]);
+                if (std::getenv("NLE_EIG_TRACE"))
+                    std::fprintf(stderr, "[nle eig] cluster of %d vectors: %s\n", starts[g + 1] - starts[g],
+                                 blk ? "block inverse iteration + Cholesky-QR" : "block form gave up, vector by vector");
+                if (!blk && !do_group(starts[g], starts[g + 1])) return false;
+                done_group[g] = 1;
+            }
     // work of a cluster of m vectors ~ m n (8 + m) (solves + re-orthogonalisation), ~2.6 ns per unit on the GPU box's cores;
     // threads (~0.1 ms to start and join) pay off from ~0.8 ms of it
     double work = 0.0;
     for (int g = 0; g < ngroups; ++g) {
-        const double m = starts[g + 1] - starts[g];
+        const double m = done_group[g] ? 0.0 : starts[g + 1] - starts[g];
         work += m * n * (8.0 + m);
     }
     int nthreads = (ngroups >= 2 && work > 3e5) ? std::min(4, ngroups) : 1;
     if (const char* ev = std::getenv("NLE_EIG_THREADS")) nthreads = std::max(1, std::min(std::atoi(ev), ngroups));
     if (nthreads <= 1) {
         for (int g = 0; g < ngroups; ++g)
-            if (!do_group(starts[g], starts[g + 1])) return false;
+            if (!done_group[g] && !do_group(starts[g], starts[g + 1])) return false;
         return true;
     }
     // contiguous runs of clusters of about equal work per thread
@@ -920,7 +1061,7 @@ bool tridiag_inverse_iteration(int n, const double* d, const double* e, const do
         double acc = 0.0;
         int t = 1;
         for (int g = 0; g < ngroups && t < nthreads; ++g) {
-            const double m = starts[g + 1] - starts[g];
+            const double m = done_group[g] ? 0.0 : starts[g + 1] - starts[g];
             acc += m * n * (8.0 + m);
             if (acc >= work * t / nthreads) cut[t++] = g + 1;
         }
@@ -928,7 +1069,7 @@ bool tridiag_inverse_iteration(int n, const double* d, const double* e, const do
     std::vector<char> okv(nthreads, 1);
     run_split(nthreads, nthreads, [&](int t) {
         for (int g = cut[t]; g < cut[t + 1]; ++g)
-            if (!do_group(starts[g], starts[g + 1])) {
+            if (!done_group[g] && !do_group(starts[g], starts[g + 1])) {
                 okv[t] = 0;
                 return;
             }
