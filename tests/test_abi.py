@@ -207,6 +207,9 @@ def test_leading_eigenvectors_by_inverse_iteration(nle):
     # enough vectors in enough separate clusters that the clusters are dealt to threads (csrc/eigen_sym.cpp)
     lam = np.sort(np.concatenate([np.linspace(1.0, 0.3, 60), 0.25 - 1e-9 * np.arange(30), rng.uniform(0, 0.2, 810)]))[::-1]
     cases.append(("threads", 900, 100, lam))
+    # one cluster of 100 (60 eigenvalues 1e-12 apart, 40 exactly repeated): block inverse iteration + Cholesky-QR, two passes
+    lam = np.sort(np.concatenate([1.0 - 1e-10 * rng.uniform(0, 1, 60), np.full(40, 1.0 - 2e-10), rng.uniform(0, 0.9, 800)]))[::-1]
+    cases.append(("block cluster", 900, 120, lam))
     for name, n, k, lam in cases:
         X = np.linalg.qr(rng.standard_normal((n, n)))[0]
         A = (X * lam) @ X.T
