@@ -491,6 +491,29 @@ def test_gram_by_index_sums_equals_the_pair_table_form(nle, oracle, ctx, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("where", [(0, 0), (0, 1), (17, 63), (40, 129), (95, 159), (33, 2)])
+def test_one_non_integer_pixel_anywhere_keeps_the_plane_off_the_tables(nle, oracle, ctx, where):
+    """auto mode takes the table formulation only when EVERY pixel is an integer in [0, 255] (k_check_levels): one pixel
+    that is not -- in any lane of any wave, at either end of an unaligned plane -- sends the plane to the general fp64 form,
+    and the result is still the oracle's"""
+    H, W, nr, nc, hx, hy, T, K, L = 96, 160, 6, 8, 40.0, 30.0, 6, 8, 3
+    x = oracle.synthetic_luminance(H, W).copy()
+    x[where] += 0.5
+    V_o, S_o = oracle.train_filter(x, nr, nc, hx, hy, T, K)
+    Y_o = oracle.apply_layers(V_o, S_o, x, L).reshape(L, -1)
+    f, Y = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
+    assert f.diag()["formulation"] in (nle.MODE_MATERIALISED_F64, nle.MODE_STREAMED_F64)
+    for j in range(L):
+        assert rel_l2(Y[j], Y_o[j]) < 1e-4
+    f.close()
+    x2 = oracle.synthetic_luminance(H, W).copy()
+    x2[where] = 256.0      # an integer, but not a level
+    f2, _ = _run_device(nle, ctx, x2, nr, nc, hx, hy, T, K, L)
+    assert f2.diag()["formulation"] in (nle.MODE_MATERIALISED_F64, nle.MODE_STREAMED_F64)
+    f2.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("levels", [(96, 111), (120, 135), (0, 255), (3, 40), (250, 255), (77, 77)],
                          ids=["one tile", "across two tiles", "full range", "low", "top tile", "flat"])
 def test_level_tiles_that_do_not_occur_are_skipped_exactly(nle, oracle, ctx, levels):
