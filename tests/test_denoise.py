@@ -142,3 +142,26 @@ def test_bilateral8_refuses_a_plane_that_is_not_8_bit(nle, ctx):
     with pytest.raises(nle.NLEError):
         f.apply(y, np.ones(f.info()["K"] + 1))
     f.close()
+
+
+@pytest.mark.gpu
+def test_level_check_on_planes_that_are_not_16_byte_aligned(nle, ctx):
+    """k_check_levels reads the plane with 16-byte loads between a scalar head and tail: a plane that starts 1, 2 or 3 floats
+    off alignment (a row slab of an odd-width image does) is checked to its first and last pixel all the same"""
+    import torch
+    rng = np.random.default_rng(4)
+    H, W = 37, 53                       # H * W is odd as well
+    y = rng.integers(0, 256, (H, W)).astype(np.float32)
+    want = ctx.bilateral8(y, 12.0, 2.0).cpu().numpy()
+    for off in (1, 2, 3):
+        buf = torch.zeros(H * W + 8, dtype=torch.float32, device="cuda:0")
+        view = buf[off:off + H * W].view(H, W)
+        view.copy_(torch.from_numpy(y))
+        assert view.data_ptr() % 16 == 4 * off
+        assert np.array_equal(ctx.bilateral8(view, 12.0, 2.0).cpu().numpy(), want)
+        for pos in ((0, 0), (0, 2), (H - 1, W - 1), (H - 1, W - 3), (H // 2, W // 2)):
+            keep = float(view[pos])
+            view[pos] = keep + 0.5
+            with pytest.raises(nle.NLEError):
+                ctx.bilateral8(view, 12.0, 2.0)
+            view[pos] = keep
