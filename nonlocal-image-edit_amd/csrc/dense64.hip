@@ -20,6 +20,7 @@
 //                     block rows on k_gemm64s (fp64 MFMA).
 // The eigenvectors of T for the wanted eigenvalues come from the host's inverse iteration (eigen_sym.cpp, O(n k)).
 #include "kernels.h"
+#include "handoff.h"
 
 #include <algorithm>
 
@@ -27,37 +28,9 @@ namespace nlek {
 
 namespace {
 
-typedef unsigned long long u64;
-constexpr u64 kUnset = ~0ull;  // a NaN no arithmetic produces (hardware NaNs are 0x7FF8.. / 0xFFF8..)
+using namespace handoff;
 constexpr int kSyT = 256;      // threads per workgroup of the reduction
 constexpr int kSyRows = 5;     // rows per thread: n <= 1152 < 5 * 256
-constexpr unsigned kSpinLimit = 1u << 22;
-
-__device__ __forceinline__ u64 ld_pub(const double* p) {
-    return __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_pub(double* p, double v) {
-    __hip_atomic_store(reinterpret_cast<u64*>(p), (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// re-read one published word until it is set; gives up (fail = true) after kSpinLimit polls or when another workgroup
-// has flagged the launch as failed
-__device__ __forceinline__ double wait_pub(const double* p, const int* status, bool& fail) {
-    u64 b;
-    unsigned spins = 0;
-    while ((b = ld_pub(p)) == kUnset) {
-        if (++spins > kSpinLimit) {
-            fail = true;
-            break;
-        }
-        if ((spins & 1023u) == 0 &&
-            __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            fail = true;
-            break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return __longlong_as_double((long long)b);
-}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
