@@ -132,6 +132,11 @@ int nle_ctx_set_topk_solver(nle_ctx* ctx, int solver);
 int nle_rccl_unique_id(void* h_id, size_t size);
 int nle_ctx_init_rccl(nle_ctx* ctx, int rank, int world, const void* h_id, size_t size);
 int nle_ctx_set_rccl_comm(nle_ctx* ctx, int rank, int world, void* nccl_comm);
+/* Error path of a multi-rank host: aborts the ctx's own communicator (ncclCommAbort) so that collectives of this ctx that
+ * are waiting for a rank that has failed end instead of blocking for ever; callable from another thread than the one using
+ * the ctx.  Afterwards every call on the ctx that needs a collective returns NLE_ERR_COMM until nle_ctx_init_rccl binds a
+ * new communicator.  No-op without an own communicator. */
+int nle_ctx_abort_rccl(nle_ctx* ctx);
 /* Callback form (any transport, e.g. gloo in the CPU rehearsal tests): */
 typedef int (*nle_allreduce_fn)(void* user, void* d_buf, size_t count);
 int nle_ctx_set_shard(nle_ctx* ctx, int rank, int world, nle_allreduce_fn allreduce,

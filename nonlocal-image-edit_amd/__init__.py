@@ -246,6 +246,10 @@ class Context:
         _check(lib().nle_ctx_init_rccl(self._h, int(rank), int(world), buf, 128), self._h)
         self.rank, self.world = rank, world
 
+    def abort_rccl(self):
+        """nle_ctx_abort_rccl: the error path of a multi-rank host (collectives of this ctx fail from here on)"""
+        _check(lib().nle_ctx_abort_rccl(self._h))
+
     def synchronize(self):
         _check(lib().nle_ctx_synchronize(self._h), self._h)
 

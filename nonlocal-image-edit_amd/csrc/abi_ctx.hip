@@ -52,7 +52,7 @@ void nle_ctx_destroy(nle_ctx* ctx) {
     }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->comm && ctx->own_comm) (void)rccl().CommDestroy(ctx->comm);
+    if (ctx->comm && ctx->own_comm && !ctx->comm_aborted.load()) (void)rccl().CommDestroy(ctx->comm);
     for (auto* f : ctx->filters) f->ctx = nullptr;  // their V is freed directly when they are destroyed
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     for (auto e : ctx->copy_ev)
@@ -307,8 +307,9 @@ int nle_ctx_init_rccl(nle_ctx* ctx, int rank, int world, const void* h_id, size_
     return guard(ctx, [&] {
         if (world < 1 || rank < 0 || rank >= world) throw Fail{NLE_ERR_INVALID, "bad rank/world"};
         HIP_OK(hipSetDevice(ctx->device));
-        if (ctx->comm && ctx->own_comm) (void)rccl().CommDestroy(ctx->comm);
-        ctx->comm = nullptr;
+        if (ctx->comm && ctx->own_comm && !ctx->comm_aborted.load()) (void)rccl().CommDestroy(ctx->comm);
+        ctx->comm = nullptr;  // (an aborted communicator has been freed by ncclCommAbort)
+        ctx->comm_aborted.store(0);
         ncclUniqueId id;
         std::memcpy(id.internal, h_id, NCCL_UNIQUE_ID_BYTES);
         ncclComm_t comm = nullptr;
@@ -321,13 +322,26 @@ int nle_ctx_init_rccl(nle_ctx* ctx, int rank, int world, const void* h_id, size_
     });
 }
 
+int nle_ctx_abort_rccl(nle_ctx* ctx) {
+    if (!ctx) return NLE_ERR_INVALID;
+    // no guard(): this may run on another thread than the one that uses the ctx (whose error string it must not touch)
+    if (!ctx->comm || !ctx->own_comm) return NLE_OK;
+    if (ctx->comm_aborted.exchange(1, std::memory_order_acq_rel) != 0) return NLE_OK;
+    try {
+        return rccl().CommAbort(ctx->comm) == ncclSuccess ? NLE_OK : NLE_ERR_COMM;
+    } catch (...) {
+        return NLE_ERR_COMM;
+    }
+}
+
 int nle_ctx_set_rccl_comm(nle_ctx* ctx, int rank, int world, void* comm) {
     if (!ctx || !comm) return NLE_ERR_INVALID;
     return guard(ctx, [&] {
         if (world < 1 || rank < 0 || rank >= world) throw Fail{NLE_ERR_INVALID, "bad rank/world"};
         (void)rccl();  // the all-reduce goes through the loaded library
-        if (ctx->comm && ctx->own_comm) (void)rccl().CommDestroy(ctx->comm);
+        if (ctx->comm && ctx->own_comm && !ctx->comm_aborted.load()) (void)rccl().CommDestroy(ctx->comm);
         ctx->comm = reinterpret_cast<ncclComm_t>(comm);
+        ctx->comm_aborted.store(0);
         ctx->own_comm = false;
         ctx->rank = rank;
         ctx->world = world;

@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <chrono>
 #include <cmath>
@@ -37,6 +38,7 @@ struct nle_ctx {
     void* ar_user = nullptr;
     ncclComm_t comm = nullptr;  // native RCCL (nle_ctx_init_rccl / nle_ctx_set_rccl_comm): all-reduce in place on `stream`
     bool own_comm = false;
+    std::atomic<int> comm_aborted{0};  // nle_ctx_abort_rccl (possibly from another thread): collectives fail from here on
     double* d_comm = nullptr;
     size_t comm_len = 0;
     std::string err;
@@ -325,6 +327,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -346,6 +349,7 @@ inline RcclApi& rccl() {
         a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
         a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
         a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+        a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(sym("ncclCommAbort"));
         a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
         return a;
@@ -360,6 +364,8 @@ inline RcclApi& rccl() {
 
 // sum over ranks of n doubles at device pointer d (stream ordered)
 inline void all_reduce(nle_ctx* c, double* d, size_t n) {
+    if (c->comm_aborted.load(std::memory_order_acquire))
+        throw Fail{NLE_ERR_COMM, "the communicator of this ctx was aborted (another rank failed)"};
     if (c->comm) {  // native: one ncclAllReduce in place on the ctx's stream (also for world == 1: same code path)
         RCCL_OK(rccl().AllReduce(d, d, n, ncclDouble, ncclSum, c->comm, c->stream));
         return;

@@ -73,9 +73,16 @@ struct DeviceGroup {
         }
     }
     void fail() {
-        std::lock_guard<std::mutex> lk(mu);
-        failed = true;
-        cv.notify_all();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            failed = true;
+            cv.notify_all();  // ranks waiting in the host-mediated all-reduce
+        }
+        // ranks waiting in a native collective for the one that failed: abort every communicator of the group, their
+        // pending ncclAllReduce ends and their next call returns NLE_ERR_COMM (the group is rebuilt by the next train)
+        if (native)
+            for (nle_ctx* c : ctx)
+                if (c) (void)nle_ctx_abort_rccl(c);
     }
     static int allreduce_cb(void* user, void* d_buf, size_t count) {
         Rank* me = static_cast<Rank*>(user);

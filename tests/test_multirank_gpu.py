@@ -254,3 +254,28 @@ def test_one_rank_short_of_memory_makes_every_rank_stream(nle, tmp_path):
     assert [int(r["code"]) for r in recs] == [0, 0]
     assert [int(r["form"]) for r in recs] == [nle.MODE_STREAMED_F64] * 2
     assert all(np.isfinite(r["Y"]).all() for r in recs)
+
+
+@pytest.mark.gpu
+def test_aborted_communicator_fails_collectives_until_rebound(nle, oracle):
+    """nle_ctx_abort_rccl (what a multi-rank host calls on every ctx when one rank has failed, so that the others' pending
+    collectives end): afterwards a train on the ctx returns NLE_ERR_COMM instead of entering a collective, a second abort
+    is a no-op, and nle_ctx_init_rccl binds a fresh communicator that works"""
+    H, W, nr, nc, hx, hy, T, K, L = 64, 96, 5, 6, 28.0, 30.0, 5, 8, 3
+    x = oracle.synthetic_luminance(H, W).astype(np.float32)
+    c = nle.Context(0)
+    c.abort_rccl()                                   # no communicator: nothing to do
+    f = nle.NLEFilter(c).train_filter(x, nr, nc, hx, hy, T, K)
+    Y0 = f.apply_layers(x, L).cpu().numpy()
+    f.close()
+    c.init_rccl(0, 1, nle.rccl_unique_id())
+    c.abort_rccl()
+    c.abort_rccl()
+    with pytest.raises(nle.NLEError) as ei:
+        nle.NLEFilter(c).train_filter(x, nr, nc, hx, hy, T, K)
+    assert ei.value.code == nle.NLE_ERR_COMM
+    c.init_rccl(0, 1, nle.rccl_unique_id())
+    f = nle.NLEFilter(c).train_filter(x, nr, nc, hx, hy, T, K)
+    assert np.array_equal(f.apply_layers(x, L).cpu().numpy(), Y0)
+    f.close()
+    c.close()
