@@ -4,7 +4,7 @@ import __graft_entry__ as entry
 import torch
 nle = entry.load_package()
 synth = entry._load("nle_amd_synthetic", os.path.join(entry.PKG_DIR, "synthetic.py"))
-cfg = synth.CONFIGS["cfg4"]
+cfg = synth.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg4"]
 H, W, L = cfg["H"], cfg["W"], cfg["L"]
 ctx = nle.Context(0)
 lum = torch.from_numpy(np.ascontiguousarray(synth.synthetic_luminance(H, W), dtype=np.float32)).cuda()
