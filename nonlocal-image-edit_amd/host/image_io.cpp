@@ -10,7 +10,8 @@
 
 namespace nle {
 
-Image read_jpeg(const std::vector<unsigned char>& b);  // jpeg.cpp
+Image read_jpeg(const std::vector<unsigned char>& b);                                // jpeg.cpp
+bool write_jpeg(std::vector<unsigned char>* out, const Image& bgr, int quality);    // jpeg.cpp
 
 namespace {
 
@@ -433,6 +434,10 @@ bool imwrite(const std::string& path, const Image& img) {
             out.push_back(s[3 * i + 1]);
             out.push_back(s[3 * i + 0]);
         }
+        return write_all(path, out);
+    }
+    if (ends_with(path, ".jpg") || ends_with(path, ".jpeg")) {  // cv::imwrite's default quality
+        if (!write_jpeg(&out, img, 95)) return false;
         return write_all(path, out);
     }
     if (ends_with(path, ".png")) {

@@ -14,6 +14,7 @@
 //   * "fancy" chroma upsampling (triangle filter: 3/4 nearer + 1/4 farther sample, the published rounding pattern),
 //   * YCbCr -> RGB in 16-bit fixed point.
 // tests/test_jpeg.py holds the output to Pillow's (libjpeg-turbo, same defaults) bit for bit on files of every supported kind.
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -687,6 +688,230 @@ Image read_jpeg(const std::vector<unsigned char>& b) {
         }
     }
     return img;
+}
+
+// ------------------------------------------------------------------------------------------------ writer
+// Baseline JPEG out (cv::imwrite's role for a .jpg result, reference src/enhance.cpp:47): 8-bit YCbCr 4:2:0, the standard
+// (ITU T.81 Annex K) quantisation tables scaled by `quality` the IJG way and the standard Huffman tables, JFIF header.
+// Colour conversion and 2 x 2 chroma averaging in the integer arithmetic the IJG documentation gives; the forward DCT in
+// double precision.  An output format, not part of any parity claim.
+namespace {
+
+const unsigned char kQLum[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,  14, 13, 16, 24, 40,  57,
+                                 69, 56, 14, 17, 22,  29,  51,  87,  80, 62, 18, 22, 37,  56,  68,  109, 103, 77, 24, 35, 55,  64,
+                                 81, 104, 113, 92, 49, 64,  78,  87,  103, 121, 120, 101, 72,  92,  95,  98, 112, 100, 103, 99};
+const unsigned char kQChr[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99,
+                                 99, 99, 47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+const unsigned char kDcLumBits[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const unsigned char kDcChrBits[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const unsigned char kDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const unsigned char kAcLumBits[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const unsigned char kAcLumVals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81,
+    0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18,
+    0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48,
+    0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75,
+    0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99,
+    0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5,
+    0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+const unsigned char kAcChrBits[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+const unsigned char kAcChrVals[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08,
+    0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25,
+    0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47,
+    0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74,
+    0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97,
+    0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba,
+    0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4,
+    0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+struct EncTable {
+    unsigned short code[256];
+    unsigned char len[256];
+    void build(const unsigned char* bits, const unsigned char* vals) {
+        std::memset(len, 0, sizeof len);
+        int code_ = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {
+            for (int i = 0; i < bits[l - 1]; ++i, ++k) {
+                code[vals[k]] = (unsigned short)code_++;
+                len[vals[k]] = (unsigned char)l;
+            }
+            code_ <<= 1;
+        }
+    }
+};
+
+struct BitSink {
+    std::vector<unsigned char>& out;
+    uint32_t acc = 0;
+    int n = 0;
+    void put(unsigned v, int bits) {  // bits <= 16
+        acc = (acc << bits) | (v & ((1u << bits) - 1u));
+        n += bits;
+        while (n >= 8) {
+            const unsigned char byte = (unsigned char)(acc >> (n - 8));
+            out.push_back(byte);
+            if (byte == 0xff) out.push_back(0x00);
+            n -= 8;
+        }
+    }
+    void flush() {
+        if (n > 0) put(0x7f, 8 - n);  // pad with ones
+    }
+};
+
+void put16(std::vector<unsigned char>& o, unsigned v) {
+    o.push_back((unsigned char)(v >> 8));
+    o.push_back((unsigned char)v);
+}
+
+void encode_block(BitSink& bs, const double* px /* 64 level-shifted samples */, const unsigned short* q, int* pred,
+                  const EncTable& dc, const EncTable& ac) {
+    // forward DCT, separable, double precision
+    static double C[8][8];
+    static bool init = false;
+    if (!init) {
+        for (int u = 0; u < 8; ++u)
+            for (int x = 0; x < 8; ++x) C[u][x] = (u == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0);
+        init = true;
+    }
+    double t[64], f[64];
+    for (int y = 0; y < 8; ++y)
+        for (int u = 0; u < 8; ++u) {
+            double s = 0.0;
+            for (int x = 0; x < 8; ++x) s += C[u][x] * px[y * 8 + x];
+            t[y * 8 + u] = s;
+        }
+    for (int v = 0; v < 8; ++v)
+        for (int u = 0; u < 8; ++u) {
+            double s = 0.0;
+            for (int y = 0; y < 8; ++y) s += C[v][y] * t[y * 8 + u];
+            f[v * 8 + u] = s;
+        }
+    int zz[64];
+    for (int k = 0; k < 64; ++k) {
+        const int nat = kZigzag[k];
+        zz[k] = (int)std::lrint(f[nat] / (double)q[nat]);
+    }
+    auto category = [](int v) {
+        int a = v < 0 ? -v : v, c = 0;
+        while (a) {
+            ++c;
+            a >>= 1;
+        }
+        return c;
+    };
+    const int diff = zz[0] - *pred;
+    *pred = zz[0];
+    int cat = category(diff);
+    bs.put(dc.code[cat], dc.len[cat]);
+    if (cat) bs.put((unsigned)(diff < 0 ? diff - 1 : diff), cat);
+    int run = 0;
+    for (int k = 1; k < 64; ++k) {
+        if (zz[k] == 0) {
+            ++run;
+            continue;
+        }
+        while (run > 15) {
+            bs.put(ac.code[0xf0], ac.len[0xf0]);
+            run -= 16;
+        }
+        cat = category(zz[k]);
+        const int sym = (run << 4) | cat;
+        bs.put(ac.code[sym], ac.len[sym]);
+        bs.put((unsigned)(zz[k] < 0 ? zz[k] - 1 : zz[k]), cat);
+        run = 0;
+    }
+    if (run > 0) bs.put(ac.code[0x00], ac.len[0x00]);
+}
+
+}  // namespace
+
+bool write_jpeg(std::vector<unsigned char>* out_bytes, const Image& img, int quality) {
+    if (img.empty() || img.channels() != 3 || img.depth() != NLE_8U || img.rows > kMaxDim || img.cols > kMaxDim) return false;
+    quality = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
+    const int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;
+    unsigned short ql[64], qc[64];
+    for (int i = 0; i < 64; ++i) {
+        int a = ((int)kQLum[i] * scale + 50) / 100, b = ((int)kQChr[i] * scale + 50) / 100;
+        ql[i] = (unsigned short)(a < 1 ? 1 : (a > 255 ? 255 : a));
+        qc[i] = (unsigned short)(b < 1 ? 1 : (b > 255 ? 255 : b));
+    }
+    const int H = img.rows, W = img.cols, mx = (W + 15) / 16, my = (H + 15) / 16, PW = mx * 16, PH = my * 16;
+    // YCbCr planes padded to whole MCUs by edge replication; chroma averaged 2 x 2 (bias 1, 2, 1, 2, ...)
+    std::vector<unsigned char> Y((size_t)PW * PH), Cb((size_t)PW * PH), Cr((size_t)PW * PH);
+    for (int r = 0; r < PH; ++r) {
+        const unsigned char* src = img.ptr<unsigned char>(r < H ? r : H - 1);
+        for (int c = 0; c < PW; ++c) {
+            const int cc = c < W ? c : W - 1;
+            const int B = src[3 * cc], G = src[3 * cc + 1], R = src[3 * cc + 2];
+            Y[(size_t)r * PW + c] = (unsigned char)((19595 * R + 38470 * G + 7471 * B + 32768) >> 16);
+            Cb[(size_t)r * PW + c] = (unsigned char)((-11059 * R - 21709 * G + 32768 * B + (128 << 16) + 32767) >> 16);
+            Cr[(size_t)r * PW + c] = (unsigned char)((32768 * R - 27439 * G - 5329 * B + (128 << 16) + 32767) >> 16);
+        }
+    }
+    const int CW = PW / 2, CH = PH / 2;
+    std::vector<unsigned char> cb2((size_t)CW * CH), cr2((size_t)CW * CH);
+    for (int r = 0; r < CH; ++r)
+        for (int c = 0; c < CW; ++c) {
+            const size_t i0 = (size_t)(2 * r) * PW + 2 * c, i1 = i0 + PW;
+            const int bias = 1 + (c & 1);
+            cb2[(size_t)r * CW + c] = (unsigned char)((Cb[i0] + Cb[i0 + 1] + Cb[i1] + Cb[i1 + 1] + bias) >> 2);
+            cr2[(size_t)r * CW + c] = (unsigned char)((Cr[i0] + Cr[i0 + 1] + Cr[i1] + Cr[i1 + 1] + bias) >> 2);
+        }
+    std::vector<unsigned char>& o = *out_bytes;
+    o.clear();
+    o.insert(o.end(), {0xff, 0xd8, 0xff, 0xe0, 0x00, 0x10, 'J', 'F', 'I', 'F', 0x00, 0x01, 0x01, 0x00, 0x00, 0x01, 0x00, 0x01, 0x00, 0x00});
+    for (int t = 0; t < 2; ++t) {  // DQT
+        o.insert(o.end(), {0xff, 0xdb, 0x00, 0x43, (unsigned char)t});
+        const unsigned short* q = t ? qc : ql;
+        for (int k = 0; k < 64; ++k) o.push_back((unsigned char)q[kZigzag[k]]);
+    }
+    o.insert(o.end(), {0xff, 0xc0, 0x00, 0x11, 0x08});
+    put16(o, (unsigned)H);
+    put16(o, (unsigned)W);
+    o.insert(o.end(), {0x03, 0x01, 0x22, 0x00, 0x02, 0x11, 0x01, 0x03, 0x11, 0x01});
+    auto dht = [&](int cls, int id, const unsigned char* bits, const unsigned char* vals, int nv) {
+        o.insert(o.end(), {0xff, 0xc4});
+        put16(o, (unsigned)(2 + 1 + 16 + nv));
+        o.push_back((unsigned char)((cls << 4) | id));
+        o.insert(o.end(), bits, bits + 16);
+        o.insert(o.end(), vals, vals + nv);
+    };
+    dht(0, 0, kDcLumBits, kDcVals, 12);
+    dht(1, 0, kAcLumBits, kAcLumVals, 162);
+    dht(0, 1, kDcChrBits, kDcVals, 12);
+    dht(1, 1, kAcChrBits, kAcChrVals, 162);
+    o.insert(o.end(), {0xff, 0xda, 0x00, 0x0c, 0x03, 0x01, 0x00, 0x02, 0x11, 0x03, 0x11, 0x00, 0x3f, 0x00});
+    EncTable dcl, acl, dcc, acc_;
+    dcl.build(kDcLumBits, kDcVals);
+    acl.build(kAcLumBits, kAcLumVals);
+    dcc.build(kDcChrBits, kDcVals);
+    acc_.build(kAcChrBits, kAcChrVals);
+    BitSink bs{o};
+    int py = 0, pcb = 0, pcr = 0;
+    double blk[64];
+    auto take = [&](const std::vector<unsigned char>& plane, int stride, int r0, int c0) {
+        for (int y = 0; y < 8; ++y)
+            for (int x = 0; x < 8; ++x) blk[y * 8 + x] = (double)plane[(size_t)(r0 + y) * stride + c0 + x] - 128.0;
+    };
+    for (int m = 0; m < my; ++m)
+        for (int n = 0; n < mx; ++n) {
+            for (int v = 0; v < 2; ++v)
+                for (int h = 0; h < 2; ++h) {
+                    take(Y, PW, m * 16 + v * 8, n * 16 + h * 8);
+                    encode_block(bs, blk, ql, &py, dcl, acl);
+                }
+            take(cb2, CW, m * 8, n * 8);
+            encode_block(bs, blk, qc, &pcb, dcc, acc_);
+            take(cr2, CW, m * 8, n * 8);
+            encode_block(bs, blk, qc, &pcr, dcc, acc_);
+        }
+    bs.flush();
+    o.insert(o.end(), {0xff, 0xd9});
+    return true;
 }
 
 }  // namespace nle

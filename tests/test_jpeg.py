@@ -133,3 +133,26 @@ def test_damaged_files_never_crash(tool, tmp_path):
         files.append(f)
     got = _decode(tool, files, tmp_path)       # asserts a clean exit of the sanitizer build
     assert all(got[f] is None for f in files[-5:])
+
+
+def test_writer_output_is_a_jpeg_every_decoder_reads(tool, tmp_path):
+    """imwrite("x.jpg") (baseline 4:2:0, quality 95 like cv::imwrite's default): Pillow decodes it, at the fidelity of
+    Pillow's own encoder at that quality, and the reader here decodes it to exactly what Pillow does"""
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    for k, (h, w) in enumerate([(1, 1), (7, 5), (16, 16), (33, 47), (240, 320)]):
+        y, x = np.mgrid[0:h, 0:w]
+        base = np.stack([128 + 100 * np.sin(x / 17.0 + y / 23.0), 128 + 90 * np.cos(x / 15.0 - y / 13.0), 40 + x * 0.7 + y * 0.5], -1)
+        img = np.clip(base + rng.normal(0, 4, (h, w, 3)), 0, 255).astype(np.uint8)
+        src, out, back = tmp_path / f"s{k}.png", tmp_path / f"o{k}.jpg", tmp_path / f"b{k}.ppm"
+        Image.fromarray(img).save(src)
+        r = subprocess.run([tool, str(src), str(out), str(out), str(back)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "EMPTY" not in r.stdout, r.stderr[-400:]
+        ours = np.asarray(Image.open(out).convert("RGB")).astype(float)
+        ref = tmp_path / f"p{k}.jpg"
+        Image.fromarray(img).save(ref, "JPEG", quality=95, subsampling="4:2:0")
+        theirs = np.asarray(Image.open(ref).convert("RGB")).astype(float)
+        mse_o, mse_t = ((ours - img) ** 2).mean(), ((theirs - img) ** 2).mean()
+        assert mse_o <= 1.1 * mse_t + 0.5, (h, w, mse_o, mse_t)
+        assert os.path.getsize(out) <= 1.15 * os.path.getsize(ref) + 64
+        assert np.array_equal(_rgb(str(back)), ours.astype(np.uint8))
