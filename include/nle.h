@@ -289,9 +289,15 @@ int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, 
 /* ---- colour wrapper on the device (the code either side of the path) ------------------------------- */
 /* cv::cvtColor(COLOR_BGR2Lab) on an 8-bit image as the reference uses it (src/filter.cpp:423,463) and
  * the split / convertTo(CV_64F) of the L channel (:424-426,465-467): d_bgr n x 3 bytes -> d_lab n x 3
- * bytes (may be NULL) and d_L n floats = L in 0..255 (may be NULL).  OpenCV's own 8-bit path is a
- * version-dependent fixed-point table; this is the documented float formula (about one grey level). */
+ * bytes (may be NULL) and d_L n floats = L in 0..255 (may be NULL).  OpenCV's 8-bit path is not the float formula of its
+ * documentation but a fixed-point table algorithm (imgproc `RGB2Lab_b`); that algorithm is what runs here -- with it the
+ * reference's README outputs are reproduced to 0.003 .. 0.5 grey levels (tests/test_oracle_readme_pairs.py). */
 int nle_bgr2lab8(nle_ctx* ctx, const unsigned char* d_bgr, long long n, unsigned char* d_lab, float* d_L);
+/* the tables of that conversion (host only): h_gamma[256] = sRGB decode scaled by 255 * 8, h_cbrt[3072] = f(t) of L*a*b*
+ * scaled by 2^15 (t = i / 2040), h_coeffs[9] = the XYZ matrix over the D65 white point in 12-bit fixed point, row major
+ * (R, G, B columns).  L = (296 fY - 1336934 + 2^14) >> 15, a = (500 (fX - fY) + 128 * 2^15 + 2^14) >> 15, b alike with
+ * 200 (fY - fZ); f* = h_cbrt[(R c0 + G c1 + B c2 + 2^11) >> 12]. */
+int nle_lab8_tables(unsigned short* h_gamma, unsigned short* h_cbrt, int* h_coeffs);
 /* max(0) / min(255) / convertTo(CV_8U) / merge / cvtColor(COLOR_Lab2BGR) (src/filter.cpp:434-440): the L
  * channel is taken from d_L (clamped, rounded half to even) when given, else from d_lab. */
 int nle_lab2bgr8(nle_ctx* ctx, const unsigned char* d_lab, const float* d_L, long long n, unsigned char* d_bgr);

@@ -93,6 +93,15 @@ def rccl_unique_id() -> bytes:
     return bytes(buf)
 
 
+def lab8_tables():
+    """tables of the fixed-point 8-bit BGR -> Lab conversion (nle_lab8_tables): gamma[256], cbrt[3072], coeffs[3][3]"""
+    g = np.zeros(256, dtype=np.uint16)
+    c = np.zeros(3072, dtype=np.uint16)
+    k = np.zeros(9, dtype=np.int32)
+    _check(lib().nle_lab8_tables(_np_ptr(g), _np_ptr(c), _np_ptr(k)))
+    return g, c, k.reshape(3, 3)
+
+
 def sample_grid(H, W, n_row_samples, n_col_samples):
     """`samplePixels` (src/filter.cpp:56-80) in closed form.
     Returns dict(row_step,row_off,n_sel_rows,col_step,col_off,n_sel_cols)."""

@@ -130,19 +130,40 @@ int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
 }
 
 namespace {
-const double* colour_lut(nle_ctx* c) {  // sRGB decode of i/255, uploaded once per ctx
+// gamma[256] | cbrt[3072] (u16) | coeffs[9] (int) of the fixed-point BGR -> Lab conversion, uploaded once per ctx
+constexpr int kLabCbrtN = 256 * 3 / 2 * 8;
+void lab8_tables_host(unsigned short* gamma, unsigned short* cbrt_tab, int* coeffs) {
+    for (int i = 0; i < 256; ++i) {
+        const double x = i / 255.0;
+        gamma[i] = (unsigned short)std::nearbyint(255.0 * 8.0 * (x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4)));
+    }
+    for (int i = 0; i < kLabCbrtN; ++i) {
+        const double t = i / (255.0 * 8.0);
+        cbrt_tab[i] = (unsigned short)std::nearbyint(32768.0 * (t < 0.008856 ? t * 7.787 + 0.13793103448275862 : std::cbrt(t)));
+    }
+    const double M[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
+    const double wp[3] = {0.950456, 1.0, 1.088754};
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) coeffs[3 * r + cc] = (int)std::nearbyint(4096.0 * M[r][cc] / wp[r]);
+}
+const double* colour_lut(nle_ctx* c) {
     if (!c->d_lut) {
-        double lut[256];
-        for (int i = 0; i < 256; ++i) {
-            const double v = i / 255.0;
-            lut[i] = v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4);
-        }
-        HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->d_lut), sizeof lut));
-        HIP_OK(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+        // one allocation: 256 + 3072 u16, then 9 ints (4-byte aligned: 3328 u16 = 6656 bytes)
+        std::vector<unsigned char> blob((256 + kLabCbrtN) * sizeof(unsigned short) + 9 * sizeof(int));
+        lab8_tables_host(reinterpret_cast<unsigned short*>(blob.data()), reinterpret_cast<unsigned short*>(blob.data()) + 256,
+                         reinterpret_cast<int*>(blob.data() + (256 + kLabCbrtN) * sizeof(unsigned short)));
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->d_lut), blob.size()));
+        HIP_OK(hipMemcpy(c->d_lut, blob.data(), blob.size(), hipMemcpyHostToDevice));
     }
     return c->d_lut;
 }
 }  // namespace
+
+int nle_lab8_tables(unsigned short* h_gamma, unsigned short* h_cbrt, int* h_coeffs) {
+    if (!h_gamma || !h_cbrt || !h_coeffs) return NLE_ERR_INVALID;
+    lab8_tables_host(h_gamma, h_cbrt, h_coeffs);
+    return NLE_OK;
+}
 
 int nle_bgr2lab8(nle_ctx* ctx, const unsigned char* d_bgr, long long n, unsigned char* d_lab, float* d_L) {
     if (!ctx || !d_bgr || n < 0 || (!d_lab && !d_L)) return NLE_ERR_INVALID;

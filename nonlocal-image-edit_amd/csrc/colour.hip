@@ -1,8 +1,8 @@
 // 8-bit BGR <-> Lab on the device: the colour wrapper either side of the hot path
 // (reference src/filter.cpp:460-469 getLuminanceChannel, :422-426 and :434-440 in NLEFilter::enhance,
-// where it is cv::cvtColor on 8-bit images).  Same formulas as the host restatement in
-// host/filter.cpp (sRGB decode, XYZ D65, L*a*b*, L*255/100, a+128, b+128), evaluated in fp64 so
-// that the two agree except for isolated round-to-nearest ties.
+// where it is cv::cvtColor on 8-bit images).  BGR -> Lab is OpenCV's fixed-point table algorithm (exact integers, the
+// same as the host restatement in host/filter.cpp); Lab -> BGR the documented float formula in fp64 (agrees with the host
+// restatement except for isolated round-to-nearest ties; OpenCV's own 8-bit inverse is not pinned).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -12,7 +12,6 @@
 namespace nlek {
 
 namespace {
-__device__ __forceinline__ double lab_f(double t) { return t > 0.008856 ? cbrt(t) : 7.787 * t + 16.0 / 116.0; }
 __device__ __forceinline__ unsigned char sat8(double v) {
     return (unsigned char)fmin(255.0, fmax(0.0, rint(v)));  // round half to even, saturate (cv convertTo CV_8U)
 }
@@ -21,24 +20,31 @@ __device__ __forceinline__ double lin2srgb(double v) {
 }
 }  // namespace
 
-// lut[i] = sRGB-decoded i/255 (256 doubles, built by the host); d_L (optional) = L channel as fp32
+// OpenCV's fixed-point 8-bit path (imgproc RGB2Lab_b, restated in include/nle.h at nle_lab8_tables): tables in LDS, integer
+// arithmetic throughout -- bit-identical to the host restatement and to the oracle.  lut = gamma[256] | cbrt[3072] (u16)
+// | coeffs[9] (int) as abi_ctx.hip uploads them; d_L (optional) = L channel as fp32
 __global__ __launch_bounds__(256) void k_bgr2lab8(const unsigned char* __restrict__ bgr, long long n,
                                                   const double* __restrict__ lut, unsigned char* __restrict__ lab,
                                                   float* __restrict__ Lf) {
-    __shared__ double sl[256];
-    sl[threadIdx.x] = lut[threadIdx.x];
+    constexpr int NCB = 256 * 3 / 2 * 8;
+    __shared__ unsigned short sg[256], sc[NCB];
+    __shared__ int sk[9];
+    const unsigned short* t16 = reinterpret_cast<const unsigned short*>(lut);
+    for (int i = threadIdx.x; i < 256; i += 256) sg[i] = t16[i];
+    for (int i = threadIdx.x; i < NCB; i += 256) sc[i] = t16[256 + i];
+    if (threadIdx.x < 9) sk[threadIdx.x] = reinterpret_cast<const int*>(t16 + 256 + NCB)[threadIdx.x];
     __syncthreads();
+    auto sat = [](int v) { return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const double b = sl[bgr[3 * i + 0]], g = sl[bgr[3 * i + 1]], r = sl[bgr[3 * i + 2]];
-        const double x = (0.412453 * r + 0.357580 * g + 0.180423 * b) / 0.950456;
-        const double y = 0.212671 * r + 0.715160 * g + 0.072169 * b;
-        const double z = (0.019334 * r + 0.119193 * g + 0.950227 * b) / 1.088754;
-        const double L = y > 0.008856 ? 116.0 * cbrt(y) - 16.0 : 903.3 * y;
-        const unsigned char L8 = sat8(L * 255.0 / 100.0);
+        const int B = sg[bgr[3 * i + 0]], G = sg[bgr[3 * i + 1]], R = sg[bgr[3 * i + 2]];
+        const int fX = sc[(R * sk[0] + G * sk[1] + B * sk[2] + 2048) >> 12];
+        const int fY = sc[(R * sk[3] + G * sk[4] + B * sk[5] + 2048) >> 12];
+        const int fZ = sc[(R * sk[6] + G * sk[7] + B * sk[8] + 2048) >> 12];
+        const unsigned char L8 = sat((296 * fY - 1336934 + 16384) >> 15);
         if (lab != nullptr) {
             lab[3 * i + 0] = L8;
-            lab[3 * i + 1] = sat8(500.0 * (lab_f(x) - lab_f(y)) + 128.0);
-            lab[3 * i + 2] = sat8(200.0 * (lab_f(y) - lab_f(z)) + 128.0);
+            lab[3 * i + 1] = sat((500 * (fX - fY) + 128 * 32768 + 16384) >> 15);
+            lab[3 * i + 2] = sat((200 * (fY - fZ) + 128 * 32768 + 16384) >> 15);
         }
         if (Lf != nullptr) Lf[i] = (float)L8;
     }

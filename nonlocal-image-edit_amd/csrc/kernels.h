@@ -271,7 +271,7 @@ hipError_t project_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, i
                         const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_D, int ldd, int K,
                         const double* d_c, float* d_V, int ldv);
 
-// 8-bit BGR <-> Lab (colour.hip): d_lut = 256 sRGB-decoded doubles; d_lab / d_L optional outputs
+// 8-bit BGR <-> Lab (colour.hip): d_lut = the fixed-point tables of nle_lab8_tables as one blob; d_lab / d_L optional outputs
 hipError_t bgr2lab8(hipStream_t s, const unsigned char* d_bgr, long long n, const double* d_lut, unsigned char* d_lab,
                     float* d_L);
 hipError_t lab2bgr8(hipStream_t s, const unsigned char* d_lab, const float* d_L, const float* d_a, const float* d_b,

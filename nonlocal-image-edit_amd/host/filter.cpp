@@ -448,34 +448,33 @@ Vec transformEigenValues(const Vec& eigvals, const std::vector<DType>& weights) 
 
 // ------------------------------------------------------------------ colour wrapper (host)
 namespace {
-// cv::cvtColor COLOR_BGR2Lab for 8-bit images as documented: sRGB decode, XYZ (D65), L*a*b*, then
-// L*255/100, a+128, b+128.  OpenCV's own 8-bit path is fixed-point and version dependent: this
-// float restatement agrees with it to about one grey level ("unpinned").
+// cv::cvtColor on 8-bit images.  BGR -> Lab: OpenCV's fixed-point table algorithm (below).  Lab -> BGR: the documented
+// float formula (sRGB encode of the XYZ D65 inverse); OpenCV's own 8-bit inverse differs between versions and is unpinned.
 const double kXn = 0.950456, kZn = 1.088754;
 const double kM[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
 const double kMi[3][3] = {{3.240479, -1.53715, -0.498535}, {-0.969256, 1.875991, 0.041556}, {0.055648, -0.204043, 1.057311}};
-inline double srgb2lin(double v) { return v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4); }
 inline double lin2srgb(double v) { return v <= 0.0031308 ? 12.92 * v : 1.055 * std::pow(std::max(v, 0.0), 1 / 2.4) - 0.055; }
-inline double labf(double t) { return t > 0.008856 ? std::cbrt(t) : 7.787 * t + 16.0 / 116.0; }
 inline unsigned char sat8(double v) { return (unsigned char)std::min(255.0, std::max(0.0, std::nearbyint(v))); }
 }  // namespace
 
 Image bgr2lab8(const Image& bgr) {
     if (bgr.channels() != 3 || bgr.depth() != NLE_8U) throw std::runtime_error("bgr2lab8: 8UC3 image expected");
-    double lut[256];
-    for (int i = 0; i < 256; ++i) lut[i] = srgb2lin(i / 255.0);
+    // OpenCV's fixed-point 8-bit path (imgproc RGB2Lab_b; include/nle.h at nle_lab8_tables): exact integers
+    unsigned short gam[256], cb[3072];
+    int k[9];
+    if (nle_lab8_tables(gam, cb, k) != NLE_OK) throw std::runtime_error("bgr2lab8: tables");
+    auto sat = [](int v) { return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
     Image lab(bgr.rows, bgr.cols, NLE_8U, 3);
     const unsigned char* s = bgr.ptr<unsigned char>();
     unsigned char* d = lab.ptr<unsigned char>();
     for (size_t i = 0; i < bgr.total(); ++i, s += 3, d += 3) {
-        const double b = lut[s[0]], g = lut[s[1]], r = lut[s[2]];
-        const double x = (kM[0][0] * r + kM[0][1] * g + kM[0][2] * b) / kXn;
-        const double y = kM[1][0] * r + kM[1][1] * g + kM[1][2] * b;
-        const double z = (kM[2][0] * r + kM[2][1] * g + kM[2][2] * b) / kZn;
-        const double L = y > 0.008856 ? 116.0 * std::cbrt(y) - 16.0 : 903.3 * y;
-        d[0] = sat8(L * 255.0 / 100.0);
-        d[1] = sat8(500.0 * (labf(x) - labf(y)) + 128.0);
-        d[2] = sat8(200.0 * (labf(y) - labf(z)) + 128.0);
+        const int B = gam[s[0]], G = gam[s[1]], R = gam[s[2]];
+        const int fX = cb[(R * k[0] + G * k[1] + B * k[2] + 2048) >> 12];
+        const int fY = cb[(R * k[3] + G * k[4] + B * k[5] + 2048) >> 12];
+        const int fZ = cb[(R * k[6] + G * k[7] + B * k[8] + 2048) >> 12];
+        d[0] = sat((296 * fY - 1336934 + 16384) >> 15);
+        d[1] = sat((500 * (fX - fY) + 128 * 32768 + 16384) >> 15);
+        d[2] = sat((200 * (fY - fZ) + 128 * 32768 + 16384) >> 15);
     }
     return lab;
 }

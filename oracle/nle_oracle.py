@@ -427,12 +427,48 @@ _M = np.array([[0.412453, 0.357580, 0.180423],
                [0.019334, 0.119193, 0.950227]])
 
 
+# cv::cvtColor(COLOR_BGR2Lab) on 8-bit images is not the float formula of its documentation but a fixed-point table
+# implementation (OpenCV imgproc, color_lab.cpp, `RGB2Lab_b`; third-party dependency of the reference, absent here).  Its
+# published algorithm, restated: sRGB decode through a 256-entry table scaled by 255 * 2^3, the XYZ matrix in 12-bit fixed
+# point with the white point folded in, f(t) through a table of 256 * 3 / 2 * 2^3 entries scaled by 2^15, then
+#   L = (296 fY - 1336934 + 2^14) >> 15,   a = (500 (fX - fY) + 128 * 2^15 + 2^14) >> 15,   b = (200 (fY - fZ) + ...) >> 15.
+# Pinned by the reference's own README pairs (tests/test_oracle_readme_pairs.py): with THIS conversion the oracle reproduces
+# the author's output images to 0.003 (paper) .. 0.5 grey levels, `bird` to 0.010 -- with the float formula of the
+# documentation (`bgr_to_lab8_float`, 14-16 % of the L pixels one level off) bird was 3.35 off, the others 0.2-0.8.
+_LAB_SHIFT, _GAMMA_SHIFT = 12, 3
+_LAB_SHIFT2 = _LAB_SHIFT + _GAMMA_SHIFT
+
+
+def lab8_tables():
+    """(gamma[256], cbrt[3072], coeffs[3][3]) of the fixed-point BGR -> Lab conversion"""
+    x = np.arange(256, dtype=np.float64) / 255.0
+    gamma = np.rint(255.0 * (1 << _GAMMA_SHIFT) * np.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)).astype(np.int64)
+    n = 256 * 3 // 2 * (1 << _GAMMA_SHIFT)
+    t = np.arange(n, dtype=np.float64) / (255.0 * (1 << _GAMMA_SHIFT))
+    cbrt = np.rint((1 << _LAB_SHIFT2) * np.where(t < 0.008856, t * 7.787 + 0.13793103448275862, np.cbrt(t))).astype(np.int64)
+    coeffs = np.rint((1 << _LAB_SHIFT) * _M / np.array([_XN, 1.0, _ZN])[:, None]).astype(np.int64)
+    return gamma, cbrt, coeffs
+
+
 def bgr_to_lab8(bgr: np.ndarray) -> np.ndarray:
-    """8-bit BGR -> 8-bit Lab as `cv::cvtColor(COLOR_BGR2Lab)` documents it
-    (src/filter.cpp:423,463): sRGB decode, XYZ (D65), L*a*b*, then L*255/100, a+128,
-    b+128, rounded.  OpenCV's own 8-bit path is a fixed-point table implementation whose
-    rounding is version dependent ("parity unpinned"): this float
-    restatement agrees to about one grey level."""
+    """8-bit BGR -> 8-bit Lab as `cv::cvtColor(COLOR_BGR2Lab)` computes it on CV_8UC3 (src/filter.cpp:423,463)."""
+    gamma, cbrt, C = lab8_tables()
+    descale = lambda v, n: (v + (1 << (n - 1))) >> n
+    B, G, R = (gamma[bgr[..., k].astype(np.int64)] for k in range(3))
+    fX = cbrt[descale(R * C[0, 0] + G * C[0, 1] + B * C[0, 2], _LAB_SHIFT)]
+    fY = cbrt[descale(R * C[1, 0] + G * C[1, 1] + B * C[1, 2], _LAB_SHIFT)]
+    fZ = cbrt[descale(R * C[2, 0] + G * C[2, 1] + B * C[2, 2], _LAB_SHIFT)]
+    Lscale = (116 * 255 + 50) // 100
+    Lshift = -((16 * 255 * (1 << _LAB_SHIFT2) + 50) // 100)
+    L = descale(Lscale * fY + Lshift, _LAB_SHIFT2)
+    a = descale(500 * (fX - fY) + 128 * (1 << _LAB_SHIFT2), _LAB_SHIFT2)
+    b = descale(200 * (fY - fZ) + 128 * (1 << _LAB_SHIFT2), _LAB_SHIFT2)
+    return np.clip(np.stack([L, a, b], axis=-1), 0, 255).astype(np.uint8)
+
+
+def bgr_to_lab8_float(bgr: np.ndarray) -> np.ndarray:
+    """The float formula OpenCV DOCUMENTS for 8-bit images (sRGB decode, XYZ D65, L*a*b*, L*255/100, a+128, b+128, rounded):
+    what rounds 1-3 used; kept to show the difference (about one grey level on one pixel in seven)."""
     rgb = bgr[..., ::-1].astype(np.float64) / 255.0
     lin = _srgb_to_linear(rgb)
     xyz = lin @ _M.T
@@ -446,7 +482,8 @@ def bgr_to_lab8(bgr: np.ndarray) -> np.ndarray:
 
 
 def lab8_to_bgr(lab: np.ndarray) -> np.ndarray:
-    """Inverse of `bgr_to_lab8` (`COLOR_Lab2BGR`, src/filter.cpp:440)."""
+    """`COLOR_Lab2BGR` on 8-bit images (src/filter.cpp:440) by the documented float formula; OpenCV's own 8-bit inverse
+    (a float / table path that differs between versions) is NOT pinned: it only touches the file written at the end."""
     L = lab[..., 0].astype(np.float64) * 100.0 / 255.0
     a = lab[..., 1].astype(np.float64) - 128.0
     b = lab[..., 2].astype(np.float64) - 128.0

@@ -143,6 +143,15 @@ def test_rccl_bootstrap_argument_checks_need_no_gpu(nle):
     assert L.nle_ctx_set_rccl_comm(None, 0, 1, None) == nle.NLE_ERR_INVALID
 
 
+def test_lab8_tables_are_the_oracles(nle, oracle):
+    """the fixed-point tables behind nle_bgr2lab8 and the C++ surface's bgr2lab8 (OpenCV's 8-bit BGR -> Lab) are, entry for
+    entry, the ones the oracle builds: the integer arithmetic on top of them then cannot differ"""
+    g, c, k = nle.lab8_tables()
+    go, co, ko = oracle.lab8_tables()
+    assert np.array_equal(g, go) and np.array_equal(c, co) and np.array_equal(k, ko)
+    assert g[0] == 0 and g[255] == 2040 and c.size == 3072 and int(k[1].sum()) == 4096
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "nonlocal-image-edit_amd")
     for dirpath, _, files in os.walk(pkg):

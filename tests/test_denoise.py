@@ -165,3 +165,16 @@ def test_level_check_on_planes_that_are_not_16_byte_aligned(nle, ctx):
             with pytest.raises(nle.NLEError):
                 ctx.bilateral8(view, 12.0, 2.0)
             view[pos] = keep
+
+
+@pytest.mark.gpu
+def test_device_bgr2lab8_equals_the_oracle_on_every_colour(nle, oracle, ctx):
+    """nle_bgr2lab8 is OpenCV's fixed-point 8-bit BGR -> Lab (integer arithmetic on the tables of nle_lab8_tables): all
+    2^24 colours come out exactly as the oracle's restatement of that algorithm has them"""
+    v = np.arange(256, dtype=np.uint8)
+    for b in range(0, 256, 16):   # 16 blue values per slab: 16 x 256 x 256 colours
+        cube = np.stack(np.meshgrid(v[b:b + 16], v, v, indexing="ij"), axis=-1).reshape(16 * 256, 256, 3)
+        lab, L = ctx.bgr2lab8(cube)
+        want = oracle.bgr_to_lab8(cube)
+        assert np.array_equal(lab.cpu().numpy(), want), b
+        assert np.array_equal(L.cpu().numpy(), want[..., 0].astype(np.float32))

@@ -101,7 +101,9 @@ def test_flower_golden_is_consistent_with_readme_pair(oracle, flower):
     from PIL import Image
     want = np.asarray(Image.open(os.path.join(GOLDEN, "flower-filtered.png")).convert("RGB"))[..., ::-1]
     L_want = oracle.bgr_to_lab8(want)[..., 0].astype(np.float64)
-    assert np.abs(flower["L_out"].astype(np.float64) - L_want).mean() < 1.0
+    # the filtered L plane itself against the L of the author's FILE (which has been through Lab -> BGR, gamut clipping, and
+    # back): 0.45; the like-for-like comparison (both through the round trip) is tests/test_oracle_flower.py: 0.044
+    assert np.abs(flower["L_out"].astype(np.float64) - L_want).mean() < 0.6
     assert flower["lam"].size == 200 and flower["S"].size == 30
     assert 0.999 < flower["S"][0] <= 1.0 + 1e-9
 

@@ -39,8 +39,8 @@ def test_flower_matches_readme_output(oracle, flower):
     print(f"filter moves L by {moved:.2f} levels on average; oracle vs README output: mean |dL| = {err.mean():.3f}, "
           f"p99 = {np.percentile(err, 99):.1f}, corr = {corr:.5f}")
     assert moved > 10.0                 # the edit is large ...
-    assert err.mean() < 1.0             # ... and the oracle reproduces it to < 1 grey level on average
-    assert np.percentile(err, 99) <= 8.0
+    assert err.mean() < 0.1             # ... and the oracle reproduces it: 0.044 grey levels on average (the author's file
+    assert np.percentile(err, 99) <= 1.0  # has been through Lab -> BGR and back), one level at most at the 99th percentile
     assert corr > 0.999
     # colour planes: a, b are passed through unchanged by `enhance` (src/filter.cpp:431-440)
     d_bgr = np.abs(got.astype(int) - want.astype(int))
