@@ -42,8 +42,10 @@ def run_pair(oracle, pair):
     out = oracle.lab8_to_bgr(lab2)
     L_want = oracle.bgr_to_lab8(want)[..., 0].astype(np.float64)
     err = np.abs(oracle.bgr_to_lab8(out)[..., 0].astype(np.float64) - L_want)
+    d_bgr = np.abs(out.astype(int) - want.astype(int))   # against the author's FILE, byte for byte
     return dict(name=name, src=src, want=want, L=L, S=S, layers=layers, L_out=L_out, out=out, info=info,
-                mean=float(err.mean()), p99=float(np.percentile(err, 99)), moved=float(np.abs(L_want - L).mean()))
+                mean=float(err.mean()), p99=float(np.percentile(err, 99)), moved=float(np.abs(L_want - L).mean()),
+                bgr_exact=float((d_bgr == 0).mean()), bgr_max=int(d_bgr.max()))
 
 
 # pairs whose oracle run is too long to repeat inside the GPU tests (rock2: 512k pixels, 600 samples, 2.5 min and ~12 GB on
@@ -61,14 +63,15 @@ def save_stored(r):
     np.savez_compressed(stored_path(r["name"]), L=r["L"].astype(np.uint8), L_out=r["L_out"], S=r["S"],
                         info=json.dumps(r["info"]), layer_norms=np.array([np.linalg.norm(l) for l in r["layers"]]),
                         layer_probes=r["layers"][:, ::PROBE_STEP].copy(), probe_step=PROBE_STEP,
-                        mean=r["mean"], p99=r["p99"], moved=r["moved"])
+                        mean=r["mean"], p99=r["p99"], moved=r["moved"], bgr_exact=r["bgr_exact"], bgr_max=r["bgr_max"])
 
 
 def load_stored(name):
     z = np.load(stored_path(name))
     return dict(name=name, L=z["L"].astype(np.float64), L_out=z["L_out"], S=z["S"], info=json.loads(str(z["info"])),
                 layer_norms=[float(v) for v in z["layer_norms"]], layer_probes=z["layer_probes"],
-                probe_step=int(z["probe_step"]), mean=float(z["mean"]), p99=float(z["p99"]), moved=float(z["moved"]))
+                probe_step=int(z["probe_step"]), mean=float(z["mean"]), p99=float(z["p99"]), moved=float(z["moved"]),
+                bgr_exact=float(z["bgr_exact"]), bgr_max=int(z["bgr_max"]))
 
 
 def main():
@@ -87,7 +90,8 @@ def main():
         rec[r["name"]] = dict(shape=list(r["L"].shape), args=rp.cli_args(pair), cuts=r["info"],
                               K_out=int(r["S"].size), eigvals=[float(x) for x in r["S"]],
                               layer_norms=[float(np.linalg.norm(l)) for l in r["layers"]],
-                              vs_readme_output=dict(moved=r["moved"], mean=r["mean"], p99=r["p99"]))
+                              vs_readme_output=dict(moved=r["moved"], mean=r["mean"], p99=r["p99"], bgr_exact=r["bgr_exact"],
+                                                    bgr_max=r["bgr_max"]))
         print(r["name"], rec[r["name"]]["cuts"], rec[r["name"]]["vs_readme_output"], flush=True)
     with open(os.path.join(HERE, "readme_oracle.json"), "w") as fh:
         json.dump(rec, fh, indent=1)

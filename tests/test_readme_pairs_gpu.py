@@ -106,6 +106,11 @@ def test_enhance_cli_reproduces_readme_pair(oracle, tmp_path, name):
     assert [info["r_Ka"], info["r_Wa"]] == [c["kept"] for c in o["info"]][:2]
     assert abs(info["r_Q"] - o["info"][2]["kept"]) <= q_count_slack(o)
     assert info["K"] == o["S"].size
+    # byte for byte against the author's file: as close as the oracle's own output file is
+    d_file = np.abs(got.astype(int) - want.astype(int))
+    print(f"{name}: {100 * (d_file == 0).mean():.1f} % of the CLI's B, G, R values equal the author's file (oracle "
+          f"{100 * o['bgr_exact']:.1f} %), max difference {int(d_file.max())}")
+    assert (d_file == 0).mean() > 0.9 and abs((d_file == 0).mean() - o["bgr_exact"]) < 0.01 and d_file.max() <= 4
     # the colour planes pass through unchanged (src/filter.cpp:431-440)
     d_ab = np.abs(oracle.bgr_to_lab8(got)[..., 1:].astype(int) - oracle.bgr_to_lab8(want)[..., 1:].astype(int))
     assert d_ab.mean() < 0.5
