@@ -183,7 +183,10 @@ def test_train_apply_layers_match_oracle(nle, oracle, ctx, mode, case):
         assert rel_l2(Y[j], Y_o[j]) < tol, f"layer {j}"
     # V itself, up to per-column sign
     V = f.eigvecs().cpu().numpy()[:, :S_o.size].astype(np.float64)
-    assert rel_l2(_align_signs(V, V_o), V_o) < 1e-3
+    ev = rel_l2(_align_signs(V, V_o), V_o)
+    print(f"V vs oracle, mode {mode}, case {case[:4]}: {ev:.2e}")
+    # fp64 formulations: the fp32 storage of V is what is left (measured 2.5e-8 .. 5.2e-7); the opt-in fp32 ones 3e-7 .. 2.3e-4
+    assert ev < (2e-6 if mode in FP64_MODES else 1e-3)
     # weighted sum == NLEFilter::apply with transformEigenValues
     w = [2.0, 3.0, 4.0, 1.0, 0.5][:L]
     y = f.apply(x.astype(np.float32), nle.transform_eigenvalues(f.eigvals, w)).cpu().numpy()
