@@ -285,6 +285,11 @@ int nle_apply_layers(nle_filter* f, const float* d_x, int H, int W, int L, float
 int nle_apply_host(nle_filter* f, const float* h_x, int H, int W, const double* h_fS,
                    float* h_y);
 int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, float* h_y);
+/* The L plane NLEFilter::enhance merges back (src/filter.cpp:428-436): y = apply(x, fS), cv::max(y, 0), cv::min(y, 255),
+ * convertTo(CV_8U) (round half to even, saturate) -- n_local BYTES instead of L fp32 planes: what `enhance` needs back from
+ * the device (16 MB instead of 268 MB at 4096^2, four weights).  Device and host-buffer forms; h_x == NULL as above. */
+int nle_apply_u8(nle_filter* f, const float* d_x, int H, int W, const double* h_fS, unsigned char* d_out);
+int nle_apply_u8_host(nle_filter* f, const float* h_x, int H, int W, const double* h_fS, unsigned char* h_out);
 
 /* ---- colour wrapper on the device (the code either side of the path) ------------------------------- */
 /* cv::cvtColor(COLOR_BGR2Lab) on an 8-bit image as the reference uses it (src/filter.cpp:423,463) and
@@ -294,12 +299,20 @@ int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, 
  * reference's README outputs are reproduced to 0.003 .. 0.5 grey levels (tests/test_oracle_readme_pairs.py). */
 int nle_bgr2lab8(nle_ctx* ctx, const unsigned char* d_bgr, long long n, unsigned char* d_lab, float* d_L);
 /* the tables of that conversion (host only): h_gamma[256] = sRGB decode scaled by 255 * 8, h_cbrt[3072] = f(t) of L*a*b*
- * scaled by 2^15 (t = i / 2040), h_coeffs[9] = the XYZ matrix over the D65 white point in 12-bit fixed point, row major
- * (R, G, B columns).  L = (296 fY - 1336934 + 2^14) >> 15, a = (500 (fX - fY) + 128 * 2^15 + 2^14) >> 15, b alike with
+ * scaled by 2^15 (t = i / 2040; made in single precision with OpenCV's truncating rational cube root, csrc/lab8_tables.cpp),
+ * h_coeffs[9] = the XYZ matrix over the D65 white point in 12-bit fixed point, row major (R, G, B columns).  L = (296 fY - 1336934 + 2^14) >> 15, a = (500 (fX - fY) + 128 * 2^15 + 2^14) >> 15, b alike with
  * 200 (fY - fZ); f* = h_cbrt[(R c0 + G c1 + B c2 + 2^11) >> 12]. */
 int nle_lab8_tables(unsigned short* h_gamma, unsigned short* h_cbrt, int* h_coeffs);
+/* the tables of the inverse conversion (host only), everything in units of 2^-14: h_yf[256][2] = (y, fy) for an 8-bit L,
+ * h_ab_to_xz[36864] = the inverse of f(t) for t = index - 8145 (t <= 3390 ? t 108 / 841 - 290 : t t / 2^14 t / 2^14, C
+ * integer division), h_inv_gamma[4096] = round(255 sRGB_encode(i / 4096)), h_coeffs[9] = round(2^12 XYZ -> sRGB times the
+ * D65 white point), rows R, G, B.  fx = fy + ((5 a 53687 + 2^7) >> 13) - 4194, fz = fy - (((b 41943 + 2^4) >> 9) - 10484);
+ * channel = h_inv_gamma[clamp((c0 x + c1 y + c2 z + 2^13) >> 14, 0, 4095)]. */
+int nle_lab8_inverse_tables(unsigned short* h_yf, int* h_ab_to_xz, unsigned short* h_inv_gamma, int* h_coeffs);
 /* max(0) / min(255) / convertTo(CV_8U) / merge / cvtColor(COLOR_Lab2BGR) (src/filter.cpp:434-440): the L
- * channel is taken from d_L (clamped, rounded half to even) when given, else from d_lab. */
+ * channel is taken from d_L (clamped, rounded half to even) when given, else from d_lab.  The conversion is OpenCV's
+ * integer 8-bit path (imgproc `Lab2RGBinteger`, tables below): with it `enhance` writes the author's README output files
+ * byte for byte wherever the filtered L plane has no rounding tie (tests/test_readme_pairs_gpu.py). */
 int nle_lab2bgr8(nle_ctx* ctx, const unsigned char* d_lab, const float* d_L, long long n, unsigned char* d_bgr);
 /* the same with any of the three channels replaced by an fp32 plane (NULL = keep d_lab's), each clamped and
  * rounded like :391-399 -- the tail of NLEFilter::denoise (src/filter.cpp:391-409) */

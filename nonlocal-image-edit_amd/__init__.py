@@ -102,6 +102,17 @@ def lab8_tables():
     return g, c, k.reshape(3, 3)
 
 
+def lab8_inverse_tables():
+    """tables of the integer 8-bit Lab -> BGR conversion (nle_lab8_inverse_tables): yf[256][2], ab_to_xz[36864] (index
+    t + 8145), inv_gamma[4096], coeffs[3][3] (rows R, G, B)"""
+    yf = np.zeros(512, dtype=np.uint16)
+    ab = np.zeros(36864, dtype=np.int32)
+    ig = np.zeros(4096, dtype=np.uint16)
+    k = np.zeros(9, dtype=np.int32)
+    _check(lib().nle_lab8_inverse_tables(_np_ptr(yf), _np_ptr(ab), _np_ptr(ig), _np_ptr(k)))
+    return yf.reshape(256, 2), ab, ig, k.reshape(3, 3)
+
+
 def sample_grid(H, W, n_row_samples, n_col_samples):
     """`samplePixels` (src/filter.cpp:56-80) in closed form.
     Returns dict(row_step,row_off,n_sel_rows,col_step,col_off,n_sel_cols)."""
@@ -591,6 +602,42 @@ class NLEFilter:
             raise NLEError(NLE_ERR_INVALID, f"apply_layers_host: out must be a C-contiguous float32 array of "
                                             f"{int(n_layers)} x {n_local} values")
         _check(lib().nle_apply_layers_host(self._f, xp, H, W, int(n_layers), _np_ptr(out)), self.ctx._h)
+        return out
+
+    def apply_u8_host(self, x, f_s, out):
+        """nle_apply_u8_host: the 8-bit L plane `enhance` merges back (src/filter.cpp:428-436) -- apply, clamp to
+        [0, 255], round half to even.  x a HOST H x W fp32 array or None (= the training plane); out: HOST uint8 array of
+        n_local values"""
+        H, W = self.shape
+        n_local = self.info()["n_local"]
+        fs = np.ascontiguousarray(f_s, dtype=np.float64)
+        if fs.ndim != 1 or fs.size != self.info()["K"]:
+            raise NLEError(NLE_ERR_INVALID, f"f_s must hold K' = {self.info()['K']} values, got {fs.shape}")
+        xp = None
+        if x is not None:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            want = n_local if (self.ctx.slab_input and self.ctx.world > 1) else H * W
+            if x.size != want:
+                raise NLEError(NLE_ERR_INVALID, f"apply_u8_host: x has {x.size} values, the filter needs {want}")
+            xp = _np_ptr(x)
+        if not (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.flags.c_contiguous and out.size == n_local):
+            raise NLEError(NLE_ERR_INVALID, f"apply_u8_host: out must be a C-contiguous uint8 array of {n_local} values")
+        _check(lib().nle_apply_u8_host(self._f, xp, H, W, _np_ptr(fs), _np_ptr(out)), self.ctx._h)
+        return out
+
+    def apply_u8(self, x, f_s, out=None):
+        """nle_apply_u8: the same on a device-resident plane; returns a uint8 device tensor of n_local values"""
+        torch = _torch()
+        x = self.ctx._lum(x)
+        H, W = self._full_shape(x, self.shape)
+        fs = np.ascontiguousarray(f_s, dtype=np.float64)
+        if fs.ndim != 1 or fs.size != self.info()["K"]:
+            raise NLEError(NLE_ERR_INVALID, f"f_s must hold K' = {self.info()['K']} values, got {fs.shape}")
+        n = self.info()["n_local"]
+        if out is None:
+            out = torch.empty(n, dtype=torch.uint8, device=x.device)
+        _check(lib().nle_apply_u8(self._f, C.c_void_p(x.data_ptr()), H, W, _np_ptr(fs), C.c_void_p(out.data_ptr())),
+               self.ctx._h)
         return out
 
     def info(self):

@@ -22,7 +22,7 @@ LIBDIR = os.path.join(HERE, "lib")
 BINDIR = os.path.join(HERE, "bin")
 LIB = os.path.join(LIBDIR, "libnle_hip.so")
 
-LIB_SOURCES = ["kernels.hip", "tsgemm_bf16x3.hip", "fused.hip", "sorted.hip", "generic64.hip", "tridiag.hip", "dense64.hip", "colour.hip", "pipeline.hip", "ortho.hip", "abi_ctx.hip", "devsolve.hip", "eigen_sym.cpp"]
+LIB_SOURCES = ["kernels.hip", "tsgemm_bf16x3.hip", "fused.hip", "sorted.hip", "generic64.hip", "tridiag.hip", "dense64.hip", "colour.hip", "pipeline.hip", "ortho.hip", "abi_ctx.hip", "devsolve.hip", "eigen_sym.cpp", "lab8_tables.cpp"]
 ARCH = "gfx950"
 
 
@@ -70,7 +70,10 @@ def build_lib(force: bool = False) -> str:
         objs.append(o)
         if force or _newer(o, [s] + sorted(_includes(s))):
             if s.endswith(".cpp"):  # host-only fp64 algebra: plain g++ (needs function multiversioning)
-                jobs.append(["g++", "-O3", "-fopenmp-simd", "-std=c++17", "-fPIC", "-pthread", "-Wno-psabi", "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
+                # lab8_tables.cpp reproduces single-precision table arithmetic operation by operation: no contraction
+                extra = ["-ffp-contract=off"] if os.path.basename(s) == "lab8_tables.cpp" else []
+                jobs.append(["g++", "-O3", "-fopenmp-simd", "-std=c++17", "-fPIC", "-pthread", "-Wno-psabi"] + extra +
+                            ["-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
             else:
                 jobs.append([_hipcc(), "-x", "hip", "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC",
                              "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])

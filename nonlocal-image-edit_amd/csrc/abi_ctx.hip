@@ -2,6 +2,9 @@
 // RCCL bootstrap, colour conversion and the bilateral pre-filter launches, the host-side eigen-solver entry points, the
 // closed-form helpers (sample grid, row slabs, eigenvalue transforms) and the profiling switches.  The train / apply /
 // stage-level entry points are in pipeline.hip, the device dense solvers' in devsolve.hip.
+#include <mutex>
+
+#include "lab8_fixed.h"
 #include "pipeline_internal.h"
 
 using nlek::GridSpec;
@@ -130,30 +133,20 @@ int nle_dev_download(nle_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
 }
 
 namespace {
-// gamma[256] | cbrt[3072] (u16) | coeffs[9] (int) of the fixed-point BGR -> Lab conversion, uploaded once per ctx
-constexpr int kLabCbrtN = 256 * 3 / 2 * 8;
-void lab8_tables_host(unsigned short* gamma, unsigned short* cbrt_tab, int* coeffs) {
-    for (int i = 0; i < 256; ++i) {
-        const double x = i / 255.0;
-        gamma[i] = (unsigned short)std::nearbyint(255.0 * 8.0 * (x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4)));
-    }
-    for (int i = 0; i < kLabCbrtN; ++i) {
-        const double t = i / (255.0 * 8.0);
-        cbrt_tab[i] = (unsigned short)std::nearbyint(32768.0 * (t < 0.008856 ? t * 7.787 + 0.13793103448275862 : std::cbrt(t)));
-    }
-    const double M[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
-    const double wp[3] = {0.950456, 1.0, 1.088754};
-    for (int r = 0; r < 3; ++r)
-        for (int cc = 0; cc < 3; ++cc) coeffs[3 * r + cc] = (int)std::nearbyint(4096.0 * M[r][cc] / wp[r]);
-}
+// the tables of the fixed-point 8-bit BGR <-> Lab conversions (lab8_fixed.h), uploaded once per ctx as one blob
 const double* colour_lut(nle_ctx* c) {
     if (!c->d_lut) {
-        // one allocation: 256 + 3072 u16, then 9 ints (4-byte aligned: 3328 u16 = 6656 bytes)
-        std::vector<unsigned char> blob((256 + kLabCbrtN) * sizeof(unsigned short) + 9 * sizeof(int));
-        lab8_tables_host(reinterpret_cast<unsigned short*>(blob.data()), reinterpret_cast<unsigned short*>(blob.data()) + 256,
-                         reinterpret_cast<int*>(blob.data() + (256 + kLabCbrtN) * sizeof(unsigned short)));
-        HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->d_lut), blob.size()));
-        HIP_OK(hipMemcpy(c->d_lut, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        using namespace nlelab8;
+        alignas(8) static unsigned char blob[kBlobBytes];
+        static std::once_flag once;
+        std::call_once(once, [] {
+            forward_tables(reinterpret_cast<unsigned short*>(blob + kOffGamma), reinterpret_cast<unsigned short*>(blob + kOffCbrt),
+                           reinterpret_cast<int*>(blob + kOffCoeffs));
+            inverse_tables(reinterpret_cast<unsigned short*>(blob + kOffYf), reinterpret_cast<unsigned short*>(blob + kOffInvGamma),
+                           reinterpret_cast<int*>(blob + kOffInvCoeffs));
+        });
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->d_lut), kBlobBytes));
+        HIP_OK(hipMemcpy(c->d_lut, blob, kBlobBytes, hipMemcpyHostToDevice));
     }
     return c->d_lut;
 }
@@ -161,7 +154,14 @@ const double* colour_lut(nle_ctx* c) {
 
 int nle_lab8_tables(unsigned short* h_gamma, unsigned short* h_cbrt, int* h_coeffs) {
     if (!h_gamma || !h_cbrt || !h_coeffs) return NLE_ERR_INVALID;
-    lab8_tables_host(h_gamma, h_cbrt, h_coeffs);
+    nlelab8::forward_tables(h_gamma, h_cbrt, h_coeffs);
+    return NLE_OK;
+}
+
+int nle_lab8_inverse_tables(unsigned short* h_yf, int* h_ab_to_xz, unsigned short* h_inv_gamma, int* h_coeffs) {
+    if (!h_yf || !h_ab_to_xz || !h_inv_gamma || !h_coeffs) return NLE_ERR_INVALID;
+    nlelab8::inverse_tables(h_yf, h_inv_gamma, h_coeffs);
+    for (int i = 0; i < nlelab8::kAbN; ++i) h_ab_to_xz[i] = nlelab8::ab_to_xz(i + nlelab8::kMinAB);
     return NLE_OK;
 }
 
@@ -183,7 +183,7 @@ int nle_lab2bgr8_planes(nle_ctx* ctx, const unsigned char* d_lab, const float* d
     if (!ctx || !d_lab || !d_bgr || n < 0) return NLE_ERR_INVALID;
     return guard(ctx, [&] {
         HIP_OK(hipSetDevice(ctx->device));
-        HIP_OK(nlek::lab2bgr8(ctx->stream, d_lab, d_L, d_a, d_b, n, d_bgr));
+        HIP_OK(nlek::lab2bgr8(ctx->stream, d_lab, d_L, d_a, d_b, n, colour_lut(ctx), d_bgr));
         HIP_OK(hipStreamSynchronize(ctx->stream));
     });
 }

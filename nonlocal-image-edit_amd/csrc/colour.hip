@@ -1,22 +1,20 @@
 // 8-bit BGR <-> Lab on the device: the colour wrapper either side of the hot path
 // (reference src/filter.cpp:460-469 getLuminanceChannel, :422-426 and :434-440 in NLEFilter::enhance,
-// where it is cv::cvtColor on 8-bit images).  BGR -> Lab is OpenCV's fixed-point table algorithm (exact integers, the
-// same as the host restatement in host/filter.cpp); Lab -> BGR the documented float formula in fp64 (agrees with the host
-// restatement except for isolated round-to-nearest ties; OpenCV's own 8-bit inverse is not pinned).
+// where it is cv::cvtColor on 8-bit images).  Both directions are OpenCV's integer table algorithms (lab8_fixed.h: exact
+// integers, the same as the host restatement in host/filter.cpp and as the oracle; the author's output files of the
+// reference's README are reproduced byte for byte where the filtered L plane has no rounding tie).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 
 #include "kernels.h"
+#include "lab8_fixed.h"
 
 namespace nlek {
 
 namespace {
-__device__ __forceinline__ unsigned char sat8(double v) {
-    return (unsigned char)fmin(255.0, fmax(0.0, rint(v)));  // round half to even, saturate (cv convertTo CV_8U)
-}
-__device__ __forceinline__ double lin2srgb(double v) {
-    return v <= 0.0031308 ? 12.92 * v : 1.055 * pow(fmax(v, 0.0), 1.0 / 2.4) - 0.055;
+__device__ __forceinline__ int sat8i(float v) {
+    return (int)fminf(255.f, fmaxf(0.f, rintf(v)));  // round half to even, saturate (cv convertTo CV_8U)
 }
 }  // namespace
 
@@ -26,13 +24,14 @@ __device__ __forceinline__ double lin2srgb(double v) {
 __global__ __launch_bounds__(256) void k_bgr2lab8(const unsigned char* __restrict__ bgr, long long n,
                                                   const double* __restrict__ lut, unsigned char* __restrict__ lab,
                                                   float* __restrict__ Lf) {
-    constexpr int NCB = 256 * 3 / 2 * 8;
+    constexpr int NCB = nlelab8::kCbrtN;
     __shared__ unsigned short sg[256], sc[NCB];
     __shared__ int sk[9];
-    const unsigned short* t16 = reinterpret_cast<const unsigned short*>(lut);
+    const unsigned char* blob = reinterpret_cast<const unsigned char*>(lut);
+    const unsigned short* t16 = reinterpret_cast<const unsigned short*>(blob + nlelab8::kOffGamma);
     for (int i = threadIdx.x; i < 256; i += 256) sg[i] = t16[i];
     for (int i = threadIdx.x; i < NCB; i += 256) sc[i] = t16[256 + i];
-    if (threadIdx.x < 9) sk[threadIdx.x] = reinterpret_cast<const int*>(t16 + 256 + NCB)[threadIdx.x];
+    if (threadIdx.x < 9) sk[threadIdx.x] = reinterpret_cast<const int*>(blob + nlelab8::kOffCoeffs)[threadIdx.x];
     __syncthreads();
     auto sat = [](int v) { return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -51,31 +50,37 @@ __global__ __launch_bounds__(256) void k_bgr2lab8(const unsigned char* __restric
 }
 
 // L from Lf when given (clamped to [0,255] and rounded half-to-even like :434-436), else lab's own
-// (the denoise wrapper also replaces a and b by filtered planes, clamped and rounded the same way, :391-399)
+// (the denoise wrapper also replaces a and b by filtered planes, clamped and rounded the same way, :391-399).
+// OpenCV's Lab2RGBinteger: (y, fy) from a 256-entry table, fx / fz by fixed-point divisions, the inverse of f(t) in
+// integers (ab_to_xz, computed rather than looked up: its table would be 147 KB), the matrix in 12-bit fixed point and a
+// 4096-entry sRGB encoding table -- the two small tables in LDS.
 __global__ __launch_bounds__(256) void k_lab2bgr8(const unsigned char* __restrict__ lab, const float* __restrict__ Lf,
                                                   const float* __restrict__ af, const float* __restrict__ bf,
-                                                  long long n, unsigned char* __restrict__ bgr) {
+                                                  long long n, const double* __restrict__ lut,
+                                                  unsigned char* __restrict__ bgr) {
+    using namespace nlelab8;
+    __shared__ unsigned short syf[kYfN], sig[kInvGammaN];
+    __shared__ int sk[9];
+    const unsigned char* blob = reinterpret_cast<const unsigned char*>(lut);
+    const unsigned short* gyf = reinterpret_cast<const unsigned short*>(blob + kOffYf);
+    const unsigned short* gig = reinterpret_cast<const unsigned short*>(blob + kOffInvGamma);
+    for (int i = threadIdx.x; i < kYfN; i += 256) syf[i] = gyf[i];
+    for (int i = threadIdx.x; i < kInvGammaN; i += 256) sig[i] = gig[i];
+    if (threadIdx.x < 9) sk[threadIdx.x] = reinterpret_cast<const int*>(blob + kOffInvCoeffs)[threadIdx.x];
+    __syncthreads();
+    auto enc = [&](int c0, int c1, int c2, int x, int y, int z) {
+        const int v = (c0 * x + c1 * y + c2 * z + (1 << 13)) >> 14;
+        return (unsigned char)sig[v < 0 ? 0 : (v > kInvGammaN - 1 ? kInvGammaN - 1 : v)];
+    };
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const double L8 = Lf != nullptr ? (double)sat8((double)Lf[i]) : (double)lab[3 * i + 0];
-        const double a8 = af != nullptr ? (double)sat8((double)af[i]) : (double)lab[3 * i + 1];
-        const double b8 = bf != nullptr ? (double)sat8((double)bf[i]) : (double)lab[3 * i + 2];
-        const double L = L8 * 100.0 / 255.0, a = a8 - 128.0, b = b8 - 128.0;
-        double fy = (L + 16.0) / 116.0, y;
-        if (L > 7.9996248) {
-            y = fy * fy * fy;
-        } else {
-            y = L / 903.3;
-            fy = 7.787 * y + 16.0 / 116.0;
-        }
-        const double fx = a / 500.0 + fy, fz = fy - b / 200.0;
-        const double x = (fx > 0.206893 ? fx * fx * fx : (fx - 16.0 / 116.0) / 7.787) * 0.950456;
-        const double z = (fz > 0.206893 ? fz * fz * fz : (fz - 16.0 / 116.0) / 7.787) * 1.088754;
-        const double r = 3.240479 * x - 1.53715 * y - 0.498535 * z;
-        const double g = -0.969256 * x + 1.875991 * y + 0.041556 * z;
-        const double bl = 0.055648 * x - 0.204043 * y + 1.057311 * z;
-        bgr[3 * i + 0] = sat8(lin2srgb(fmin(1.0, fmax(0.0, bl))) * 255.0);
-        bgr[3 * i + 1] = sat8(lin2srgb(fmin(1.0, fmax(0.0, g))) * 255.0);
-        bgr[3 * i + 2] = sat8(lin2srgb(fmin(1.0, fmax(0.0, r))) * 255.0);
+        const int L8 = Lf != nullptr ? sat8i(Lf[i]) : (int)lab[3 * i + 0];
+        const int a8 = af != nullptr ? sat8i(af[i]) : (int)lab[3 * i + 1];
+        const int b8 = bf != nullptr ? sat8i(bf[i]) : (int)lab[3 * i + 2];
+        const int y = syf[2 * L8], fy = syf[2 * L8 + 1];
+        const int x = ab_to_xz(fx_of(fy, a8)), z = ab_to_xz(fz_of(fy, b8));
+        bgr[3 * i + 0] = enc(sk[6], sk[7], sk[8], x, y, z);
+        bgr[3 * i + 1] = enc(sk[3], sk[4], sk[5], x, y, z);
+        bgr[3 * i + 2] = enc(sk[0], sk[1], sk[2], x, y, z);
     }
 }
 
@@ -88,10 +93,10 @@ hipError_t bgr2lab8(hipStream_t s, const unsigned char* d_bgr, long long n, cons
 }
 
 hipError_t lab2bgr8(hipStream_t s, const unsigned char* d_lab, const float* d_L, const float* d_a, const float* d_b,
-                    long long n, unsigned char* d_bgr) {
+                    long long n, const double* d_lut, unsigned char* d_bgr) {
     if (n <= 0) return hipSuccess;
     const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_lab2bgr8, dim3(grid), dim3(256), 0, s, d_lab, d_L, d_a, d_b, n, d_bgr);
+    hipLaunchKernelGGL(k_lab2bgr8, dim3(grid), dim3(256), 0, s, d_lab, d_L, d_a, d_b, n, d_lut, d_bgr);
     return hipGetLastError();
 }
 
@@ -106,6 +111,29 @@ hipError_t channel8(hipStream_t s, const unsigned char* d_img, long long n, int 
     if (n <= 0) return hipSuccess;
     const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(k_channel8, dim3(grid), dim3(256), 0, s, d_img, n, ch, d_out);
+    return hipGetLastError();
+}
+
+// the tail of NLEFilter::enhance on the filtered plane alone (src/filter.cpp:434-436): clamp to [0, 255], convertTo(CV_8U)
+// (round half to even).  Four pixels per thread where the plane allows 16-byte loads.
+__global__ __launch_bounds__(256) void k_plane_to_u8(const float* __restrict__ y, long long n, unsigned char* __restrict__ out) {
+    const long long n4 = n >> 2;
+    const bool vec = ((reinterpret_cast<size_t>(y) & 15) | (reinterpret_cast<size_t>(out) & 3)) == 0;
+    if (vec) {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            const float4 v = reinterpret_cast<const float4*>(y)[i];
+            const unsigned r = (unsigned)sat8i(v.x) | ((unsigned)sat8i(v.y) << 8) | ((unsigned)sat8i(v.z) << 16) | ((unsigned)sat8i(v.w) << 24);
+            reinterpret_cast<unsigned*>(out)[i] = r;
+        }
+    }
+    for (long long i = (vec ? n4 * 4 : 0) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = (unsigned char)sat8i(y[i]);
+}
+
+hipError_t plane_to_u8(hipStream_t s, const float* d_y, long long n, unsigned char* d_out) {
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)std::min<long long>((n / 4 + 255) / 256 + 1, 4096);
+    hipLaunchKernelGGL(k_plane_to_u8, dim3(grid), dim3(256), 0, s, d_y, n, d_out);
     return hipGetLastError();
 }
 

@@ -275,8 +275,10 @@ hipError_t project_hist(hipStream_t s, const float* d_lum, GridSpec gs, int p, i
 hipError_t bgr2lab8(hipStream_t s, const unsigned char* d_bgr, long long n, const double* d_lut, unsigned char* d_lab,
                     float* d_L);
 hipError_t lab2bgr8(hipStream_t s, const unsigned char* d_lab, const float* d_L, const float* d_a, const float* d_b,
-                    long long n, unsigned char* d_bgr);
+                    long long n, const double* d_lut, unsigned char* d_bgr);
 hipError_t channel8(hipStream_t s, const unsigned char* d_img, long long n, int ch, float* d_out);
+// cv::max(y, 0) / cv::min(y, 255) / convertTo(CV_8U) of a filtered plane (src/filter.cpp:434-436): round half to even
+hipError_t plane_to_u8(hipStream_t s, const float* d_y, long long n, unsigned char* d_out);
 // single-channel 8-bit bilateral filter (fp32 planes holding integers); tables from the host: space_w (2r+1)^2 with 0
 // outside the circle, colour_w 256 entries
 int bilateral8_max_radius();

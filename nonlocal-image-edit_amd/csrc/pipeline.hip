@@ -1634,6 +1634,48 @@ int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, 
     });
 }
 
+// NLEFilter::enhance's L plane (src/filter.cpp:428-436): apply, clamp, convertTo(CV_8U) -- one byte per pixel leaves the device
+int nle_apply_u8(nle_filter* f, const float* d_x, int H, int W, const double* h_fS, unsigned char* d_out) {
+    if (!f || !f->ctx || !d_x || !h_fS || !d_out) return NLE_ERR_INVALID;
+    return guard(f->ctx, [&] {
+        nle_ctx* c = f->ctx;
+        DevBuf<float> d_y((size_t)std::max<long long>(f->n_local, 1));
+        apply_impl(f, d_x, H, W, h_fS, 1, d_y.p);
+        HIP_OK(nlek::plane_to_u8(c->stream, d_y.p, f->n_local, d_out));
+        HIP_OK(hipStreamSynchronize(c->stream));   // d_y returns to the ctx's cache
+    });
+}
+
+int nle_apply_u8_host(nle_filter* f, const float* h_x, int H, int W, const double* h_fS, unsigned char* h_out) {
+    if (!f || !f->ctx || !h_fS || !h_out) return NLE_ERR_INVALID;
+    return guard(f->ctx, [&] {
+        nle_ctx* c = f->ctx;
+        if ((long long)H * W != (long long)f->H * f->W)
+            throw Fail{NLE_ERR_INVALID, "Number of values in channel must match that of training image."};
+        if (!h_x && !f->d_plane)
+            throw Fail{NLE_ERR_INVALID, "h_x == NULL needs a filter trained by nle_train_host (it keeps the training plane)"};
+        HIP_OK(hipSetDevice(c->device));
+        const size_t n = (size_t)std::max<long long>(f->n_local, 1);
+        DevBuf<float> d_xbuf, d_y(n);
+        DevBuf<unsigned char> d_o(n);
+        const float* d_x = f->d_plane;
+        if (h_x) {
+            const size_t npx = (c->slab_input && c->world > 1) ? (size_t)f->n_local : (size_t)H * W;
+            d_xbuf.alloc(std::max<size_t>(npx, 1));
+            HIP_OK(hipMemcpyAsync(d_xbuf.p, h_x, npx * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            d_x = d_xbuf.p;
+        }
+        struct Drain {   // no copy may still be writing the caller's buffer, nor a kernel using d_y, when this is left
+            nle_ctx* c;
+            ~Drain() { (void)hipStreamSynchronize(c->stream); }
+        } drain{c};
+        apply_impl(f, d_x, H, W, h_fS, 1, d_y.p);
+        HIP_OK(nlek::plane_to_u8(c->stream, d_y.p, f->n_local, d_o.p));
+        HIP_OK(hipMemcpyAsync(h_out, d_o.p, (size_t)f->n_local, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    });
+}
+
 int nle_bench_affinity(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples, int n_col_samples, double hx,
                        double hy, float* d_kab, int reps, double* h_avg_ms) {
     if (!ctx || !d_lum || !d_kab || reps < 1 || !h_avg_ms) return NLE_ERR_INVALID;

@@ -447,16 +447,7 @@ Vec transformEigenValues(const Vec& eigvals, const std::vector<DType>& weights) 
 }
 
 // ------------------------------------------------------------------ colour wrapper (host)
-namespace {
-// cv::cvtColor on 8-bit images.  BGR -> Lab: OpenCV's fixed-point table algorithm (below).  Lab -> BGR: the documented
-// float formula (sRGB encode of the XYZ D65 inverse); OpenCV's own 8-bit inverse differs between versions and is unpinned.
-const double kXn = 0.950456, kZn = 1.088754;
-const double kM[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
-const double kMi[3][3] = {{3.240479, -1.53715, -0.498535}, {-0.969256, 1.875991, 0.041556}, {0.055648, -0.204043, 1.057311}};
-inline double lin2srgb(double v) { return v <= 0.0031308 ? 12.92 * v : 1.055 * std::pow(std::max(v, 0.0), 1 / 2.4) - 0.055; }
-inline unsigned char sat8(double v) { return (unsigned char)std::min(255.0, std::max(0.0, std::nearbyint(v))); }
-}  // namespace
-
+// cv::cvtColor on 8-bit images: both directions are OpenCV's integer table algorithms (tables from the C ABI)
 Image bgr2lab8(const Image& bgr) {
     if (bgr.channels() != 3 || bgr.depth() != NLE_8U) throw std::runtime_error("bgr2lab8: 8UC3 image expected");
     // OpenCV's fixed-point 8-bit path (imgproc RGB2Lab_b; include/nle.h at nle_lab8_tables): exact integers
@@ -481,32 +472,31 @@ Image bgr2lab8(const Image& bgr) {
 
 Image lab2bgr8(const Image& lab) {
     if (lab.channels() != 3 || lab.depth() != NLE_8U) throw std::runtime_error("lab2bgr8: 8UC3 image expected");
+    // OpenCV's integer 8-bit path (imgproc Lab2RGBinteger; include/nle.h at nle_lab8_inverse_tables): exact integers
+    static std::vector<int> ab(36864);
+    static unsigned short yf[512], ig[4096];
+    static int k[9];
+    static const bool ok = nle_lab8_inverse_tables(yf, ab.data(), ig, k) == NLE_OK;
+    if (!ok) throw std::runtime_error("lab2bgr8: tables");
     Image bgr(lab.rows, lab.cols, NLE_8U, 3);
     const unsigned char* s = lab.ptr<unsigned char>();
     unsigned char* d = bgr.ptr<unsigned char>();
-    auto finv = [](double t) { return t > 0.206893 ? t * t * t : (t - 16.0 / 116.0) / 7.787; };
+    auto enc = [&](const int* c, int x, int y, int z) {
+        const int v = (c[0] * x + c[1] * y + c[2] * z + (1 << 13)) >> 14;
+        return (unsigned char)ig[std::min(4095, std::max(0, v))];
+    };
     for (size_t i = 0; i < lab.total(); ++i, s += 3, d += 3) {
-        const double L = s[0] * 100.0 / 255.0, a = s[1] - 128.0, b = s[2] - 128.0;
-        double fy = (L + 16.0) / 116.0, y;
-        if (L > 7.9996248) {
-            y = fy * fy * fy;
-        } else {
-            y = L / 903.3;
-            fy = 7.787 * y + 16.0 / 116.0;
-        }
-        const double x = finv(a / 500.0 + fy) * kXn, z = finv(fy - b / 200.0) * kZn;
-        const double r = kMi[0][0] * x + kMi[0][1] * y + kMi[0][2] * z;
-        const double g = kMi[1][0] * x + kMi[1][1] * y + kMi[1][2] * z;
-        const double bl = kMi[2][0] * x + kMi[2][1] * y + kMi[2][2] * z;
-        d[0] = sat8(lin2srgb(std::min(1.0, std::max(0.0, bl))) * 255.0);
-        d[1] = sat8(lin2srgb(std::min(1.0, std::max(0.0, g))) * 255.0);
-        d[2] = sat8(lin2srgb(std::min(1.0, std::max(0.0, r))) * 255.0);
+        const int y = yf[2 * s[0]], fy = yf[2 * s[0] + 1];
+        const int x = ab[fy + (((5 * s[1] * 53687 + (1 << 7)) >> 13) - 4194) + 8145];
+        const int z = ab[fy - (((s[2] * 41943 + (1 << 4)) >> 9) - 10484) + 8145];
+        d[0] = enc(k + 6, x, y, z);
+        d[1] = enc(k + 3, x, y, z);
+        d[2] = enc(k, x, y, z);
     }
     return bgr;
 }
 
-// the same conversions on the GPU (csrc/colour.hip) -- what NLEFilter uses; results agree with the host
-// functions above except for isolated rounding ties
+// the same conversions on the GPU (csrc/colour.hip) -- what NLEFilter uses; bit-identical to the host functions above
 Image bgr2lab8_device(const Image& bgr) {
     if (bgr.channels() != 3 || bgr.depth() != NLE_8U) throw std::runtime_error("bgr2lab8: 8UC3 image expected");
     nle_ctx* c = shared_ctx();

@@ -39,4 +39,7 @@ CONFIGS = {
     "cfg3": dict(H=2048, W=2048, n_row=20, n_col=20, hx=2048 / 4, hy=30.0, T=50, K=50, L=4),
     "cfg4": dict(H=4096, W=4096, n_row=20, n_col=10, hx=4096 / 4, hy=30.0, T=10, K=50, L=4),
     "cfg5": dict(H=8192, W=8192, n_row=30, n_col=30, hx=8192 / 8, hy=30.0, T=10, K=100, L=6),
+    # cfg5's sample grid, bandwidth ratio (hx = W / 8), K and L at the largest size whose N x 900 fp64 matrix a 62 GB
+    # host holds (30 GB): the shape the CPU oracle can still pin (tests/golden/fullsize_cfg5_2k.npz)
+    "cfg5_2k": dict(H=2048, W=2048, n_row=30, n_col=30, hx=2048 / 8, hy=30.0, T=10, K=100, L=6),
 }

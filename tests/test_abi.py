@@ -150,6 +150,20 @@ def test_lab8_tables_are_the_oracles(nle, oracle):
     go, co, ko = oracle.lab8_tables()
     assert np.array_equal(g, go) and np.array_equal(c, co) and np.array_equal(k, ko)
     assert g[0] == 0 and g[255] == 2040 and c.size == 3072 and int(k[1].sum()) == 4096
+    # made in single precision with OpenCV's truncating cube root: exactly two entries differ (by one) from the table a
+    # double-precision cube root gives -- what decides the last 16 pixels of the reference's flower-filtered.png
+    t = np.arange(3072) / 2040.0
+    c64 = np.rint(32768 * np.where(t < 216 / 24389, t * (841 / 108) + 16 / 116, np.cbrt(t))).astype(np.int64)
+    assert np.flatnonzero(c64 != c).tolist() == [49, 628] and int(c[49]) == c64[49] - 1 and int(c[628]) == c64[628] + 1
+
+
+def test_lab8_inverse_tables_are_the_oracles(nle, oracle):
+    """the same for the integer Lab -> BGR (OpenCV's Lab2RGBinteger) behind nle_lab2bgr8 and the C++ surface's lab2bgr8"""
+    yf, ab, ig, k = nle.lab8_inverse_tables()
+    yfo, abo, igo, ko = oracle.lab8_inverse_tables()
+    assert np.array_equal(yf, yfo) and np.array_equal(ab, abo) and np.array_equal(ig, igo) and np.array_equal(k, ko)
+    assert ig[0] == 0 and ig[-1] == 255 and yf[255, 0] == 16384 and yf[255, 1] == 16384 and yf[0, 1] == 2260
+    assert ab[0] == -1335 and ab[3390 + 8145] == 145 and ab[16384 + 8145] == 16384       # both branches of f^-1, C division
 
 
 def test_product_never_imports_the_oracle():

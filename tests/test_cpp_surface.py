@@ -115,7 +115,7 @@ def test_enhance_cli_on_a_large_ppm_matches_the_python_pipeline(nle, oracle, ctx
     want = oracle.lab8_to_bgr(lab2)
     d = np.abs(got.astype(int) - want.astype(int))
     print("CLI vs python pipeline: max", d.max(), "mismatching values", (d > 0).mean())
-    assert d.max() <= 3 and (d > 0).mean() < 5e-3     # rounding ties in the 8-bit conversions only
+    assert d.max() <= 3 and (d > 0).mean() < 1e-3     # rounding ties of the filtered L plane only: both conversions are exact integers
     f.close()
 
 

@@ -120,7 +120,7 @@ def test_denoise_cli_matches_the_oracle_pipeline(oracle, tmp_path):
     assert got.shape == want.shape == src.shape
     d = np.abs(got.astype(int) - want.astype(int))
     print("denoise CLI vs oracle: max", d.max(), "mismatching values", (d > 0).mean())
-    assert d.max() <= 3 and (d > 0).mean() < 5e-3          # rounding ties in the 8-bit conversions only
+    assert d.max() <= 3 and (d > 0).mean() < 5e-3          # rounding ties of the filtered a, b planes only
     # and it is a denoiser of the chroma: a/b channels get smoother, L is the bilateral-filtered plane
     lab_in, lab_out = oracle.bgr_to_lab8(src).astype(int), oracle.bgr_to_lab8(got).astype(int)
     for ch in (1, 2):
@@ -178,3 +178,25 @@ def test_device_bgr2lab8_equals_the_oracle_on_every_colour(nle, oracle, ctx):
         want = oracle.bgr_to_lab8(cube)
         assert np.array_equal(lab.cpu().numpy(), want), b
         assert np.array_equal(L.cpu().numpy(), want[..., 0].astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_device_lab2bgr8_equals_the_oracle_on_every_lab_triple(nle, oracle, ctx):
+    """nle_lab2bgr8 is OpenCV's integer 8-bit Lab -> BGR (Lab2RGBinteger on the tables of nle_lab8_inverse_tables; the
+    inverse of f(t) computed in the kernel, looked up in the oracle): all 2^24 (L, a, b) triples come out exactly as the
+    oracle's restatement of that algorithm has them -- and so do float planes handed in for L, a, b after their clamp and
+    round-half-even (src/filter.cpp:434-436, :391-399)"""
+    import torch
+    v = np.arange(256, dtype=np.uint8)
+    for l0 in range(0, 256, 16):   # 16 L values per slab: 16 x 256 x 256 triples
+        cube = np.ascontiguousarray(np.stack(np.meshgrid(v[l0:l0 + 16], v, v, indexing="ij"), axis=-1).reshape(16 * 256, 256, 3))
+        got = ctx.lab2bgr8(torch.as_tensor(cube, device="cuda:0")).cpu().numpy()
+        assert np.array_equal(got, oracle.lab8_to_bgr(cube)), l0
+    rng = np.random.default_rng(11)
+    lab = rng.integers(0, 256, (64, 96, 3)).astype(np.uint8)
+    Lf = rng.uniform(-20, 280, (64, 96)).astype(np.float32)
+    Lf[0, :8] = [0.5, 1.5, 2.5, 254.5, 255.5, -0.5, 127.5, 128.5]          # ties go to even
+    want = lab.copy()
+    want[..., 0] = np.rint(np.clip(Lf.astype(np.float64), 0, 255)).astype(np.uint8)
+    got = ctx.lab2bgr8(torch.as_tensor(lab, device="cuda:0"), torch.as_tensor(Lf, device="cuda:0")).cpu().numpy()
+    assert np.array_equal(got, oracle.lab8_to_bgr(want))

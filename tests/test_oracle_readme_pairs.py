@@ -4,13 +4,15 @@ the eleven pairs are rank-truncated -- eigenvalues of Ka, Wa and Q sit right at 
 :262, :287, :313) -- so these are the inputs on which the truncation rules, `q = phi.cols()` (:247) and the
 lower-triangle reading of the non-symmetric Wa (:287) matter.
 
-The 8-bit Lab conversion either side of the path is OpenCV's in the reference.  Rounds 1-3 restated the float formula of
-its documentation and met the author's outputs to 0.2-0.8 grey levels (`bird` 3.35, `rock2` 2.0: tools/
-readme_pair_sensitivity.py showed +-1 level on a tenth of the L pixels moving those outputs by several levels).  OpenCV's
-8-bit BGR -> Lab is in fact a fixed-point table algorithm (oracle.bgr_to_lab8 now restates THAT; 14-16 % of the L pixels
-differ by one level from the float formula): with it the oracle reproduces ALL eleven author's outputs to 0.009-0.044 grey
-levels in the mean and at most one level at the 99th percentile -- what is left is the author's file having gone through
-Lab -> BGR and back.  So the pairs now pin the hot path's arithmetic, the truncation rules AND the colour conversion.
+The 8-bit Lab conversions either side of the path are OpenCV's in the reference (cv::cvtColor, :423 and :440).  Both are
+integer table algorithms there, not the float formulas of the documentation, and the oracle restates both
+(`bgr_to_lab8`: RGB2Lab_b with its single-precision tables, round 3 / 4; `lab8_to_bgr`: Lab2RGBinteger, round 4).  With them
+the oracle writes the author's output FILES: flower, brickwall and red-cherries byte for byte (every B, G, R value of the
+image), snow-mountain, paper, canyon, conifer to 1-5 values per 100 000, forest 99.96 %, mountain 99.7 %, bird 99.5 % -- and
+every byte that differs is explained by the filtered L plane being one level off at a rounding tie of an ill-conditioned
+example (bird: 905 of 182 865 pixels, all of them fixed by L -+ 1).  With the float formulas (rounds 1-3) 1.5-7 % of the
+bytes differed and the L planes were 0.2-3.4 grey levels apart in the mean.  So the pairs pin the hot path's arithmetic, the
+truncation rules AND both colour conversions, at the resolution of the author's own files.
 """
 import json
 import os
@@ -21,9 +23,13 @@ import pytest
 import readme_pairs as rp
 from conftest import GOLDEN
 
-# mean / p99 of |L_oracle - L_author| in grey levels allowed per pair (measured: 0.009 .. 0.044 and <= 1, tests/golden/
-# readme_oracle.json)
-TOL = {name: (0.1, 1.0) for name in [p[0] for p in rp.PAIRS]}
+# mean / p99 of |L_oracle - L_author| in grey levels allowed per pair (measured: 0 .. 0.005 and 0, tests/golden/
+# readme_oracle.json), L of both files read back through the pinned BGR -> Lab
+TOL = {name: (0.01, 0.0) for name in [p[0] for p in rp.PAIRS]}
+# fraction of the B, G, R values of the written file that must equal the author's file (measured: 1.0 on flower, brickwall,
+# red-cherries; the residue elsewhere is rounding ties of the filtered L plane)
+BGR_EXACT_MIN = {"flower": 1.0, "brickwall": 1.0, "red-cherries": 1.0, "bird": 0.994, "rock2": 0.994, "mountain": 0.996, "forest": 0.9995}
+BGR_EXACT_DEFAULT = 0.9999
 MOVED_MIN = {"paper": 4.5}   # how far the edit moves L at least (mean grey levels); 5 elsewhere
 
 _cache = {}
@@ -74,14 +80,13 @@ def test_oracle_reproduces_readme_output(oracle, golden, name):
     assert r["moved"] > MOVED_MIN.get(name, 5.0)  # the edit is large ...
     assert r["mean"] < mean_tol                  # ... and the oracle reproduces it
     assert r["p99"] <= p99_tol
-    # byte for byte against the author's FILE (which also went through OpenCV's 8-bit Lab -> BGR, here the documented float
-    # formula): at least nine values in ten identical, none further off than a few levels
-    print(f"{name}: {100 * r['bgr_exact']:.1f} % of the output file's B, G, R values equal the author's, max difference {r['bgr_max']}")
-    assert r["bgr_exact"] > 0.9 and r["bgr_max"] <= 4
+    # byte for byte against the author's FILE (which went through OpenCV's integer 8-bit Lab -> BGR, restated in the oracle)
+    print(f"{name}: {100 * r['bgr_exact']:.4f} % of the output file's B, G, R values equal the author's, max difference {r['bgr_max']}")
+    assert r["bgr_exact"] >= BGR_EXACT_MIN.get(name, BGR_EXACT_DEFAULT) and r["bgr_max"] <= 2
     # the rank decisions and spectra are the committed ones (guards against LAPACK / numpy drift of the oracle)
     assert cuts == [(c["n"], c["kept"]) for c in g["cuts"]]
     assert r["S"].size == g["K_out"]
-    np.testing.assert_allclose(r["S"], g["eigvals"], rtol=1e-6)
+    np.testing.assert_allclose(r["S"], g["eigvals"], rtol=1e-6, atol=1e-9)   # atol: eigenvalues near 1e-5 of an ill-conditioned pair move by 1e-11 with BLAS threading
     np.testing.assert_allclose(r["layer_norms"], g["layer_norms"], rtol=1e-5)
 
 

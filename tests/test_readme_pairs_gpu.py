@@ -18,7 +18,7 @@ import pytest
 
 import readme_pairs as rp
 from conftest import ROOT, rel_l2
-from test_oracle_readme_pairs import TOL, oracle_run
+from test_oracle_readme_pairs import BGR_EXACT_DEFAULT, BGR_EXACT_MIN, TOL, oracle_run
 
 pytestmark = pytest.mark.gpu
 
@@ -101,16 +101,19 @@ def test_enhance_cli_reproduces_readme_pair(oracle, tmp_path, name):
           f"{np.percentile(err, 99):.1f} (oracle {o['p99']:.1f}); kept {[info['r_Ka'], info['r_Wa'], info['r_Q']]}, "
           f"K' = {info['K']}")
     mean_tol, p99_tol = TOL[name]
-    assert err.mean() < mean_tol and np.percentile(err, 99) <= p99_tol
-    assert abs(err.mean() - o["mean"]) < 0.05                   # and it is the oracle's answer, not merely a close one
+    assert err.mean() < mean_tol + 2e-3 and np.percentile(err, 99) <= p99_tol   # + the HIP path's own rounding ties (< 2e-3 of the pixels)
+    assert abs(err.mean() - o["mean"]) < 2e-3                   # and it is the oracle's answer, not merely a close one
     assert [info["r_Ka"], info["r_Wa"]] == [c["kept"] for c in o["info"]][:2]
     assert abs(info["r_Q"] - o["info"][2]["kept"]) <= q_count_slack(o)
     assert info["K"] == o["S"].size
-    # byte for byte against the author's file: as close as the oracle's own output file is
+    # byte for byte against the author's FILE: both colour conversions are OpenCV's integer algorithms, so what can differ
+    # is a rounding tie of the filtered L plane (the HIP path's ties are allowed 2e-3 of the pixels above, each moving up
+    # to three bytes)
     d_file = np.abs(got.astype(int) - want.astype(int))
-    print(f"{name}: {100 * (d_file == 0).mean():.1f} % of the CLI's B, G, R values equal the author's file (oracle "
-          f"{100 * o['bgr_exact']:.1f} %), max difference {int(d_file.max())}")
-    assert (d_file == 0).mean() > 0.9 and abs((d_file == 0).mean() - o["bgr_exact"]) < 0.01 and d_file.max() <= 4
+    exact = float((d_file == 0).mean())
+    print(f"{name}: {100 * exact:.4f} % of the CLI's B, G, R values equal the author's file (oracle "
+          f"{100 * o['bgr_exact']:.4f} %), max difference {int(d_file.max())}")
+    assert exact >= BGR_EXACT_MIN.get(name, BGR_EXACT_DEFAULT) - 2e-3 and abs(exact - o["bgr_exact"]) < 2e-3 and d_file.max() <= 2
     # the colour planes pass through unchanged (src/filter.cpp:431-440)
     d_ab = np.abs(oracle.bgr_to_lab8(got)[..., 1:].astype(int) - oracle.bgr_to_lab8(want)[..., 1:].astype(int))
     assert d_ab.mean() < 0.5
