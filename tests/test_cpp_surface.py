@@ -120,6 +120,53 @@ def test_enhance_cli_on_a_large_ppm_matches_the_python_pipeline(nle, oracle, ctx
 
 
 @pytest.mark.gpu
+def test_enhance_cli_on_cfg5_s_3_channel_image(nle, oracle, ctx, tmp_path):
+    """BASELINE.json configs[4] end to end: an 8192 x 8192 3-channel image through `enhance` with 30 x 30 samples, hx = W / 8,
+    K = 100 and six weights (BGR -> Lab, train on L, apply, clamp / round, merge, Lab -> BGR -- all on the device) against the
+    same steps done plane by plane: the oracle's integer colour conversions (numpy, on the CPU) around the filter run
+    through the ctypes mirror.  Exact: both conversions are integer algorithms and the filter is the same library."""
+    H = W = 8192
+    base = oracle.synthetic_luminance(H, W)
+    img = np.empty((H, W, 3), dtype=np.uint8)                                        # BGR
+    for r0 in range(0, H, 1024):
+        rr, cc = np.mgrid[r0:r0 + 1024, 0:W]
+        b = base[r0:r0 + 1024]
+        img[r0:r0 + 1024, :, 0] = np.clip(b * 0.8 + 20 * np.sin(cc / 397.0), 0, 255)
+        img[r0:r0 + 1024, :, 1] = np.clip(b, 0, 255)
+        img[r0:r0 + 1024, :, 2] = np.clip(b * 0.9 + 25 * np.cos(rr / 261.0), 0, 255)
+    src, out = tmp_path / "in.ppm", tmp_path / "out.ppm"
+    head = b"P6\n%d %d\n255\n" % (W, H)
+    with open(src, "wb") as fh:
+        fh.write(head)
+        for r0 in range(0, H, 1024):
+            fh.write(np.ascontiguousarray(img[r0:r0 + 1024, :, ::-1]).tobytes())
+    args = ["30", "30", "1024", "30", "10", "100", "2", "3", "3", "4", "4", "1"]
+    r = subprocess.run([ENHANCE, str(src), str(out)] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(out, dtype=np.uint8)
+    assert bytes(raw[:len(head)]) == head
+    got = raw[len(head):].reshape(H, W, 3)                                           # RGB
+    lab = np.concatenate([oracle.bgr_to_lab8(img[r0:r0 + 512]) for r0 in range(0, H, 512)])
+    Lp = lab[..., 0].astype(np.float32)
+    f = nle.NLEFilter(ctx).train_filter(Lp, 30, 30, 1024.0, 30.0, 10, 100)
+    d = f.diag()
+    assert d["formulation"] == nle.MODE_PHI_FREE and d["p"] == 900 and d["K"] == 100
+    fs = nle.transform_eigenvalues(f.eigvals, [2.0, 3.0, 3.0, 4.0, 4.0, 1.0])
+    lab[..., 0] = f.apply_u8(Lp, fs).cpu().numpy().reshape(H, W)
+    f.close()
+    ctx.trim()
+    bad = worst = 0
+    for r0 in range(0, H, 512):
+        want = oracle.lab8_to_bgr(lab[r0:r0 + 512])[..., ::-1]
+        dd = np.abs(got[r0:r0 + 512].astype(np.int16) - want.astype(np.int16))
+        bad += int((dd > 0).sum())
+        worst = max(worst, int(dd.max()))
+    moved = float(np.abs(got[..., 1].astype(np.int16) - img[..., 1].astype(np.int16)).mean())
+    print(f"cfg5 3-channel CLI vs plane-level pipeline: {bad} of {got.size} values differ, max {worst}; the edit moves G by {moved:.2f}")
+    assert bad == 0 and moved > 1.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
 def test_enhance_cli_over_a_device_group_matches_one_device(tmp_path, devices):
     """NLE_DEVICES: `bin/enhance` shards the image by row slabs over one context and host thread per listed device

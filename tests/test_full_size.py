@@ -122,6 +122,53 @@ def test_other_full_size_configs_keep_the_filter_properties(nle, ctx, name):
     ctx.trim()
 
 
+def test_cfg5_table_form_agrees_with_the_streamed_fp64_formulation_at_full_size(nle, ctx):
+    """BASELINE.json configs[4] at its own 8192^2 (900 samples, K = 100, six weights), where no CPU oracle fits: the table
+    form the default path takes against NLE_MODE_STREAMED_F64 -- an independent formulation (fp64 libm-exp affinity rows
+    regenerated chunk by chunk, a materialised fp64 V, no look-up tables, no level-sorted rows, no index-sum Gram) that is
+    itself held to the oracle at small sizes (tests/test_gpu_parity.py runs every case under it) and shares only the p-sized
+    solvers with the table form.  Asserted: the same three rank cuts (src/filter.cpp:214 at :262, :287, :313), eigenvalues
+    to 1e-8, every layer to 1e-5 on 16 384 probe pixels (incl. sample pixels) and on the layer norms.  Together with
+    tests/test_full_size_golden.py::cfg5_2k (the same grid / K / L against the ORACLE at 2048^2) this is cfg5's
+    correctness evidence; the properties below it hold for any orthonormal V."""
+    import torch
+    import __graft_entry__ as entry
+    synth = entry._load("nle_amd_synthetic", os.path.join(entry.PKG_DIR, "synthetic.py"))
+    cfg = synth.CONFIGS["cfg5"]
+    H, W, L = cfg["H"], cfg["W"], cfg["L"]
+    lum = torch.as_tensor(synth.synthetic_luminance(H, W).astype(np.float32), device="cuda:0")
+    rng = np.random.default_rng(5)
+    g = nle.sample_grid(H, W, cfg["n_row"], cfg["n_col"])
+    sel = [(g["row_off"] + i * g["row_step"]) * W + g["col_off"] + j * g["col_step"]
+           for i in range(0, g["n_sel_rows"], 5) for j in range(0, g["n_sel_cols"], 5)]
+    probe = torch.as_tensor(np.unique(np.concatenate([rng.choice(H * W, 16384, replace=False), np.array(sel)])), device="cuda:0")
+
+    def run(mode):
+        f = _train(nle, ctx, cfg, lum, mode)
+        d, ev = f.diag(), f.eigvals.copy()
+        Y = f.apply_layers(lum, L)
+        yp = Y[:, probe].double().cpu().numpy()
+        norms = torch.linalg.norm(Y.double(), dim=1).cpu().numpy()
+        del Y
+        f.close()
+        ctx.trim()
+        return d, ev, yp, norms
+
+    d_t, ev_t, y_t, n_t = run(0)
+    assert d_t["formulation"] == nle.MODE_PHI_FREE                       # auto mode took the tables
+    d_s, ev_s, y_s, n_s = run(5)
+    assert d_s["formulation"] == 5
+    print("cfg5 ranks kept Ka/Wa/Q, K':", [d_t[k] for k in ("r_Ka", "r_Wa", "r_Q", "K")], "streamed:",
+          [d_s[k] for k in ("r_Ka", "r_Wa", "r_Q", "K")], "max |d lambda|", np.abs(ev_t - ev_s).max())
+    assert [d_t[k] for k in ("p", "r_Wa", "r_Q", "K")] == [d_s[k] for k in ("p", "r_Wa", "r_Q", "K")]
+    assert 0 < d_t["p"] - d_t["r_Wa"] <= d_t["p"] // 8                   # the cut on W_A bites: the deflated root ran
+    assert np.abs(ev_t - ev_s).max() <= 1e-8
+    errs = [rel_l2(y_t[j], y_s[j]) for j in range(L)]
+    print("cfg5 per-layer relative L2, tables vs streamed fp64, on", y_t.shape[1], "probes:", ["%.2e" % e for e in errs])
+    assert max(errs) <= 1e-5, errs
+    assert np.abs(n_t - n_s).max() <= 1e-5 * n_s.max() and np.all(np.abs(n_t - n_s) <= 1e-4 * n_s)
+
+
 def test_non_integer_luminance_takes_the_generic_path(nle, oracle, ctx):
     """auto mode must not use the 0..255 look-up tables when the plane is not integer valued"""
     H, W, nr, nc, hx, hy, T, K, L = 96, 128, 6, 8, 32.0, 30.0, 10, 10, 4

@@ -1,10 +1,14 @@
 """Full-size parity against the ORACLE (not against another HIP formulation): BASELINE.json configs[2] (cfg3, 2048^2,
-400 samples, T = 50) and configs[3] (cfg4, the headline 4096^2 config).  tests/golden/fullsize_<cfg>.npz holds what the
+400 samples, T = 50), configs[3] (cfg4, the headline 4096^2 config) and configs[4]'s SHAPE (cfg5_2k: the 30 x 30 grid,
+hx = W / 8, K = 100, six weights of cfg5 on a 2048^2 plane -- the largest size whose N x 900 fp64 matrix the 62 GB build
+container holds; 104 of W_A's 900 eigenvalues fall below the 1e-10 cut there, as 100 do at 8192^2, so the deflated root,
+the block inverse iteration and the wide sorted kernels of that config run on it).  tests/golden/fullsize_<cfg>.npz holds what the
 streaming fp64 oracle (oracle/nle_oracle.py: train_filter_streaming, one run per config in the build container,
 tests/golden/make_fullsize_golden.py) computed at the config's own size: all eigenvalues, the ranks kept by the 1e-10 cuts
 of src/filter.cpp:214, every layer's norm, 4096 probe pixels and a 64 x 64 block of every layer, |V^T x|.  The bar is
 north_star's: 1e-4 relative L2 per layer (asserted on the probes, the block and the norms), eigenvalues to 1e-8.
-cfg5 stays property-only (tests/test_full_size.py): its Phi is 483 GB of fp64, beyond any host here."""
+cfg5 at its own 8192^2 is beyond any host here (Phi is 483 GB of fp64): there tests/test_full_size.py holds the table
+form to the independent streamed-fp64 formulation and to the filter's properties."""
 import json
 import os
 
@@ -56,16 +60,26 @@ def _run(nle, ctx, name):
     ctx.trim()
 
 
-@pytest.mark.parametrize("name", ["cfg3", "cfg4"])
+@pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5_2k"])
 def test_full_size_layers_match_the_oracle(nle, ctx, name):
     _run(nle, ctx, name)
 
 
-def test_cfg3_host_solvers_give_the_oracle_s_layers_too(nle, ctx):
+@pytest.mark.parametrize("name", ["cfg3", "cfg5_2k"])
+def test_host_solvers_give_the_oracle_s_layers_too(nle, ctx, name):
     """the same with the p x p eigen-computations on the host (NLE_HOST_SOLVER=1; the default takes the device solvers of
     dense64.hip from 288 samples on)"""
     os.environ["NLE_HOST_SOLVER"] = "1"
     try:
-        _run(nle, ctx, "cfg3")
+        _run(nle, ctx, name)
     finally:
         del os.environ["NLE_HOST_SOLVER"]
+
+
+def test_cfg5_shape_takes_the_deflated_root(nle, ctx):
+    """what makes cfg5_2k a pin of cfg5's code path: the cut on W_A drops between 1 and q / 8 eigenvalues (so the root is the
+    deflated Cholesky factor with the dropped eigenvectors from block inverse iteration, not a plain Cholesky and not a full
+    eigen-decomposition), on the 30-column wide sorted kernels"""
+    meta = json.load(open(os.path.join(GOLDEN, "fullsize_cfg5_2k.json")))
+    n, kept = meta["cuts"][0]["n"], meta["cuts"][0]["kept"]
+    assert n == 900 and 0 < n - kept <= n // 8

@@ -367,6 +367,25 @@ def test_host_buffer_entry_points_match_the_device_ones(nle, oracle, ctx, pinned
     # a filter trained from a device pointer keeps no plane: NULL is refused, loudly
     with pytest.raises(nle.NLEError):
         f_dev.apply_layers_host(None, L, h_y)
+    # the one-plane return `enhance` needs (src/filter.cpp:428-436): weighted sum, clamp, convertTo(CV_8U) on the device,
+    # n bytes home -- equal to doing the clamp and round-half-even on the fp32 weighted sum, bit for bit, device and host forms
+    w = [2.0, 3.0, 3.0, 4.0, 1.0]
+    fs = nle.transform_eigenvalues(f.eigvals, w)
+    y = f_dev.apply(x, fs).cpu().numpy()
+    want = np.rint(np.clip(y, 0, 255)).astype(np.uint8)
+    assert 0 in want and 255 in want                      # the weights push parts of the plane out of range: the clamp is exercised
+    assert np.array_equal(f_dev.apply_u8(x, fs).cpu().numpy(), want)
+    h_o = ctx.host_alloc((H * W,), dtype=np.uint8) if pinned else np.empty(H * W, dtype=np.uint8)
+    h_o[...] = 7
+    f.apply_u8_host(None, fs, h_o)
+    assert np.array_equal(h_o, want)
+    h_o[...] = 7
+    f.apply_u8_host(h_x, fs, h_o)
+    assert np.array_equal(h_o, want)
+    with pytest.raises(nle.NLEError):
+        f_dev.apply_u8_host(None, fs, h_o)
+    with pytest.raises(nle.NLEError):
+        f.apply_u8_host(None, fs, np.empty(H * W - 1, dtype=np.uint8))
     f.close()
     f_dev.close()
 

@@ -72,6 +72,8 @@ def test_hot_path_matches_oracle_on_readme_pair(nle, oracle, ctx, name):
     diff = np.abs(L_out - o["L_out"].astype(np.int64))
     print(f"{name}: 8-bit plane vs oracle: {int((diff > 0).sum())} of {diff.size} pixels differ, max {int(diff.max())}")
     assert diff.max() <= 1 and (diff > 0).mean() < 2e-3        # rounding ties of .5 values only
+    # nle_apply_u8: the same plane clamped and rounded on the device (what `enhance` brings home)
+    assert np.array_equal(f.apply_u8(x, nle.transform_eigenvalues(ev, wts)).cpu().numpy().reshape(L.shape).astype(np.int64), L_out)
     f.close()
 
 
