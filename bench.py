@@ -56,7 +56,7 @@ def gram_on_index_sums(grid, W, hx):
     return 2.0 * W * W / (hx * hx) < 600.0 and (2.0 * cs * W + 2.0 * nC * cs * cs) / (hx * hx) < 600.0
 
 
-def roofline_models(info, L, form, grid, lazy=False, gsum=False):
+def roofline_models(info, L, form, grid, lazy=False, gsum=False, level_tiles=16):
     """kernel name -> (bound, algorithmic units per launch, peak) for this rank (n = pixels of its slab).
 
     Per-unit figures are SURVEY.md section 8(d)'s (fp32 storage, s = 4 B) where the kernel still does the
@@ -88,7 +88,9 @@ def roofline_models(info, L, form, grid, lazy=False, gsum=False):
             m["sinkhorn_pass"] = ("valu", n * p * (8.0 + 1.0 + 4.0), FP32_PEAK_TF)
             m["gram"] = ("mfma", 2.0 * n * p * p, FP64_MFMA_PEAK_TF)     # F_D with r -> p
         else:
-            tab = rows * 256.0 * nC * 8.0                                # one 256 x nC fp64 table per image row
+            # one (16 level_tiles) x nC fp64 table per image row: the columns of 16-level tiles that do not occur in the
+            # plane are neither made, stored nor contracted (nle_filter_level_tiles; 12 of 16 on the synthetic plane)
+            tab = rows * 16.0 * level_tiles * nC * 8.0
             npair = nC * (nC + 1) / 2.0
             ldm = ((nR * (nR + 1) // 2) + 15) // 16 * 16
             m["sink_tables"] = ("hbm", tab, HBM_PEAK_GBS)                # g written
@@ -100,7 +102,7 @@ def roofline_models(info, L, form, grid, lazy=False, gsum=False):
                 ntab, ldm = 2.0 * nC - 1.0, ((2 * nR - 1) + 15) // 16 * 16
             else:
                 ntab = npair
-            m["gram_rows"] = ("hbm", srt + n * 8.0 + rows * 256.0 * ntab * 8.0, HBM_PEAK_GBS)
+            m["gram_rows"] = ("hbm", srt + n * 8.0 + rows * 16.0 * level_tiles * ntab * 8.0, HBM_PEAK_GBS)
             m["gram_gemm"] = ("mfma", 2.0 * ldm * 256.0 * ntab * rows, FP64_MFMA_PEAK_TF)
             if lazy:  # V stays implicit: apply runs on the tables too (bytes the two kernels really move)
                 m["apply_reduce"] = ("hbm", srt + n * (8.0 + s) + tab, HBM_PEAK_GBS)      # sorted row, c, x in; h out
@@ -112,17 +114,18 @@ def roofline_models(info, L, form, grid, lazy=False, gsum=False):
 
 
 def load_traffic():
-    """HBM bytes per launch from the committed PMC summary (tools/prof.sh + tools/pmc_summary.py):
-    {kernel-name substring: bytes}; rocprofv3 cannot run inside bench.py."""
+    """HBM bytes per launch from the COMMITTED PMC summary (tools/prof.sh + tools/pmc_summary.py):
+    ({kernel-name substring: bytes}, file name); rocprofv3 cannot run inside bench.py, so `traffic` is a record of an
+    earlier run of the same command, not a measurement of this one -- the line says so (`traffic_source`)."""
     import csv
     import glob
     out = {}
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_final_hbm_traffic.csv")))   # the newest round's final run
     if not files:
-        return out
+        return out, None
     for row in csv.DictReader(open(files[-1])):
         out[row["kernel"]] = float(row["hbm_bytes_per_launch"])
-    return out
+    return out, os.path.relpath(files[-1], ROOT)
 
 
 def kernel_symbols(form, lazy):
@@ -156,13 +159,14 @@ def main():
                          "torch.distributed); 'torch' = torch.distributed.all_reduce through the callback ABI")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the replica-throughput leg")
     ap.add_argument("--no-pipelined", action="store_true", help="N = 1: skip the images-in-flight throughput leg")
+    ap.add_argument("--no-affinity", action="store_true", help="N = 1: skip the stand-alone affinity-pass roofline legs")
     ap.add_argument("--full-plane-input", action="store_true",
                     help="N > 1: every rank holds the whole plane (default: slab input, a rank holds and uploads its rows only)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--simulate-world", type=int, default=0,
-                    help="timing only, one GPU: run rank 0 of a W-way row shard with a no-op all-reduce (results are "
-                         "meaningless, the per-rank compute time at 1/W of the rows is not)")
+                    help="timing only, one GPU: run rank 0 of a W-way row shard whose 'all-reduce' scales the rank's partial sums "
+                         "by W (results are meaningless, the per-rank compute time at 1/W of the rows is not)")
     ap.add_argument("--inflight", type=int, default=1, help="images in flight on one GPU (throughput mode, opt-in)")
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 materialised Phi, 2 Phi-free (NLE_MODE_*)")
     ap.add_argument("--h2h-runs", type=int, default=7, help="host-to-host (section 8d) runs after 2 warm-ups; 0 skips")
@@ -466,10 +470,11 @@ def main():
                   5: "streamed_f64 (no N x r matrix: fp64 affinity rows regenerated chunk by chunk)"}.get(flt.diag()["formulation"], form)
     lazy = form == "phi_free_tables" and "project" not in ran
     gsum = form == "phi_free_tables" and gram_on_index_sums(g, W, cfg["hx"])
-    models = roofline_models(info, L, form, g, lazy, gsum)
+    lev_t0, lev_nt = flt.level_tiles()
+    models = roofline_models(info, L, form, g, lazy, gsum, lev_nt)
     # (the committed PMC summary was collected at N = 1 on the default config: per-launch bytes of a row slab or of
     # another config differ, so `traffic` is only attached to that case)
-    traffic = load_traffic() if (world == 1 and args.config == "cfg4" and args.simulate_world <= 1) else {}
+    traffic, traffic_file = load_traffic() if (world == 1 and args.config == "cfg4" and args.simulate_world <= 1) else ({}, None)
     per_kernel = {}
     for name, (launches, total_ms) in stats.items():
         if launches == 0:
@@ -505,9 +510,40 @@ def main():
     d = per_kernel[dom]
     roofline = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
                 "frac": d["frac"], "traffic": d.get("traffic"), "avg_launch_ms": d["avg_ms"],
-                "launches_per_step": d["launches_per_step"]}
+                "launches_per_step": d["launches_per_step"],
+                "algorithmic_bytes_per_launch" if d["bound"] == "hbm" else "algorithmic_flops_per_launch": models[dom][1],
+                "traffic_source": (f"{traffic_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an earlier "
+                                   "box, committed; NOT measured inside this run") if d.get("traffic") else None,
+                "level_tiles": {"first": lev_t0, "count": lev_nt, "of": 16}}
     if "valu_f64" in d:
         roofline["valu_f64"] = d["valu_f64"]
+
+    # ---- the materialising affinity pass (north_star: ">= 40 % HBM-bandwidth roofline on the affinity pass"): the default
+    # path never writes K_AB, so the kernels of the stage-level API / the literal formulations are timed here by
+    # themselves, HIP events on the ctx's stream, in the same run.  k_affinity: fp32 rows, B_A = N s (1 + p) (SURVEY.md
+    # section 8d); k_affinity64: the fp64 rows of NLE_MODE_STREAMED_F64 (libm exp), one 2 GB chunk as that mode makes them
+    affinity_pass = None
+    if world == 1 and args.simulate_world <= 1 and not args.no_affinity:
+        affinity_pass = {}
+        ldp = nle.ld(p)
+        free_b, _ = torch.cuda.mem_get_info()
+        if H * W * ldp * 4.0 < 0.5 * free_b:
+            ms_a, kab = ctx.bench_affinity(lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], reps=10)
+            del kab
+            b_a = H * W * 4.0 * (1 + p)
+            affinity_pass["k_affinity"] = {"bound": "hbm", "avg_ms": ms_a, "launches": 10, "algorithmic_bytes_per_launch": b_a,
+                                           "achieved": b_a / (ms_a * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": b_a / (ms_a * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "what": f"computeKernel's K_AB materialised in fp32: {H}x{W} pixels x {p} samples, read 4 B + write 4 p B per pixel"}
+        rows64 = max(1, min(H, int((2048 << 20) // (W * ldp * 8))))
+        ms_b, bytes_b = ctx.bench_affinity64(lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], rows64, reps=10)
+        b_b = rows64 * W * (4.0 + 8.0 * p)
+        affinity_pass["k_affinity64"] = {"bound": "hbm", "avg_ms": ms_b, "launches": 10, "algorithmic_bytes_per_launch": b_b,
+                                         "achieved": b_b / (ms_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": b_b / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         "what": f"fp64 affinity rows (libm exp) of {rows64} image rows x {p} samples = one chunk of the streamed "
+                                                 "fp64 formulation: read 4 B + write 8 p B per pixel"}
+        ctx.trim()
 
     # ---- CPU baseline (rank 0, N = 1 only): oracle/nle_cpu_baseline.cpp, the C++17 + OpenMP streaming restatement of the
     # hot path (pinned against the numpy oracle by tests/test_cpu_baseline.py), on this box's host cores -- at the
@@ -571,7 +607,7 @@ def main():
                                    f"(p={p}), K={cfg['K']}, T={cfg['T']}, L={L} layers; device-resident: the luminance plane is in HBM when the "
                                    f"timed region starts and the {L} layer planes are left in HBM (no PCIe inside `value`)",
                        "parallelism": (f"row-slab x{world}" if world > 1 else
-                                       f"TIMING ONLY: rank 0 of a simulated {args.simulate_world}-way row shard, no-op all-reduce"
+                                       f"TIMING ONLY: rank 0 of a simulated {args.simulate_world}-way row shard, partial sums scaled by {args.simulate_world} in place of the all-reduce"
                                        if args.simulate_world > 1 else "single GPU")
                        + (f", {args.inflight} images in flight" if args.inflight > 1 else ""),
                        "formulation": form_label + (" (V implicit, apply in sample space)" if lazy else ""),
@@ -588,6 +624,7 @@ def main():
             "shard_check": shard_check,
             "soak": soak,
             "roofline": roofline,
+            "affinity_pass": affinity_pass,
             "cpu_baseline": cpu,
             "kernels": per_kernel,
             "stage_ms_last_step": stage_ms,

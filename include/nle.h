@@ -366,6 +366,14 @@ int nle_ctx_kernel_stats(nle_ctx* ctx, int kid, long long* launches, double* tot
 int nle_bench_affinity(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples,
                        int n_col_samples, double hx, double hy, float* d_kab, int reps,
                        double* h_avg_ms);
+/* the same for the fp64 affinity rows of NLE_MODE_STREAMED_F64 / nle_compute_kernel64 (libm exp, 8 bytes per entry) on the
+ * first `rows` image rows of this rank's slab: d_kab holds rows * W * nle_ld(p) doubles */
+int nle_bench_affinity64(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples, int n_col_samples, double hx,
+                         double hy, long long rows, double* d_kab, int reps, double* h_avg_ms);
+/* the range of 16-level tiles [first, first + n) that occur in the plane the filter was trained on: the columns of the
+ * look-up-table formulation's g / h tables that its kernels make, store and contract (the others are skipped); (0, 16)
+ * for a filter that does not run on level-sorted rows.  For byte models of those kernels. */
+int nle_filter_level_tiles(const nle_filter* f, int* first_tile, int* n_tiles);
 /* same for one Sinkhorn half-iteration pass over a device-resident phi */
 int nle_bench_sinkhorn_pass(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r,
                             int reps, double* h_avg_ms);

@@ -518,6 +518,20 @@ class Context:
                                         float(hx), float(hy), C.c_void_p(kab.data_ptr()), reps, C.byref(ms)), self._h)
         return ms.value, kab
 
+    def bench_affinity64(self, lum, n_row_samples, n_col_samples, hx, hy, rows, reps=10):
+        """average launch time (ms) of the fp64 affinity kernel on the first `rows` image rows; returns (ms, bytes written)"""
+        torch = _torch()
+        lum = self._lum(lum)
+        H, W = lum.shape
+        g = sample_grid(H, W, n_row_samples, n_col_samples)
+        p = g["n_sel_rows"] * g["n_sel_cols"]
+        rows = int(min(rows, H))
+        kab = torch.empty((rows * W, ld(p)), dtype=torch.float64, device=lum.device)
+        ms = C.c_double()
+        _check(lib().nle_bench_affinity64(self._h, C.c_void_p(lum.data_ptr()), H, W, n_row_samples, n_col_samples,
+                                          float(hx), float(hy), rows, C.c_void_p(kab.data_ptr()), reps, C.byref(ms)), self._h)
+        return ms.value, kab.numel() * 8
+
     def bench_sinkhorn_pass(self, phi, r, reps=10):
         self._sync_in()
         ms = C.c_double()
@@ -603,6 +617,12 @@ class NLEFilter:
                                             f"{int(n_layers)} x {n_local} values")
         _check(lib().nle_apply_layers_host(self._f, xp, H, W, int(n_layers), _np_ptr(out)), self.ctx._h)
         return out
+
+    def level_tiles(self):
+        """(first, count) of the 16-level tiles the table kernels of this filter work on (nle_filter_level_tiles)"""
+        a, b = C.c_int(), C.c_int()
+        _check(lib().nle_filter_level_tiles(self._f, C.byref(a), C.byref(b)), self.ctx._h)
+        return a.value, b.value
 
     def apply_u8_host(self, x, f_s, out):
         """nle_apply_u8_host: the 8-bit L plane `enhance` merges back (src/filter.cpp:428-436) -- apply, clamp to

@@ -31,34 +31,66 @@ __device__ __forceinline__ double recip0_g(double s, double eps) {
 // kab[i][s] = exp(-sw (dr^2 + dc^2) - pw (x_i - y_s)^2), natural pixel order, i in [pix0, pix0 + M); columns >= p zero
 // (skip_samples != 0: the rows of the sample pixels themselves come out as zeros -- the sample-space algebra sums over
 // the non-sample pixels only and treats the samples exactly on its p-sized side)
+// A workgroup covers 64 consecutive pixels at a time (one contiguous 64 * ld * 8-byte span), a thread one double2 of one
+// pixel's row: 16-byte coalesced stores, 32-bit index arithmetic, the samples (row, col, value as doubles) in LDS.
+constexpr int kAff64Pix = 64;
+
 __global__ __launch_bounds__(256) void k_affinity64(const float* __restrict__ lum, GridSpec gs,
                                                     const Sample4* __restrict__ samples, int p, int ld, double sw,
                                                     double pw, long long pix0, long long M, double* __restrict__ kab,
                                                     int skip_samples) {
-    const long long total = M * ld;
-    for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (long long)gridDim.x * blockDim.x) {
-        const long long il = f / ld;
-        const int s = (int)(f - il * ld);
-        double v = 0.0;
-        if (s < p) {
-            const long long gi = pix0 + il;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw64[];
+    int2* srow_col = reinterpret_cast<int2*>(smem_raw64);                       // [ld]
+    double* sval = reinterpret_cast<double*>(smem_raw64 + (size_t)ld * sizeof(int2));  // [ld]
+    for (int k = threadIdx.x; k < ld; k += 256) {
+        Sample4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < p) v = samples[k];
+        srow_col[k] = make_int2((int)v.x, (int)v.y);
+        sval[k] = (double)v.z;
+    }
+    __syncthreads();
+    const unsigned nq = (unsigned)ld >> 1, per_group = kAff64Pix * nq;
+    const long long ngroups = (M + kAff64Pix - 1) / kAff64Pix;
+    for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const long long i0 = grp * kAff64Pix;
+        double* __restrict__ out = kab + i0 * ld;
+        const unsigned nvalid = (unsigned)min((long long)kAff64Pix, M - i0) * nq;
+        for (unsigned f = threadIdx.x; f < per_group; f += 256) {
+            if (f >= nvalid) break;
+            const unsigned il = f / nq, q = f - il * nq;
+            const long long gi = pix0 + i0 + il;
             const int row = (int)(gi / gs.W), col = (int)(gi - (long long)row * gs.W);
-            const Sample4 sm = samples[s];
-            const long long dr = row - (int)sm.x, dc = col - (int)sm.y;  // integer spatial term (:109)
-            const double dv = (double)lum[gi] - (double)sm.z;
-            v = exp(-sw * (double)(dr * dr + dc * dc) - pw * (dv * dv));
-            if (skip_samples && is_sample_pixel(gs, row, col)) v = 0.0;
+            const double x = (double)lum[gi];
+            const bool zero_row = skip_samples && is_sample_pixel(gs, row, col);
+            double2 o = make_double2(0.0, 0.0);
+            const unsigned s0 = 2 * q;
+            if (!zero_row) {
+                if (s0 < (unsigned)p) {
+                    const int2 rc = srow_col[s0];
+                    const long long dr = row - rc.x, dc = col - rc.y;  // integer spatial term (:109)
+                    const double dv = x - sval[s0];
+                    o.x = exp(-sw * (double)(dr * dr + dc * dc) - pw * (dv * dv));
+                }
+                if (s0 + 1 < (unsigned)p) {
+                    const int2 rc = srow_col[s0 + 1];
+                    const long long dr = row - rc.x, dc = col - rc.y;
+                    const double dv = x - sval[s0 + 1];
+                    o.y = exp(-sw * (double)(dr * dr + dc * dc) - pw * (dv * dv));
+                }
+            }
+            *reinterpret_cast<double2*>(out + (size_t)f * 2) = o;
         }
-        kab[f] = v;
     }
 }
 
 hipError_t affinity64(hipStream_t s, const float* d_lum, GridSpec gs, const Sample4* d_samples, int p, int ld, double sw,
                       double pw, long long pix0, long long M, double* d_kab, bool skip_samples) {
     if (M <= 0) return hipSuccess;
-    const long long nb = std::min<long long>((M * ld + 255) / 256, 16384);
-    hipLaunchKernelGGL(k_affinity64, dim3((unsigned)nb), dim3(256), 0, s, d_lum, gs, d_samples, p, ld, sw, pw, pix0, M, d_kab,
-                       skip_samples ? 1 : 0);
+    if (ld & 1) return hipErrorInvalidValue;   // rows are written two doubles at a time (ld = nle_ld(p) is a multiple of 4)
+    const long long ngroups = (M + kAff64Pix - 1) / kAff64Pix;
+    const int grid = (int)std::min<long long>(ngroups, 16384);
+    hipLaunchKernelGGL(k_affinity64, dim3((unsigned)grid), dim3(256), (size_t)ld * (sizeof(int2) + sizeof(double)), s, d_lum, gs,
+                       d_samples, p, ld, sw, pw, pix0, M, d_kab, skip_samples ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -1701,6 +1701,38 @@ int nle_bench_affinity(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row
     });
 }
 
+int nle_bench_affinity64(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples, int n_col_samples, double hx,
+                         double hy, long long rows, double* d_kab, int reps, double* h_avg_ms) {
+    if (!ctx || !d_lum || !d_kab || reps < 1 || !h_avg_ms || rows < 1) return NLE_ERR_INVALID;
+    return guard(ctx, [&] {
+        check_image_size(H, W);
+        GridSpec gs;
+        if (!make_grid(H, W, n_row_samples, n_col_samples, &gs)) throw Fail{NLE_ERR_INVALID, "invalid sample counts"};
+        HIP_OK(hipSetDevice(ctx->device));
+        SampleSet ss = fetch_samples(ctx, d_lum, gs);
+        int row0, row1;
+        slab(H, ctx->rank, ctx->world, &row0, &row1);
+        DevBuf<float4> d_samples(ss.p);
+        HIP_OK(hipMemcpyAsync(d_samples.p, ss.packed.data(), ss.p * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        const long long pix0 = (long long)row0 * W, M = std::min<long long>(rows, row1 - row0) * W;
+        const double sw = 1.0 / (hx * hx), pw = 1.0 / (hy * hy);
+        HIP_OK(nlek::affinity64(ctx->stream, d_lum, gs, d_samples.p, ss.p, ld4(ss.p), sw, pw, pix0, M, d_kab, true));
+        Timer tm(ctx->stream);
+        tm.start();
+        for (int i = 0; i < reps; ++i)
+            HIP_OK(nlek::affinity64(ctx->stream, d_lum, gs, d_samples.p, ss.p, ld4(ss.p), sw, pw, pix0, M, d_kab, true));
+        tm.stop();
+        *h_avg_ms = tm.ms() / reps;
+    });
+}
+
+int nle_filter_level_tiles(const nle_filter* f, int* first_tile, int* n_tiles) {
+    if (!f || !first_tile || !n_tiles) return NLE_ERR_INVALID;
+    *first_tile = f->has_sorted ? f->sorted.lev_t0 : 0;
+    *n_tiles = f->has_sorted ? f->sorted.lev_nt : 16;
+    return NLE_OK;
+}
+
 int nle_bench_sinkhorn_pass(nle_ctx* ctx, const float* d_phi, long long M, int ld, int r, int reps, double* h_avg_ms) {
     if (!ctx || !d_phi || reps < 1 || !h_avg_ms || M < 1 || r < 1 || ld < r || (ld & 3)) return NLE_ERR_INVALID;
     return guard(ctx, [&] {
