@@ -346,6 +346,7 @@ int nle_ctx_init_rccl(nle_ctx* ctx, int rank, int world, const void* h_id, size_
 int nle_ctx_abort_rccl(nle_ctx* ctx) {
     if (!ctx) return NLE_ERR_INVALID;
     // no guard(): this may run on another thread than the one that uses the ctx (whose error string it must not touch)
+    std::lock_guard<std::mutex> lk(ctx->comm_mu);  // not while the ctx's own thread is inside an enqueue on this communicator
     if (!ctx->comm || !ctx->own_comm) return NLE_OK;
     if (ctx->comm_aborted.exchange(1, std::memory_order_acq_rel) != 0) return NLE_OK;
     try {

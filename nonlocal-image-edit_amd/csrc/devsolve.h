@@ -10,10 +10,11 @@ namespace nlep {
 int dev_solver_min_n();
 bool use_dev_solver(int n);
 
-// holds `n` compute units of the process-wide budget for persistent launches while alive
+// holds `n` compute units of the DEVICE's budget for persistent launches while alive
+int device_cu_count(int device);
 struct CuLease {
-    int n;
-    explicit CuLease(int n);
+    int dev, n;
+    CuLease(int device, int n);
     ~CuLease();
     CuLease(const CuLease&) = delete;
     CuLease& operator=(const CuLease&) = delete;
@@ -30,8 +31,10 @@ struct DevSymEig {
     // workspace for order n; everything below runs on `stream` (null: the ctx stream).  Called by reduce() if need be;
     // call it earlier when the workspace has to be taken from the ctx cache at a particular moment (a second stream)
     void prepare(nle_ctx* c, int n, hipStream_t stream = nullptr);
-    // reduction + eigenvalues; synchronises the stream and fills d, e, D
-    void reduce(nle_ctx* c, int n, const double* d_M, const double* d_diag_add);
+    // reduction + eigenvalues; synchronises the stream and fills d, e, D.  false: the device cannot run the persistent
+    // reduction (fewer compute units than workgroups), a hand-off timed out, or an eigenvalue is not finite -- the caller
+    // falls back to the host solver (and, with more than one rank, agrees on that with its peers first)
+    bool reduce(nle_ctx* c, int n, const double* d_M, const double* d_diag_add);
     // eigenvectors of D[first .. first + count) into d_Z (n x count column-major, device), enqueued on the stream
     // (hZ is the upload's staging buffer: it must outlive the copy, i.e. this object must)
     void vectors(nle_ctx* c, int first, int count, double* d_Z);

@@ -13,23 +13,38 @@
 namespace nlep {
 
 namespace {
-// Workgroups of persistent launches must all be resident at once: at most kCuBudget of them are in flight per process
-// (each needs a compute unit of its own; ctxs on other host threads wait here, not on the GPU)
-constexpr int kCuBudget = 224;
+// Workgroups of persistent launches must all be resident at once: at most (compute units of the device - 32) of them are
+// in flight per DEVICE (each needs a compute unit of its own; ctxs on other host threads wait here, not on the GPU)
+constexpr int kMaxDevices = 64;
 std::mutex g_cu_mu;
 std::condition_variable g_cu_cv;
-int g_cu_used = 0;
+int g_cu_used[kMaxDevices] = {};
 }  // namespace
 
-CuLease::CuLease(int n_) : n(std::min(n_, kCuBudget)) {
+int device_cu_count(int device) {
+    static std::mutex mu;
+    static int cache[kMaxDevices] = {};
+    const int slot = device >= 0 && device < kMaxDevices ? device : 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (cache[slot] == 0) {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 1;
+        cache[slot] = ncu;
+    }
+    return cache[slot];
+}
+
+CuLease::CuLease(int device, int n_) : dev(device >= 0 && device < kMaxDevices ? device : 0) {
+    const int budget = std::max(16, device_cu_count(device) - 32);
+    n = std::min(n_, budget);
     std::unique_lock<std::mutex> lk(g_cu_mu);
-    g_cu_cv.wait(lk, [&] { return g_cu_used + n <= kCuBudget; });
-    g_cu_used += n;
+    g_cu_cv.wait(lk, [&] { return g_cu_used[dev] + n <= budget; });
+    g_cu_used[dev] += n;
 }
 CuLease::~CuLease() {
     {
         std::lock_guard<std::mutex> lk(g_cu_mu);
-        g_cu_used -= n;
+        g_cu_used[dev] -= n;
     }
     g_cu_cv.notify_all();
 }
@@ -63,16 +78,19 @@ void DevSymEig::prepare(nle_ctx* c, int n_, hipStream_t stream) {
     status.alloc(1);
 }
 
-void DevSymEig::reduce(nle_ctx* c, int n_, const double* d_M, const double* d_diag_add) {
+bool DevSymEig::reduce(nle_ctx* c, int n_, const double* d_M, const double* d_diag_add) {
     if (!pub.p || n != n_) prepare(c, n_, st);
     int G = nlek::sytrd_groups(n);
     if (const char* e = std::getenv("NLE_SYTRD_G")) G = std::atoi(e);
+    // every workgroup of the persistent launch needs a compute unit of its own for the whole launch: a device that exposes
+    // fewer (a partitioned or smaller part) cannot run it -- the caller takes the host solver
+    if (G <= 0 || G + 16 > device_cu_count(c->device)) return false;
     d.assign(n, 0.0);
     e.assign(n, 0.0);
     D.assign(n, 0.0);
     int h_status = 0;
     {
-        CuLease lease(G);
+        CuLease lease(c->device, G);
         HIP_OK(nlek::sytrd_dist(st, n, G, d_M, d_diag_add, pub.p, tde.p, tde.p + n, status.p));
         HIP_OK(nlek::tridiag_bisect(st, n, tde.p, tde.p + n, tde.p + 2 * n));
         std::vector<double> hv;
@@ -88,9 +106,15 @@ void DevSymEig::reduce(nle_ctx* c, int n_, const double* d_M, const double* d_di
         std::copy(h + n, h + 2 * n, e.begin());
         std::copy(h + 2 * n, h + 3 * n, D.begin());
     }
-    if (h_status != 0) throw Fail{NLE_ERR_NUMERIC, "device eigensolver: a hand-off between workgroups timed out"};
+    // a hand-off between workgroups timed out (the workgroups were not co-resident after all), or the matrix was not
+    // finite: not an error of the train -- the host solver (nleh::eigen_decomposition*) takes over
+    if (h_status != 0) {
+        if (std::getenv("NLE_TRACE")) std::fprintf(stderr, "[nle trace] device eigensolver (n = %d): hand-off timed out, host solver takes over\n", n);
+        return false;
+    }
     for (int i = 0; i < n; ++i)
-        if (!std::isfinite(D[i])) throw Fail{NLE_ERR_NUMERIC, "device eigensolver: non-finite eigenvalue"};
+        if (!std::isfinite(D[i])) return false;
+    return true;
 }
 
 void DevSymEig::vectors(nle_ctx* c, int first, int count, double* d_Z) {
@@ -155,7 +179,9 @@ int nle_sym_eigen_device(nle_ctx* ctx, const double* h_M, int n, double eps, int
         DevBuf<double> d_M(nn), d_Z((size_t)n * std::max(count, 1));
         HIP_OK(hipMemcpyAsync(d_M.p, h_M, nn * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         DevSymEig es;
-        es.reduce(ctx, n, d_M.p, nullptr);
+        if (!es.reduce(ctx, n, d_M.p, nullptr))
+            throw Fail{NLE_ERR_NUMERIC, "device eigensolver: not enough compute units for the persistent reduction, a hand-off "
+                                        "between its workgroups timed out, or a non-finite matrix"};
         std::copy(es.D.begin(), es.D.end(), h_D);
         int k = 0;
         while (k < n && es.D[k] >= eps) ++k;  // src/filter.cpp:213-216

@@ -1367,7 +1367,7 @@ hipError_t sink_hist_tiled(hipStream_t s, int mode, const float* d_lum, GridSpec
     if (sorted != nullptr) {
         Scope sc(obs, SUB_HIST_PIX);
         hipError_t ep = sorted_pass(s, mode, gs, row0, nrows_local, sorted->scol, sorted->desc, sorted->first, sorted->E, d_g,
-                                    eps, d_ybuf, d_h, d_cvec, d_xvec, sorted->rec, sorted->kappa, lev_t0, lev_nt);
+                                    eps, d_ybuf, d_h, d_cvec, d_xvec, sorted->rec, sorted->kappa, lev_t0, lev_nt, sorted->mom);
         if (ep != hipSuccess) return ep;
     } else {
         Scope sc(obs, SUB_HIST_PIX);

@@ -210,6 +210,7 @@ struct SortedRows {
     const double* E2 = nullptr;   // [W + 1] exp(-2 d^2 / hx^2): set (with hx) where the Gram runs on index sums (sorted_gsum_ok)
     double hx = 0.0;
     int lev_t0 = 0, lev_nt = 16;  // the 16-level tiles [lev_t0, lev_t0 + lev_nt) that occur in the image (check_levels)
+    bool mom = false;             // the pass kernel's pixel loop in its moment form (sorted_moments_ok)
 };
 // Gram by index sums (sorted.hip: k_sorted_gsum): S_r[t][x] = sum c_i^2 G_t(col_i), t < 2 nC - 1; layout [row][t][level]
 bool sorted_gsum_ok(GridSpec gs, double hx);
@@ -232,7 +233,9 @@ hipError_t sort_rows(hipStream_t s, const float* d_lum, GridSpec gs, int row0, i
 hipError_t sorted_pass(hipStream_t s, int mode, GridSpec gs, int row0, int nrows_local, const unsigned short* d_scol,
                        const uint2* d_desc, const unsigned short* d_first, const double* d_E, const double* d_g, double eps,
                        double* d_ybuf, double* d_h, const double* d_cvec, const float* d_xvec, bool rec, double kappa,
-                       int lev_t0 = 0, int lev_nt = 16);  // table columns of the level tiles [lev_t0, +lev_nt) only
+                       int lev_t0 = 0, int lev_nt = 16,   // table columns of the level tiles [lev_t0, +lev_nt) only
+                       bool mom = false);                 // the moment form of the pixel loop (sorted_moments_ok)
+bool sorted_moments_ok(GridSpec gs, double hx);
 hipError_t sorted_gram_rows(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
                             const unsigned short* d_first, const double* d_E, const double* d_cvec, double* d_Aout, bool rec,
                             double kappa);

@@ -401,9 +401,15 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
         // (no separate Cholesky attempt here: the host's stops at the first pivot that proves it futile, a device
         // factorisation costs as much as the reduction -- so the eigenvalues come first and decide; none below the cut
         // is the deflated route with nothing to deflate)
+        bool reduced = false;
         if (!force_eig && std::getenv("NLE_NO_DEFLATE") == nullptr) {
-            esw.reduce(c, q, d_Ah.p, nullptr);
+            reduced = esw.reduce(c, q, d_Ah.p, nullptr);
+            // a rank whose device reduction failed takes the host root below; its peers must not wait for it in a different
+            // sequence of collectives nor cut at another rank: if one falls back, all do (one 8-byte all-reduce, world > 1)
+            if (c->world > 1) reduced = ranks_where(c, !reduced) == 0;
             tr.mark("ss:   Wa: tridiagonal form + eigenvalues (device)");
+        }
+        if (reduced) {
             int kept = 0;
             while (kept < q && esw.D[kept] >= NLE_EPS) ++kept;  // :213-216
             nd = q - kept;
@@ -617,9 +623,7 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
     // (NLE_DEVICE_TRIDIAG=1, opt-in, K <= m / 2, m <= 224: the one-workgroup reduction of tridiag.hip -- measured at m = 196:
     // 0.66 ms on the device against 0.43 ms of the 1.26 ms host solve, so it is not the default).
     const int kq = std::min(std::max(n_eig, 1), m);
-    const bool dev_eig = c->topk_solver == 0 && use_dev_solver(m) && !std::getenv("NLE_HOST_Q");
-    const bool dev_tridiag = !dev_eig && c->topk_solver == 0 && m >= 16 && m <= nlek::tridiag_max_n() && 2 * kq <= m &&
-                             std::getenv("NLE_DEVICE_TRIDIAG") != nullptr;
+    bool dev_eig = c->topk_solver == 0 && use_dev_solver(m) && !std::getenv("NLE_HOST_Q");
     DevSymEig es;  // (its staging buffer must outlive the upload it enqueues: function scope)
     DevBuf<double> d_Vq, d_l2q;
     if (dev_eig) {
@@ -629,7 +633,12 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
             HIP_OK(hipMemcpyAsync(d_l2q.p, l2_kept.data(), m * sizeof(double), hipMemcpyHostToDevice, st));
             d_add = d_l2q.p;
         }
-        es.reduce(c, m, d_Qm.p, d_add);
+        dev_eig = es.reduce(c, m, d_Qm.p, d_add);
+        if (c->world > 1) dev_eig = ranks_where(c, !dev_eig) == 0;  // one rank on the host solver: all of them (see Wa)
+    }
+    const bool dev_tridiag = !dev_eig && c->topk_solver == 0 && m >= 16 && m <= nlek::tridiag_max_n() && 2 * kq <= m &&
+                             std::getenv("NLE_DEVICE_TRIDIAG") != nullptr;
+    if (dev_eig) {
         tr.mark("ss: Q, its tridiagonal form and eigenvalues (device)");
         h0 = now_ms();
         Sq = es.D;

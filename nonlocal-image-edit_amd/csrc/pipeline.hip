@@ -626,6 +626,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
         HIP_OK(hipMemsetAsync(d_cbuf.p, 0, d_cbuf.n * sizeof(double), c->stream));  // sample pixels are never visited
         sr = nlek::SortedRows{d_scol.p, d_desc.p, d_first.p, d_E.p, false, 0.0};
         sr.rec = nlek::sorted_recurrence(ss.gs, hx, &sr.kappa);
+        sr.mom = nlek::sorted_moments_ok(ss.gs, hx);
         if (std::getenv("NLE_ALL_LEVEL_TILES") == nullptr) {  // the tables' columns of level tiles that do not occur are skipped
             int t0 = 0, t1 = 16;
             while (t0 < 15 && !((ss.level_tiles >> t0) & 1u)) ++t0;
@@ -815,6 +816,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
             f->sorted = nlek::SortedRows{own(d_scol), own(d_desc), own(d_first), own(d_E), sr.rec, sr.kappa};
             f->sorted.lev_t0 = sr.lev_t0;
             f->sorted.lev_nt = sr.lev_nt;
+            f->sorted.mom = sr.mom;
         }
         f->h_Vrows = o.Vrows;
         f->h_sample_pix = ss.pix;

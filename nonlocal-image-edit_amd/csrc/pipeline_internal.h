@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <functional>
 #include <chrono>
 #include <cmath>
@@ -39,6 +40,8 @@ struct nle_ctx {
     ncclComm_t comm = nullptr;  // native RCCL (nle_ctx_init_rccl / nle_ctx_set_rccl_comm): all-reduce in place on `stream`
     bool own_comm = false;
     std::atomic<int> comm_aborted{0};  // nle_ctx_abort_rccl (possibly from another thread): collectives fail from here on
+    std::mutex comm_mu;                // serialises the enqueue of a collective on `comm` against nle_ctx_abort_rccl, which
+                                       // frees it (ncclCommAbort) on another thread: no enqueue may use a freed communicator
     double* d_comm = nullptr;
     size_t comm_len = 0;
     std::string err;
@@ -367,6 +370,11 @@ inline void all_reduce(nle_ctx* c, double* d, size_t n) {
     if (c->comm_aborted.load(std::memory_order_acquire))
         throw Fail{NLE_ERR_COMM, "the communicator of this ctx was aborted (another rank failed)"};
     if (c->comm) {  // native: one ncclAllReduce in place on the ctx's stream (also for world == 1: same code path)
+        // the ENQUEUE (not the collective's execution) under the mutex: an abort from another thread either comes first --
+        // seen by the check below -- or waits for the enqueue to return and then ends the pending collective
+        std::lock_guard<std::mutex> lk(c->comm_mu);
+        if (c->comm_aborted.load(std::memory_order_acquire))
+            throw Fail{NLE_ERR_COMM, "the communicator of this ctx was aborted (another rank failed)"};
         RCCL_OK(rccl().AllReduce(d, d, n, ncclDouble, ncclSum, c->comm, c->stream));
         return;
     }
@@ -381,10 +389,8 @@ inline void all_reduce(nle_ctx* c, double* d, size_t n) {
 // A rank-local verdict that the collectives after it depend on (does Phi fit HERE?  which formulation?) is agreed over the
 // ranks before anything acts on it: the number of ranks on which `flag` holds.  Without this a rank that refuses (or picks
 // another formulation) leaves its peers blocked in their next all-reduce.  One 8-byte all-reduce; nothing when world == 1.
-// NLE_FAULT_RANK=<r> (fault injection for the tests) makes rank r answer "true" whatever it found.
+// (The tests inject a dissenting rank through the all-reduce callback: this is the only one-double all-reduce.)
 inline int ranks_where(nle_ctx* c, bool flag) {
-    if (const char* e = std::getenv("NLE_FAULT_RANK"))
-        if (c->world > 1 && std::atoi(e) == c->rank) flag = true;
     if (c->world <= 1 && !c->comm) return flag ? 1 : 0;
     DevBuf<double> d(1);
     double v = flag ? 1.0 : 0.0;

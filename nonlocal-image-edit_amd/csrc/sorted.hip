@@ -32,8 +32,6 @@
 #include <cmath>
 #include <cstdlib>
 
-// (The ablation / timestamp variants of k_sorted_pass behind profiles/r2_pass_ablation.txt are not in this file: they are
-// tools/micro/sorted_pass_ablation.patch, applied to a copy of it by tools/abl_build.sh.)
 #define NLE_PIXEL_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 namespace nlek {
@@ -291,9 +289,10 @@ hipError_t sort_rows(hipStream_t s, const float* d_lum, GridSpec gs, int row0, i
 }
 
 // ------------------------------------------------------------------ LDS layout shared by the two pass kernels
-// sE [W + 1] doubles | sP [kT][PS] doubles | sfirst [2][260] u16 (this row's and the next row's)
+// sE [W + 1] doubles | sP [kT][PS] doubles | sfirst [2][260] u16 (this row's and the next row's) | sCk [40] doubles (the
+// quadratic factors of the moment form of k_sorted_pass)
 __host__ __device__ inline size_t sorted_lds_bytes(int W, int ps) {
-    return ((size_t)((W + 2) & ~1) + (size_t)kT * ps) * sizeof(double) + 2 * 260 * sizeof(unsigned short);
+    return ((size_t)((W + 2) & ~1) + (size_t)kT * ps + 40) * sizeof(double) + 2 * 260 * sizeof(unsigned short);
 }
 
 // Combines the per-chunk partial sums v[0..NV) of the threads of one level (consecutive threads, j = position in the
@@ -324,7 +323,18 @@ __device__ __forceinline__ void combine_chunks(double (&v)[NV], double* sP, int 
 // For every local image row r (persistent workgroups, rows r = blockIdx.x, + gridDim.x, ...):
 //   y_i = 1 (COLSUM) | recip(sum_b ec[c_i][b] g_r[x_i][b]) (RECIP) | c_i x_i (XVEC),   h_r[x][b] = sum_{i: x_i = x} ec[c_i][b] y_i
 // g, hout: [nrows][b][x] (b-major tables, as k_hist_g writes and k_hist_hh reads them).
-template <int NC, bool REC>
+//
+// CF: how a pixel gets its nC column factors e_b = exp(-(c - c_b)^2 / hx^2).
+//   0  nC reads of the LDS table E (64 lanes, 64 unrelated addresses: ~8 cycles of the CU's one LDS pipe per read -- at
+//      nC = 10 that pipe, not the vector units, bounds the pixel loop: 64 wave-pixels x 10 reads x 8 cycles = 2.1 us per row)
+//   1  e_0, e_1 from the table, the rest by the recurrence of column_factors (nC > 12)
+//   2  MOMENTS: on the equispaced grid e_b = e_0 rho^b C_b with rho = e_1 / e_0 (per pixel) and C_b = kappa^(b (b - 1) / 2)
+//      (per grid), so the row product is a POLYNOMIAL in rho, sum_b e_b g_b = e_0 sum_b (C_b g_b) rho^b -- Horner on
+//      coefficients the thread keeps for its chunk -- and the per-level sums are MOMENTS, sum_i e_b y_i = C_b sum_i (y_i e_0)
+//      rho^b, scaled by C_b once per chunk: two table reads and ~3.5 nC fp64 operations per pixel, no e_b ever formed.
+//      Exact algebra; the rounding is the recurrence's (a product of b factors).  The host enables it where no power
+//      leaves the normal range (sorted_moments_ok).
+template <int NC, int CF>
 __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode, const unsigned short* __restrict__ scol,
                                                     const uint2* __restrict__ desc, const unsigned short* __restrict__ first,
                                                     GridSpec gs, int row0, int nrows, const double* __restrict__ Etab,
@@ -336,13 +346,23 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
     constexpr int SL = NC < 11 ? NC : 11;  // sums combined per tree (slices of the nC sums when nC > 11)
     constexpr int PS = SL | 1;             // odd stride: consecutive threads' rows start on different banks
     constexpr bool KEEP_E = NC <= 32;      // keep the column factors of a pixel in registers between the two loops (254 VGPRs at NC = 30, no spills)
+    constexpr bool REC = CF == 1, MOM = CF == 2;
     const int W = gs.W;
     const size_t pitch = sorted_row_pitch(W);
     double* sE = reinterpret_cast<double*>(smem_raw);
     double* sP = sE + ((W + 2) & ~1);
     unsigned short* sfirst = reinterpret_cast<unsigned short*>(sP + (size_t)kT * PS);  // [2][260], rows alternate
+    double* sCk = reinterpret_cast<double*>(sfirst + 2 * 260);                          // [NC] C_b = kappa^(b (b - 1) / 2)
     const int tid = threadIdx.x;
     for (int i = tid; i <= W; i += kT) sE[i] = Etab[i];
+    if (MOM && tid == 0) {
+        double ck = 1.0, kp = 1.0;  // C_{b+1} = C_b kappa^b
+        for (int b = 0; b < NC; ++b) {
+            sCk[b] = ck;
+            ck *= kp;
+            kp *= kappa;
+        }
+    }
     const int cb0 = gs.colOff, cs = gs.colStep;
     const bool recip = mode == ROWPASS_RECIP, xmode = mode == ROWPASS_XVEC;
     const unsigned sEa = lds_addr(sE);
@@ -398,6 +418,101 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
         // One pixel at a time (the column factors of one pixel fill the registers; the scheduling barrier keeps the
         // unrolled bodies from being interleaved), up to the longest chunk of the WAVE: a scalar bound, so that a wave
         // whose chunks are all short skips the rest without per-lane bookkeeping.  Lanes past their own chunk add zeros.
+        double(&q)[NC] = gv;  // MOM: the polynomial's coefficients C_b g_b of this thread's chunk, in place of g_b
+        if constexpr (MOM) {
+            if (recip) {
+#pragma unroll
+                for (int b = 2; b < NC; ++b) gv[b] *= sCk[b];  // C_0 = C_1 = 1
+            }
+        }
+        // MOM: two (nC <= 12) or FOUR pixels of the chunk at a time.  A pixel's work is a few dependent chains of fp64
+        // operations -- the reciprocal's Newton steps, the Horner recurrences, the running powers -- and with 2-4 waves per
+        // SIMD their LATENCY, not their issue rate, is what the loop costs; four independent pixels give the scheduler
+        // 8-16 chains to interleave, and the state of a pixel is 8 doubles now that no e_b is kept.  Lanes past their own
+        // chunk (and the padding of the last block) work on column 0 and add exact zeros.
+        constexpr int PB = NC <= 12 ? 2 : 4;  // pixels in flight per thread (registers: 128 per thread at two workgroups per CU)
+        auto pixels = [&](const unsigned (&c8)[PB], const int base) {
+            double e0[PB], rho[PB], rho2[PB], y[PB];
+            bool keep[PB];
+#pragma unroll
+            for (int k = 0; k < PB; ++k) {
+                e0[k] = e_at(sEa, c8[k], (unsigned)cb0 << 3);
+                rho[k] = e_at(sEa, c8[k], (unsigned)(cb0 + cs) << 3);
+                keep[k] = base + k < len;
+                y[k] = 1.0;
+            }
+            if (xmode) {
+#pragma unroll
+                for (int k = 0; k < PB; ++k) y[k] = cv_row[c8[k] >> 3] * (double)xv_row[c8[k] >> 3];  // apply: y_i = c_i x_i
+            }
+#pragma unroll
+            for (int k = 0; k < PB; ++k) {
+                double r0 = __builtin_amdgcn_rcp(e0[k]);  // e_0 is a normal number here (sorted_moments_ok)
+                r0 = fma(fma(-e0[k], r0, 1.0), r0, r0);
+                r0 = fma(fma(-e0[k], r0, 1.0), r0, r0);
+                rho[k] *= r0;
+                rho2[k] = rho[k] * rho[k];
+            }
+            if (recip) {
+                // even and odd coefficients: two Horner chains in rho^2 of half the length, per pixel
+                constexpr int LE = (NC - 1) & ~1, LO = ((NC - 2) & ~1) + 1;   // highest even / odd index < NC
+                double se[PB], so[PB];
+#pragma unroll
+                for (int k = 0; k < PB; ++k) {
+                    se[k] = q[LE];
+                    so[k] = q[LO];
+                }
+#pragma unroll
+                for (int b = LE - 2; b >= 0; b -= 2) {
+#pragma unroll
+                    for (int k = 0; k < PB; ++k) se[k] = fma(se[k], rho2[k], q[b]);
+                }
+#pragma unroll
+                for (int b = LO - 2; b >= 1; b -= 2) {
+#pragma unroll
+                    for (int k = 0; k < PB; ++k) so[k] = fma(so[k], rho2[k], q[b]);
+                }
+#pragma unroll
+                for (int k = 0; k < PB; ++k) {
+                    const double sm = fma(so[k], rho[k], se[k]) * e0[k];
+                    double r = __builtin_amdgcn_rcp(sm);  // inplaceReciprocal (src/filter.cpp:42-54), recip0_d's arithmetic
+                    r = fma(fma(-sm, r, 1.0), r, r);
+                    r = fma(fma(-sm, r, 1.0), r, r);
+                    y[k] = r;
+                    keep[k] = keep[k] && fabs(sm) >= eps;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PB; ++k) {
+                const bool on = base + k < len;
+                y[k] = keep[k] ? y[k] : 0.0;  // the padding of the slot adds exact zeros
+                if (yb_row != nullptr && on) yb_row[c8[k] >> 3] = y[k];
+            }
+            // moments: acc_b += sum_k y_k e_0k rho_k^b, even and odd chains per pixel, the pixels summed pairwise
+            auto sum_pb = [](const double (&t)[PB]) {
+                if constexpr (PB == 4) return (t[0] + t[1]) + (t[2] + t[3]);
+                else return t[0] + t[1];
+            };
+            double te[PB], to[PB];
+#pragma unroll
+            for (int k = 0; k < PB; ++k) {
+                te[k] = y[k] * e0[k];
+                to[k] = te[k] * rho[k];
+            }
+            acc[0] += sum_pb(te);
+            acc[1] += sum_pb(to);
+#pragma unroll
+            for (int b = 2; b < NC; b += 2) {
+#pragma unroll
+                for (int k = 0; k < PB; ++k) te[k] *= rho2[k];
+                acc[b] += sum_pb(te);
+                if (b + 1 < NC) {
+#pragma unroll
+                    for (int k = 0; k < PB; ++k) to[k] *= rho2[k];
+                    acc[b + 1] += sum_pb(to);
+                }
+            }
+        };
         auto pixel = [&](const unsigned c8, const bool on) {
             double e[KEEP_E ? NC : 1];
             double y = 1.0;
@@ -433,6 +548,25 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wlen = max(wlen, __shfl_xor(wlen, off));
         wlen = __builtin_amdgcn_readfirstlane(wlen);
+        if constexpr (MOM) {
+#pragma unroll
+            for (int b = 0; b < kMaxBlocks; ++b) {
+                if (4 * b >= wlen) break;
+                if constexpr (PB == 4) {
+                    const unsigned c8[PB] = {idx[b].x & 0xffffu, idx[b].x >> 16, idx[b].y & 0xffffu, idx[b].y >> 16};
+                    pixels(c8, 4 * b);
+                    NLE_PIXEL_FENCE();
+                } else {
+                    const unsigned c8a[PB] = {idx[b].x & 0xffffu, idx[b].x >> 16}, c8b[PB] = {idx[b].y & 0xffffu, idx[b].y >> 16};
+                    pixels(c8a, 4 * b);
+                    NLE_PIXEL_FENCE();
+                    if (4 * b + 2 < wlen) {
+                        pixels(c8b, 4 * b + 2);
+                        NLE_PIXEL_FENCE();
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int b = 0; b < kMaxBlocks; ++b) {
             if (4 * b >= wlen) break;
@@ -451,10 +585,15 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
                 NLE_PIXEL_FENCE();
             }
         }
+        }
         // The combine / load / store phase is a chain of barriers and memory round trips; the other workgroup of the CU is
         // (usually) in its pixel loop and, being older or younger, wins or loses every issue slot wholesale (the stamps of
         // tools/stamps_run.sh: the second workgroup's combine took 4-5 us against 2.2 us alone).  Raise the priority here,
         // drop it for the loop.
+        if constexpr (MOM) {
+#pragma unroll
+            for (int b = 2; b < NC; ++b) acc[b] *= sCk[b];  // C_0 = C_1 = 1
+        }
         __builtin_amdgcn_s_setprio(3);
         int steps = dsc_steps(dsc), j = dsc_j(dsc), m = dsc_m(dsc);
         asm volatile("" : "+v"(steps), "+v"(j), "+v"(m));  // decoded before the loads below are issued, not after
@@ -533,34 +672,50 @@ bool sorted_recurrence(GridSpec gs, double hx, double* kappa) {
     return !off && gs.nSelCols > 12 && m_e < 500.0 && m_rho < 500.0;
 }
 
+// Where the moment form of k_sorted_pass stays inside the normal range of fp64 with a wide margin: e_0 = exp(-u^2 / hx^2)
+// (u = c - cb0), the powers rho^b = exp(b (2 cs u - cs^2) / hx^2), b < nC, and the running products y e_0 rho^b =
+// y e_b / C_b <= y exp(nC^2 cs^2 / hx^2).  Very narrow kernels (W / hx beyond ~14) keep the table / recurrence forms.
+bool sorted_moments_ok(GridSpec gs, double hx) {
+    if (std::getenv("NLE_SORTED_TABLE") != nullptr || std::getenv("NLE_SORTED_NO_MOMENTS") != nullptr) return false;
+    const double cs = gs.colStep, umax = std::max<double>(gs.colOff, gs.W - 1 - gs.colOff), nC = gs.nSelCols;
+    const double span = umax + nC * cs;
+    return span * span / (hx * hx) < 200.0 && nC * (2.0 * cs * umax + nC * cs * cs) / (hx * hx) < 400.0;
+}
+
 hipError_t sorted_pass(hipStream_t s, int mode, GridSpec gs, int row0, int nrows_local, const unsigned short* d_scol,
                        const uint2* d_desc, const unsigned short* d_first, const double* d_E, const double* d_g, double eps,
                        double* d_ybuf, double* d_h, const double* d_cvec, const float* d_xvec, bool rec, double kappa,
-                       int lev_t0, int lev_nt) {
+                       int lev_t0, int lev_nt, bool mom) {
     const int nC = gs.nSelCols;
     if (nC < 1 || nC > 36 || gs.W > sorted_max_width() || lev_t0 < 0 || lev_nt < 1 || lev_t0 + lev_nt > kLevels / 16)
         return hipErrorInvalidValue;
     if (nrows_local <= 0) return hipSuccess;
     const size_t shm = sorted_lds_bytes(gs.W, (nC < 11 ? nC : 11) | 1);
     const int grid = sorted_grid(nrows_local);
-#define NLE_SP1(NCV, RECV)                                                                                                \
+#define NLE_SP1(NCV, CFV)                                                                                                 \
     {                                                                                                                     \
         if (shm > 48 * 1024) {                                                                                            \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sorted_pass<NCV, RECV>),                  \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sorted_pass<NCV, CFV>),                   \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                    \
             if (ea != hipSuccess) return ea;                                                                              \
         }                                                                                                                 \
-        hipLaunchKernelGGL((k_sorted_pass<NCV, RECV>), dim3((unsigned)grid), dim3(kT), shm, s, mode, d_scol, d_desc,       \
+        hipLaunchKernelGGL((k_sorted_pass<NCV, CFV>), dim3((unsigned)grid), dim3(kT), shm, s, mode, d_scol, d_desc,        \
                            d_first, gs, row0, nrows_local, d_E, d_g, eps, d_ybuf, d_h, d_cvec, d_xvec, kappa, lev_t0,     \
                            lev_nt);                                                                                       \
     }
 #define NLE_SP(NCV)                                                                                                       \
     case NCV:                                                                                                             \
+        if constexpr ((NCV) > 1) {                                                                                        \
+            if (mom) {                                                                                                    \
+                NLE_SP1(NCV, 2)                                                                                           \
+                break;                                                                                                    \
+            }                                                                                                             \
+        }                                                                                                                 \
         if constexpr ((NCV) > 12) {                                                                                       \
-            if (rec) NLE_SP1(NCV, true) else NLE_SP1(NCV, false)                                                          \
+            if (rec) NLE_SP1(NCV, 1) else NLE_SP1(NCV, 0)                                                                 \
         } else {                                                                                                          \
             if (rec) return hipErrorInvalidValue;                                                                         \
-            NLE_SP1(NCV, false)                                                                                           \
+            NLE_SP1(NCV, 0)                                                                                               \
         }                                                                                                                 \
         break;
     switch (nC) {

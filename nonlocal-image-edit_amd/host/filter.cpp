@@ -53,6 +53,8 @@ struct DeviceGroup {
     int arrived = 0;
     long long generation = 0;
     bool failed = false;
+    int bound_p = -1;           // sample count the communicator / comm buffers are bound for (-1: not bound)
+    bool native_bound = false;  // the library's RCCL communicator exists on every ctx
     std::vector<std::vector<double>> slot;  // one per rank
     std::vector<void*> d_comm;
     struct Rank { DeviceGroup* g; int r; };
@@ -79,10 +81,20 @@ struct DeviceGroup {
             cv.notify_all();  // ranks waiting in the host-mediated all-reduce
         }
         // ranks waiting in a native collective for the one that failed: abort every communicator of the group, their
-        // pending ncclAllReduce ends and their next call returns NLE_ERR_COMM (the group is rebuilt by the next train)
+        // pending ncclAllReduce ends and their next call returns NLE_ERR_COMM; device_group() rebuilds the group (a fresh
+        // unique id, ncclCommInitRank on every ctx) before the next train
         if (native)
             for (nle_ctx* c : ctx)
                 if (c) (void)nle_ctx_abort_rccl(c);
+    }
+    // after a failed run (every rank thread has been joined): forget the failure and whatever was bound, so that the next
+    // train binds a fresh communicator / fresh comm buffers instead of failing for the rest of the process
+    void recover() {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = false;
+        arrived = 0;
+        bound_p = -1;
+        native_bound = false;
     }
     static int allreduce_cb(void* user, void* d_buf, size_t count) {
         Rank* me = static_cast<Rank*>(user);
@@ -160,15 +172,16 @@ DeviceGroup* device_group(int p_samples) {
         }
     }
     if (g && p_samples > 0) {
+        if (g->failed) g->recover();  // an earlier train / enhance of this process failed on some rank
         // (re)bind the communicator for this sample count: the callback form needs a comm buffer of nle_comm_len(p)
-        static int bound_p = -1;
-        if (bound_p != p_samples) {
+        if (g->bound_p != p_samples) {
             const int G = g->size();
             if (g->native) {
-                if (bound_p < 0) {
+                if (!g->native_bound) {
                     unsigned char id[NLE_RCCL_UNIQUE_ID_BYTES];
                     check(nle_rccl_unique_id(id, sizeof id), nullptr);
                     g->run([&](int r) { check(nle_ctx_init_rccl(g->ctx[r], r, G, id, sizeof id), g->ctx[r]); });
+                    g->native_bound = true;
                 }
             } else {
                 const size_t len = nle_comm_len(p_samples);
@@ -180,7 +193,7 @@ DeviceGroup* device_group(int p_samples) {
                 }
             }
             for (int r = 0; r < G; ++r) check(nle_ctx_set_slab_input(g->ctx[r], 1), g->ctx[r]);
-            bound_p = p_samples;
+            g->bound_p = p_samples;
         }
     }
     return g;

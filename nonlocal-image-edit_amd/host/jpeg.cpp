@@ -165,9 +165,9 @@ struct Decoder {
 };
 
 constexpr int kMaxDim = 65535;
-constexpr size_t kMaxBlocks = (size_t)1 << 24;  // 1 G coefficients: images up to ~32k x 32k, nothing a header can inflate beyond
+constexpr size_t kMaxBlocks = (size_t)1 << 24;  // 2^24 blocks = 2^30 coefficients (2 GiB of shorts): images up to ~32k x 32k
 
-bool parse_sof(Decoder& d, const unsigned char* s, size_t len, bool progressive) {
+bool parse_sof(Decoder& d, const unsigned char* s, size_t len, bool progressive, size_t file_bytes) {
     if (d.have_frame || len < 6) return false;
     if (s[0] != 8) return false;  // 8-bit samples only
     d.H = (s[1] << 8) | s[2];
@@ -200,6 +200,9 @@ bool parse_sof(Decoder& d, const unsigned char* s, size_t len, bool progressive)
         blocks += (size_t)c.bw * c.bh;
     }
     if (blocks > kMaxBlocks) return false;
+    // every coded block costs at least one bit of entropy data (its DC code), so a file of n bytes cannot hold more than
+    // 8 n blocks: a 200-byte header claiming 32k x 32k is refused HERE, before gigabytes are allocated on its word
+    if (blocks > 8 * file_bytes) return false;
     for (int i = 0; i < d.ncomp; ++i) d.comp[i].coef.assign((size_t)d.comp[i].bw * d.comp[i].bh * 64, 0);
     d.progressive = progressive;
     d.have_frame = true;
@@ -600,10 +603,10 @@ Image read_jpeg(const std::vector<unsigned char>& b) {
         switch (m) {
             case 0xc0:
             case 0xc1:
-                if (!parse_sof(d, s, len, false)) return Image();
+                if (!parse_sof(d, s, len, false, b.size())) return Image();
                 break;
             case 0xc2:
-                if (!parse_sof(d, s, len, true)) return Image();
+                if (!parse_sof(d, s, len, true, b.size())) return Image();
                 break;
             case 0xc3: case 0xc5: case 0xc6: case 0xc7: case 0xc9: case 0xca: case 0xcb: case 0xcd: case 0xce: case 0xcf:
                 return Image();  // lossless, hierarchical, arithmetic coding

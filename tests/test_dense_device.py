@@ -79,3 +79,38 @@ def test_device_cholesky_reports_an_indefinite_matrix(nle, ctx):
     M = X + X.T
     _, _, _, ok = ctx.cholesky_device(M)
     assert not ok
+
+
+def test_a_device_that_cannot_run_the_persistent_reduction_falls_back_to_the_host_solver(nle, oracle, ctx):
+    """the Householder reduction is ONE persistent launch whose workgroups must all be resident; a device with
+    fewer compute units than workgroups (a partition, a smaller part) or a timed-out hand-off used to fail the whole train
+    with NLE_ERR_NUMERIC although the host solver was there.  NLE_SYTRD_G=250 asks for more workgroups than the chip offers
+    (+ the 16 held back): the train must take the host solvers and give exactly what NLE_HOST_SOLVER=1 gives; the
+    stand-alone entry point, which has no host form to fall back on, reports the reason."""
+    import os
+    H, W, nr, nc, hx, hy, T, K, L = 192, 256, 17, 18, 48.0, 30.0, 6, 24, 4          # 306 samples: above the device threshold
+    x = oracle.synthetic_luminance(H, W).astype(np.float32)
+
+    def run(env):
+        os.environ.update(env)
+        try:
+            f = nle.NLEFilter(ctx).train_filter(x, nr, nc, hx, hy, T, K)
+            ev, Y = f.eigvals.copy(), f.apply_layers(x, L).cpu().numpy()
+            f.close()
+            return ev, Y
+        finally:
+            for k in env:
+                del os.environ[k]
+
+    ev_h, Y_h = run({"NLE_HOST_WA": "1", "NLE_HOST_Q": "1"})
+    ev_f, Y_f = run({"NLE_SYTRD_G": "250"})
+    assert np.array_equal(ev_f, ev_h) and np.array_equal(Y_f, Y_h)
+    ev_d, Y_d = run({})                                                         # and the device solvers agree to rounding
+    assert np.abs(ev_d - ev_h).max() <= 1e-10 and np.abs(Y_d - Y_h).max() <= 1e-3 * np.abs(Y_h).max()
+    os.environ["NLE_SYTRD_G"] = "250"
+    try:
+        M, _ = _spectrum_matrix(300, 1, "q")
+        with pytest.raises(nle.NLEError, match="compute units"):
+            ctx.sym_eigen_device(0.5 * (M + M.T), 0, 4)
+    finally:
+        del os.environ["NLE_SYTRD_G"]

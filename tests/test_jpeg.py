@@ -127,12 +127,15 @@ def test_damaged_files_never_crash(tool, tmp_path):
         files.append(f)
     for k, blob in enumerate((b"\xff\xd8", b"\xff\xd8\xff\xd9", b"\xff\xd8\xff\xc0\x00\x02", b"\xff\xd8" + b"\xff" * 64,
                               # 65535 x 65535 frame: refused before any allocation
-                              b"\xff\xd8\xff\xc0\x00\x11\x08\xff\xff\xff\xff\x03\x01\x22\x00\x02\x11\x01\x03\x11\x01\xff\xd9")):
+                              b"\xff\xd8\xff\xc0\x00\x11\x08\xff\xff\xff\xff\x03\x01\x22\x00\x02\x11\x01\x03\x11\x01\xff\xd9",
+                              # 32000 x 32000 grey frame (under the block cap: 16 M blocks = 2 GiB of coefficients) in a
+                              # 17-byte file: a block needs at least one bit of entropy data, so the header is refused
+                              b"\xff\xd8\xff\xc0\x00\x0b\x08\x7d\x00\x7d\x00\x01\x01\x11\x00\xff\xd9")):
         f = str(tmp_path / f"junk{k}.jpg")
         open(f, "wb").write(blob)
         files.append(f)
     got = _decode(tool, files, tmp_path)       # asserts a clean exit of the sanitizer build
-    assert all(got[f] is None for f in files[-5:])
+    assert all(got[f] is None for f in files[-6:])
 
 
 def test_writer_output_is_a_jpeg_every_decoder_reads(tool, tmp_path):

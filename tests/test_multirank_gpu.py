@@ -205,11 +205,12 @@ def test_native_rccl_reinit_and_lifetimes(nle, oracle):
 
 
 def _fault_worker(rank, world, port, mode, outdir):
-    """rank 1 is made to answer "Phi does not fit here" (NLE_FAULT_RANK): what do BOTH ranks do?"""
+    """rank 1 is made to answer "Phi does not fit here": what do BOTH ranks do?  The fault is injected from here, through
+    the all-reduce callback -- the agreement of a rank-local verdict (ranks_where) is the library's only ONE-double
+    all-reduce, and rank 1 adds 1 to its contribution -- not by a hook in the product."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ["NLE_FAULT_RANK"] = "1"
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     import __graft_entry__ as entry
@@ -222,7 +223,12 @@ def _fault_worker(rank, world, port, mode, outdir):
         ctx = nle.Context(0)
         ctx.set_mode(mode)
         g = nle.sample_grid(H, W, nr, nc)
-        ctx.set_shard(rank, world, g["n_sel_rows"] * g["n_sel_cols"], lambda t: dist.all_reduce(t))
+        def allreduce(t):
+            if t.numel() == 1 and rank == 1:
+                t += 1.0            # "it does not fit HERE"
+            dist.all_reduce(t)
+
+        ctx.set_shard(rank, world, g["n_sel_rows"] * g["n_sel_cols"], allreduce)
         try:
             f = nle.NLEFilter(ctx).train_filter(x, nr, nc, hx, hy, T, K)
             Y = f.apply_layers(x, L).cpu().numpy()
