@@ -175,17 +175,130 @@ def sinkhorn_with_scalings(phi, eigvals, max_iter=10):
     return Wa, Wab, r, c
 
 
-def orthogonalize(Wa: np.ndarray, Wab: np.ndarray, n_eig_vectors: int = 5, eps: float = EPS, info: list | None = None):
-    """`orthogonalize`, src/filter.cpp:282-331, default (non-Spectra) branch :313-316.
-    Returns (V (N x K'), Sq (K'))."""
+def _spectra_start_vector(n: int) -> np.ndarray:
+    """The start vector of Spectra's `init()` (ext/Spectra/SymEigsBase.h:297-302: `SimpleRandom<Scalar> rng(0)`): the
+    minimal-standard Lehmer generator x <- 16807 x mod (2^31 - 1) from x = 1 (a zero seed is replaced by 1), each value
+    x / (2^31 - 1) - 0.5.  Only the path of the iteration depends on it, not its limit."""
+    m = (1 << 31) - 1
+    x, out = 1, np.empty(n)
+    for i in range(n):
+        x = (16807 * x) % m
+        out[i] = x / m - 0.5
+    return out
+
+
+def topk_eigen_decomposition(M: np.ndarray, n_largest: int, eps: float = EPS, tol: float = 1e-10, maxit: int = 1000,
+                             info: list | None = None):
+    """`topkEigenDecomposition`, src/filter.cpp:170-199 -- what `orthogonalize` calls on Q in a USE_SPECTRA build (:310-311):
+    `Spectra::SymEigsSolver<double, LARGEST_MAGN, DenseGenMatProd>` with nev = min(nLargest, n - 1) (:171) and
+    ncv = min(2 nev, n) (:173), `compute()` with its defaults (at most 1000 restarts, tolerance 1e-10, result sorted by
+    algebraic value descending: ext/Spectra/SymEigsBase.h:331), then only the CONVERGED pairs (:379-398), then the leading
+    run >= eps (:187-196).  Returns (U (n x r), D (r)).
+
+    Spectra (vendored in the reference, but it needs Eigen to compile) is an implicitly restarted Lanczos method.  Restated
+    here as its published algorithm in the mathematically equivalent thick-restart form: an ncv-step Lanczos factorisation
+    M V = V T + f e^T with full re-orthogonalisation, driven ONLY by products M x with the matrix AS GIVEN
+    (`DenseGenMatProd`: no triangle is mirrored, unlike `eigenDecomposition`, :207); Ritz pairs of T ordered by magnitude;
+    a wanted pair counts as converged when |last component of its Ritz vector| ||f|| < tol max(eps^(2/3), |theta|)
+    (:111-119); restart on the leading nev' Ritz vectors, nev' adjusted as ARPACK's dsaup2 does (:122-141)."""
+    M = np.asarray(M, dtype=np.float64)
+    n = M.shape[0]
+    nev = min(int(n_largest), n - 1)                    # :171
+    if nev < 1:
+        raise RuntimeError("topkEigenDecomposition needs a matrix of order >= 2")   # the reference asserts (:172)
+    ncv = min(2 * nev, n)                               # :173
+    if ncv <= nev:
+        raise ValueError("ncv must satisfy nev < ncv <= n")   # Spectra's constructor throws (SymEigsBase.h:270-271)
+    eps23 = np.finfo(np.float64).eps ** (2.0 / 3.0)
+    near0 = np.finfo(np.float64).tiny * 10.0
+    V = np.zeros((n, ncv))
+    T = np.zeros((ncv, ncv))
+    v0 = _spectra_start_vector(n)
+    V[:, 0] = v0 / np.linalg.norm(v0)
+
+    def extend(k0, f):
+        """Lanczos steps k0 .. ncv-1 (column k0 of V is set); returns the residual f of the last step"""
+        for j in range(k0, ncv):
+            w = M @ V[:, j]
+            h = V[:, :j + 1].T @ w
+            w = w - V[:, :j + 1] @ h
+            for _ in range(5):                          # iterated Gram-Schmidt, as the reference's factorisation does
+                c = V[:, :j + 1].T @ w
+                if np.abs(c).max() <= np.finfo(np.float64).eps * np.linalg.norm(w):
+                    break
+                w = w - V[:, :j + 1] @ c
+                h = h + c
+            T[j, j] = h[j]
+            beta = np.linalg.norm(w)
+            if j + 1 < ncv:
+                if beta < near0:                        # invariant subspace: continue with a vector orthogonal to V
+                    rng = np.random.default_rng(j)
+                    w = rng.standard_normal(n)
+                    w -= V[:, :j + 1] @ (V[:, :j + 1].T @ w)
+                    V[:, j + 1] = w / np.linalg.norm(w)
+                    beta = 0.0
+                else:
+                    V[:, j + 1] = w / beta
+                T[j + 1, j] = T[j, j + 1] = beta
+            f = w
+        return f
+
+    f = extend(0, None)
+    nconv, it = 0, 0
+    theta = S = conv = None
+    for it in range(maxit + 1):
+        theta, S = np.linalg.eigh(T)
+        order = np.argsort(-np.abs(theta), kind="stable")       # LARGEST_MAGN selection
+        theta, S = theta[order], S[:, order]
+        fnorm = np.linalg.norm(f)
+        est = np.abs(S[-1, :]) * fnorm
+        conv = est[:nev] < tol * np.maximum(eps23, np.abs(theta[:nev]))
+        nconv = int(conv.sum())
+        if nconv >= nev or it == maxit:
+            break
+        k = nev + int(np.sum(est[nev:] / max(fnorm, near0) < near0))   # nev_adjusted, SymEigsBase.h:122-141
+        k += min(nconv, (ncv - k) // 2)
+        if k == 1 and ncv >= 6:
+            k = ncv // 2
+        elif k == 1 and ncv > 2:
+            k = 2
+        k = min(k, ncv - 1)
+        # thick restart on the leading k Ritz vectors: T = diag(theta_k) bordered by ||f|| S[-1, :k], next vector f / ||f||
+        V[:, :k] = V @ S[:, :k]
+        T[:, :] = 0.0
+        T[np.arange(k), np.arange(k)] = theta[:k]
+        if fnorm < near0:
+            break
+        V[:, k] = f / fnorm
+        T[k, :k] = T[:k, k] = fnorm * S[-1, :k]
+        f = extend(k, f)
+    lam, vec, ok = theta[:nev], V @ S[:, :nev], conv
+    if info is not None:
+        info.append(dict(n=n, nev=nev, ncv=ncv, restarts=it, converged=nconv))
+    lam, vec = lam[ok], vec[:, ok]                      # converged pairs only (SymEigsBase.h:379-398)
+    o = np.argsort(-lam, kind="stable")                 # compute()'s default sort: LARGEST_ALGE (:331)
+    lam, vec = lam[o], vec[:, o]
+    r = 0
+    while r < lam.size and lam[r] >= eps:               # :187-189
+        r += 1
+    return np.ascontiguousarray(vec[:, :r]), lam[:r].copy()
+
+
+def orthogonalize(Wa: np.ndarray, Wab: np.ndarray, n_eig_vectors: int = 5, eps: float = EPS, info: list | None = None,
+                  use_spectra: bool = False):
+    """`orthogonalize`, src/filter.cpp:282-331; default (non-Spectra) branch :313-316, or with `use_spectra` the
+    USE_SPECTRA build's :310-311.  Returns (V (N x K'), Sq (K'))."""
     eigvecs, eigvals = eigen_decomposition(Wa, info=info)  # :287
     inv_root, _ = inplace_reciprocal(eigvals)  # :289-291
     inv_root = np.sqrt(inv_root)
     inv_root_wa = (eigvecs * inv_root[None, :]) @ eigvecs.T  # :292
     Q = Wa + inv_root_wa @ (Wab @ Wab.T) @ inv_root_wa  # :296
-    Vq, Sq = eigen_decomposition(Q, info=info)  # :313
-    k = min(n_eig_vectors, Vq.shape[1])  # :314
-    Vq, Sq = Vq[:, :k], Sq[:k]
+    if use_spectra:
+        Vq, Sq = topk_eigen_decomposition(Q, n_eig_vectors, info=info)  # :311
+    else:
+        Vq, Sq = eigen_decomposition(Q, info=info)  # :313
+        k = min(n_eig_vectors, Vq.shape[1])  # :314
+        Vq, Sq = Vq[:, :k], Sq[:k]
     inv_root_sq, _ = inplace_reciprocal(Sq)  # :319-321
     inv_root_sq = np.sqrt(inv_root_sq)
     tmp = np.vstack([Wa, Wab.T])  # :324-325
@@ -216,7 +329,8 @@ def layer_responses(eigvals: np.ndarray, n_layers: int) -> np.ndarray:
 
 def train_filter(channel: np.ndarray, n_row_samples: int, n_col_samples: int,
                  hx: float, hy: float, n_sinkhorn_iter: int, n_eigen_vectors: int,
-                 return_intermediates: bool = False, info: list | None = None, force_rank: int | None = None):
+                 return_intermediates: bool = False, info: list | None = None, force_rank: int | None = None,
+                 use_spectra: bool = False):
     """`NLEFilter::trainFilter`, src/filter.cpp:480-502 (GUI loop :504-511 omitted).
     Returns (eigvecs N x K' in PIXEL order, eigvals K').  `info` collects the three eigensolves' cut
     diagnostics (K_A, W_A, Q, in that order); `force_rank` overrides K_A's cut (diagnostics only)."""
@@ -224,7 +338,7 @@ def train_filter(channel: np.ndarray, n_row_samples: int, n_col_samples: int,
     eigvals, phi = nystrom_approximation(Ka, Kab, info=info, force_rank=force_rank)
     del Kab
     Wa, Wab, r_vec, c_vec = sinkhorn_with_scalings(phi, eigvals, n_sinkhorn_iter)
-    V, S = orthogonalize(Wa, Wab, n_eigen_vectors, info=info)
+    V, S = orthogonalize(Wa, Wab, n_eigen_vectors, info=info, use_spectra=use_spectra)   # use_spectra: the USE_SPECTRA build
     out = np.empty_like(V)
     out[perm] = V  # :502  (P*V).row(P.indices[i]) = V.row(i)
     if return_intermediates:

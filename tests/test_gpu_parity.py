@@ -615,22 +615,28 @@ def test_streamed_fp64_form_takes_what_does_not_fit(nle, oracle, ctx, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [SMALL_CASES[1], SMALL_CASES[4], (96, 128, 8, 10, 40.0, 30.0, 8, 79, 4)])
-def test_lanczos_topk_solver_for_Q_is_opt_in_and_agrees(nle, oracle, ctx, case):
+def test_lanczos_topk_solver_for_Q_matches_the_oracle_s_use_spectra_branch(nle, oracle, ctx, case):
     """the reference's USE_SPECTRA build finds the top eigenpairs of Q by Lanczos
-    (src/filter.cpp:170-199, 310-311).  Opt-in here (nle_ctx_set_topk_solver / NLE_Q_SOLVER=lanczos); against the
-    default full solver: same K' unless K >= q (Spectra's nev = min(K, q - 1)), eigenvalues and layers to the solver's
-    tolerance."""
+    (src/filter.cpp:170-199, 310-311).  Opt-in here (nle_ctx_set_topk_solver / NLE_Q_SOLVER=lanczos) and held to the ORACLE's
+    restatement of that branch (oracle.train_filter(use_spectra=True): nev = min(K, q - 1), ncv = min(2 nev, q), converged
+    pairs only, cut at 1e-10, products with the unsymmetrised Q): the same K', eigenvalues to 1e-8, every layer to the
+    1e-4 bar -- and, beside it, the default full solver where the two builds must agree (K' equal unless K >= q)."""
     H, W, nr, nc, hx, hy, T, K, L = case
     x = oracle.synthetic_luminance(H, W)
+    V_o, S_o = oracle.train_filter(x, nr, nc, hx, hy, T, K, use_spectra=True)
+    Y_o = oracle.apply_layers(V_o, S_o, x, L).reshape(L, -1)
     f0, Y0 = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
     ctx.set_topk_solver(1)
     try:
         f1, Y1 = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
     finally:
         ctx.set_topk_solver(0)
-    q = f0.diag()["r_Wa"] if False else f0.diag()["r_Ka"]
+    q = f0.diag()["r_Ka"]
     k0, k1 = f0.info()["K"], f1.info()["K"]
-    assert k1 == min(k0, q - 1)
+    assert k1 == S_o.size == min(k0, q - 1)
+    assert np.abs(f1.eigvals - S_o).max() < 1e-8
+    for j in range(L):
+        assert rel_l2(Y1[j], Y_o[j]) < PER_LAYER_TOL, j
     assert rel_l2(f1.eigvals, f0.eigvals[:k1]) < 1e-8
     if k1 == k0:
         for j in range(L):

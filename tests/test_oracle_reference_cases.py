@@ -108,6 +108,50 @@ def test_orthogonalize(oracle, seed):
     assert is_approx(V.T @ V, np.eye(S.size), TOL)                      # :148-152
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_orthogonalize_use_spectra_branch(oracle, seed):
+    """the same property through the USE_SPECTRA build's branch (src/filter.cpp:310-311 -> topkEigenDecomposition :170-199),
+    and against the default branch: Spectra's nev = min(k, q - 1) caps the count (:171), the eigenvalues are the default
+    solver's to the iteration's tolerance, and V spans the same space"""
+    rng = np.random.default_rng(seed)
+    p, n, k = 10, 100, 5
+    Wa = (rng.uniform(-1, 1, (p, p)) + 1) / 2
+    Wa = (Wa + Wa.T) / 2
+    Wab = (rng.uniform(-1, 1, (p, n - p)) + 1) / 2
+    info = []
+    V, S = oracle.orthogonalize(Wa, Wab, k, use_spectra=True, info=info)
+    assert S.size > 0 and V.shape == (n, S.size)
+    assert is_approx(V.T @ V, np.eye(S.size), 1e-8)
+    V0, S0 = oracle.orthogonalize(Wa, Wab, k)
+    assert S.size == min(S0.size, info[-1]["nev"]) and np.abs(S - S0[:S.size]).max() < 1e-9
+    assert np.abs(np.abs(np.sum(V * V0[:, :S.size], axis=0)) - 1.0).max() < 1e-6
+    # asking for as many pairs as the matrix has rows: the default branch keeps every eigenvalue >= 1e-10, Spectra at most q - 1
+    Vb, Sb = oracle.orthogonalize(Wa, Wab, 50, use_spectra=True)
+    V0b, S0b = oracle.orthogonalize(Wa, Wab, 50)
+    assert Sb.size <= Wa.shape[0] - 1 and np.abs(Sb - S0b[:Sb.size]).max() < 1e-9
+
+
+def test_topk_eigen_decomposition_reads_the_matrix_as_given(oracle):
+    """DenseGenMatProd multiplies by the FULL matrix (src/filter.cpp:174): garbage in the upper triangle changes the
+    Spectra branch's answer, while eigenDecomposition (SelfAdjointEigenSolver, :207) reads the lower triangle only"""
+    rng = np.random.default_rng(7)
+    Qo, _ = np.linalg.qr(rng.standard_normal((12, 12)))
+    lam = np.linspace(1.0, 0.05, 12)
+    M = (Qo * lam) @ Qo.T
+    M = 0.5 * (M + M.T)
+    U, D = oracle.topk_eigen_decomposition(M, 4)
+    assert D.size == 4 and np.abs(D - lam[:4]).max() < 1e-9 and np.all(np.diff(D) < 0)
+    junk = np.tril(M) + np.triu(np.full((12, 12), 3.0), 1)
+    assert np.abs(oracle.eigen_decomposition(junk)[1] - lam).max() < 1e-12
+    Dj = oracle.topk_eigen_decomposition(junk, 4)[1]
+    assert Dj.size != 4 or np.abs(Dj - lam[:4]).max() > 1e-2
+    # eigenvalues below the cut are dropped, negative ones of large magnitude are SELECTED (LARGEST_MAGN) and then cut too
+    lam2 = np.concatenate([[1.0, 0.5, -0.9], np.full(9, 1e-12)])
+    M2 = (Qo * lam2) @ Qo.T
+    U2, D2 = oracle.topk_eigen_decomposition(0.5 * (M2 + M2.T), 3)
+    assert D2.size == 2 and np.abs(D2 - [1.0, 0.5]).max() < 1e-9
+
+
 def test_conversion_order(oracle):
     """opencv2eigen flattens row-major (include/utils.hpp:28-41; test :10-40): the oracle's
     apply uses the same order."""
