@@ -52,7 +52,8 @@ struct OrthoSS {
 Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_c, const std::vector<double>& u_r,
                          std::vector<double> G, int n_eig, bool device_f32 = true, int topk_solver = 0);
 // sample-space form, host: everything that does not need the Gram matrix, then the rest
-void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<double>& sA_c, const std::vector<double>& sA_r);
+void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<double>& sA_c, const std::vector<double>& sA_r,
+                      bool literal_q = false);  // literal_q: S = Wa^-1/2 itself (no Cholesky root): Q is then the reference's matrix
 void ortho_ss_finish(OrthoSS& o, std::vector<double> Gk, int n_eig, int topk_solver = 0);
 // sample-space form with the p x p products (and, from dev_solver_min_n() samples on, the solvers) on the device
 void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std::vector<double>& sA_c,

@@ -174,7 +174,7 @@ Ortho orthogonalize_host(const Nystrom& ny, int p, const std::vector<double>& u_
 // first half: everything that does not depend on the Gram matrix (runs on the host while the GPU
 // computes Gk): sample scalings, Kr, P, Wa and S = Wa^-1/2 (:287-292)
 void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<double>& sA_c,
-                      const std::vector<double>& sA_r) {
+                      const std::vector<double>& sA_r, bool literal_q) {
     const int r = ny.r, q = ny.r;
     o.p = p;
     o.r = r;
@@ -209,7 +209,8 @@ void ortho_ss_prepare(OrthoSS& o, const Nystrom& ny, int p, const std::vector<do
     // (A^-1)_ii >= 1 / A_ii, so sum_i 1 / A_ii above the certificate's bound already rules the Cholesky form out
     double inv_diag = 0.0;
     for (int a = 0; a < q; ++a) inv_diag += o.Wa[(size_t)a * q + a] > 0.0 ? 1.0 / o.Wa[(size_t)a * q + a] : 1e300;
-    if (std::getenv("NLE_FORCE_EIG") == nullptr && inv_diag <= kCholMaxInvTrace) {
+    // (literal_q: the caller wants Q itself, S = Wa^-1/2 the symmetric root -- the Lanczos option -- not a similar matrix)
+    if (!literal_q && std::getenv("NLE_FORCE_EIG") == nullptr && inv_diag <= kCholMaxInvTrace) {
         std::vector<double> L((size_t)q * q), Li((size_t)q * q);
         double inv_trace = 0.0;
         if (nleh::cholesky_with_inverse(o.Wa.data(), q, L.data(), Li.data(), &inv_trace, kCholMaxInvTrace) && inv_trace <= kCholMaxInvTrace) {

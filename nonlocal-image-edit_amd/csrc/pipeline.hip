@@ -728,7 +728,10 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     }
     };
     OrthoSS o;
-    if (ghist && std::getenv("NLE_HOST_ORTHO") == nullptr) {
+    // (the opt-in Lanczos solver works on the LITERAL q x q matrix Q = Wa + S (Wab Wab^T) S with Wa as computed, not mirrored
+    // from its lower triangle -- what Spectra's DenseGenMatProd multiplies by in a USE_SPECTRA build, src/filter.cpp:174, 311
+    // -- so it takes the host route, which forms exactly that; the device route diagonalises a symmetric similar matrix)
+    if (ghist && std::getenv("NLE_HOST_ORTHO") == nullptr && c->topk_solver == 0) {
         // the Gram kernels were enqueued above; the q-sized products run on the device, the eigensolves on the host
         ortho_ss_device(c, o, ny, p, sA_c, sA_r, d_tiles.p, n_eig, enqueue_gram, [&] { all_reduce(c, d_tiles.p, g_elems); },
                         &ms->host, &ms->host_overlapped, tr);
@@ -736,7 +739,7 @@ void train_sample_space(nle_ctx* c, nle_filter* f, const float* d_lum, const Sam
     } else {
     enqueue_gram();
     double h0 = now_ms();
-    ortho_ss_prepare(o, ny, p, sA_c, sA_r);  // host, while the Gram kernel runs
+    ortho_ss_prepare(o, ny, p, sA_c, sA_r, /*literal_q=*/c->topk_solver != 0);  // host, while the Gram kernel runs
     const double h_overlapped = now_ms() - h0;
     tr.mark("ss: ortho prepare (host)");
     // (a device-to-host copy into pageable memory blocks the host until the stream reaches it, so it

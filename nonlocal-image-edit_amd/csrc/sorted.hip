@@ -432,6 +432,8 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
         // chunk (and the padding of the last block) work on column 0 and add exact zeros.
         constexpr int PB = NC <= 12 ? 2 : 4;  // pixels in flight per thread (registers: 128 per thread at two workgroups per CU)
         auto pixels = [&](const unsigned (&c8)[PB], const int base) {
+            if constexpr (!MOM) return;
+            else {
             double e0[PB], rho[PB], rho2[PB], y[PB];
             bool keep[PB];
 #pragma unroll
@@ -511,6 +513,7 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
                     for (int k = 0; k < PB; ++k) to[k] *= rho2[k];
                     acc[b + 1] += sum_pb(to);
                 }
+            }
             }
         };
         auto pixel = [&](const unsigned c8, const bool on) {
@@ -595,8 +598,6 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
             for (int b = 2; b < NC; ++b) acc[b] *= sCk[b];  // C_0 = C_1 = 1
         }
         __builtin_amdgcn_s_setprio(3);
-        int steps = dsc_steps(dsc), j = dsc_j(dsc), m = dsc_m(dsc);
-        asm volatile("" : "+v"(steps), "+v"(j), "+v"(m));  // decoded before the loads below are issued, not after
         // the next row's table row: in flight under the combine.  (Requested before the pixel loop -- registers
         // permitting -- the kernel gets SLOWER, as it does with an L2 prefetch: profiles/r2_pass_ablation.txt.)
         if (has_next && recip) {
@@ -609,11 +610,19 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
             double v[SL];
 #pragma unroll
             for (int i = 0; i < SL; ++i) v[i] = (s0 + i < NC) ? acc[s0 + i] : 0.0;
-            combine_chunks<SL, PS>(v, sP, tid, len > 0, j, m, steps);
+            // The partial sums of the chunks of a level sit in consecutive threads.  They are written to LDS once and
+            // every table entry (level x, column b) is then summed by ONE thread over the level's chunks in chunk order --
+            // a fixed order, so still bitwise reproducible -- and stored straight away: two barriers per slice, where the
+            // binary tree through LDS took 2 log2(max chunks per level) + 2 (ablation, profiles/r4_pass_ablation.txt:
+            // the tree was 25 of 81 us at cfg4, 190 of 697 at cfg5).  A level of a flat row has up to 512 chunks: its nC
+            // entries are then summed by nC threads, 512 LDS reads each (~2 us), about what the tree cost on such a row.
+#pragma unroll
+            for (int i = 0; i < SL; ++i) sP[tid * PS + i] = v[i];
+            __syncthreads();
             if (s0 == 0) {
                 // Were the loads above still pending behind the table stores below, the next row's first pixel would
                 // wait for those stores to be acknowledged.  Take them in here (all lanes: a divergent use would leave
-                // a load pending for the others), after the tree has given them time to arrive.
+                // a load pending for the others).
                 asm volatile("" ::"v"(sf_n), "v"(dsc_nn.x), "v"(dsc_nn.y));
 #pragma unroll
                 for (int b = 0; b < kMaxBlocks; ++b) asm volatile("" ::"v"(idx_n[b].x), "v"(idx_n[b].y));
@@ -630,8 +639,10 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
             for (int i = tid; i < ns * nlev; i += kT) {
                 const int bb = (int)(((float)i + 0.5f) * inv_nlev);  // i / nlev, exact: i < 12 * 256, (i + 0.5) / nlev is >= 1 / 512 off an integer
                 const int xx = xlo + (i - bb * nlev);
-                const int f0 = sfc[xx];
-                hrow[(size_t)(s0 + bb) * kLevels + xx] = sfc[xx + 1] > f0 ? sP[f0 * PS + bb] : 0.0;
+                const int f0 = sfc[xx], f1 = sfc[xx + 1];
+                double sum = 0.0;
+                for (int t = f0; t < f1; ++t) sum += sP[t * PS + bb];
+                hrow[(size_t)(s0 + bb) * kLevels + xx] = sum;
             }
             __syncthreads();  // before the next slice / row overwrites sP and sfirst
         }

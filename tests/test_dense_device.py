@@ -85,8 +85,9 @@ def test_a_device_that_cannot_run_the_persistent_reduction_falls_back_to_the_hos
     """the Householder reduction is ONE persistent launch whose workgroups must all be resident; a device with
     fewer compute units than workgroups (a partition, a smaller part) or a timed-out hand-off used to fail the whole train
     with NLE_ERR_NUMERIC although the host solver was there.  NLE_SYTRD_G=250 asks for more workgroups than the chip offers
-    (+ the 16 held back): the train must take the host solvers and give exactly what NLE_HOST_SOLVER=1 gives; the
-    stand-alone entry point, which has no host form to fall back on, reports the reason."""
+    (+ the 16 held back): the train must take the host solvers and give what NLE_HOST_WA / NLE_HOST_Q give (to rounding: the
+    matrices handed to the host solver were formed on the device on one route, on the host on the other); the stand-alone
+    entry point, which has no host form to fall back on, reports the reason."""
     import os
     H, W, nr, nc, hx, hy, T, K, L = 192, 256, 17, 18, 48.0, 30.0, 6, 24, 4          # 306 samples: above the device threshold
     x = oracle.synthetic_luminance(H, W).astype(np.float32)
@@ -104,7 +105,7 @@ def test_a_device_that_cannot_run_the_persistent_reduction_falls_back_to_the_hos
 
     ev_h, Y_h = run({"NLE_HOST_WA": "1", "NLE_HOST_Q": "1"})
     ev_f, Y_f = run({"NLE_SYTRD_G": "250"})
-    assert np.array_equal(ev_f, ev_h) and np.array_equal(Y_f, Y_h)
+    assert np.abs(ev_f - ev_h).max() <= 1e-12 and np.abs(Y_f - Y_h).max() <= 1e-6 * np.abs(Y_h).max()
     ev_d, Y_d = run({})                                                         # and the device solvers agree to rounding
     assert np.abs(ev_d - ev_h).max() <= 1e-10 and np.abs(Y_d - Y_h).max() <= 1e-3 * np.abs(Y_h).max()
     os.environ["NLE_SYTRD_G"] = "250"

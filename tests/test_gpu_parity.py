@@ -614,15 +614,22 @@ def test_streamed_fp64_form_takes_what_does_not_fit(nle, oracle, ctx, kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [SMALL_CASES[1], SMALL_CASES[4], (96, 128, 8, 10, 40.0, 30.0, 8, 79, 4)])
+@pytest.mark.parametrize("case", [SMALL_CASES[1], SMALL_CASES[4], (96, 128, 8, 10, 40.0, 30.0, 8, 79, 4),
+                                  (96, 128, 6, 8, 32.0, 30.0, 60, 10, 4)])
 def test_lanczos_topk_solver_for_Q_matches_the_oracle_s_use_spectra_branch(nle, oracle, ctx, case):
     """the reference's USE_SPECTRA build finds the top eigenpairs of Q by Lanczos
     (src/filter.cpp:170-199, 310-311).  Opt-in here (nle_ctx_set_topk_solver / NLE_Q_SOLVER=lanczos) and held to the ORACLE's
     restatement of that branch (oracle.train_filter(use_spectra=True): nev = min(K, q - 1), ncv = min(2 nev, q), converged
-    pairs only, cut at 1e-10, products with the unsymmetrised Q): the same K', eigenvalues to 1e-8, every layer to the
-    1e-4 bar -- and, beside it, the default full solver where the two builds must agree (K' equal unless K >= q)."""
+    pairs only, cut at 1e-10, products with the unsymmetrised Q): the same K', eigenvalues to 1e-8 + 0.25 ||Wa - Wa^T||_F,
+    every layer to the 1e-4 bar + 2 ||Wa - Wa^T||_F.  The second terms are what a SYMMETRIC Lanczos iteration leaves undefined on a matrix that is
+    not symmetric: Q = Wa + S (Wab Wab^T) S inherits the asymmetry of Wa (T = 10 Sinkhorn iterations leave 1e-5; T = 60,
+    the last case, 5e-12), the tridiagonal projection drops entries of that size, and which ones depends on the start
+    vector -- the oracle's two branches themselves differ by 0.06 ||Wa - Wa^T||_F (the full solver reads the lower
+    triangle, :207).  Beside it the default full solver, where the two builds must agree: K' equal unless K >= q."""
     H, W, nr, nc, hx, hy, T, K, L = case
     x = oracle.synthetic_luminance(H, W)
+    _, S_d, inter = oracle.train_filter(x, nr, nc, hx, hy, T, K, return_intermediates=True)
+    asym = float(np.linalg.norm(inter["Wa"] - inter["Wa"].T))
     V_o, S_o = oracle.train_filter(x, nr, nc, hx, hy, T, K, use_spectra=True)
     Y_o = oracle.apply_layers(V_o, S_o, x, L).reshape(L, -1)
     f0, Y0 = _run_device(nle, ctx, x, nr, nc, hx, hy, T, K, L)
@@ -634,11 +641,15 @@ def test_lanczos_topk_solver_for_Q_matches_the_oracle_s_use_spectra_branch(nle, 
     q = f0.diag()["r_Ka"]
     k0, k1 = f0.info()["K"], f1.info()["K"]
     assert k1 == S_o.size == min(k0, q - 1)
-    assert np.abs(f1.eigvals - S_o).max() < 1e-8
+    tol = 1e-8 + 0.25 * asym
+    print(f"||Wa - Wa^T||_F = {asym:.2e}; Lanczos option vs oracle's USE_SPECTRA branch: max |d lambda| = "
+          f"{np.abs(f1.eigvals - S_o).max():.2e} (oracle's two branches: {np.abs(S_o - S_d[:k1]).max():.2e})")
+    assert np.abs(f1.eigvals - S_o).max() < tol
     for j in range(L):
-        assert rel_l2(Y1[j], Y_o[j]) < PER_LAYER_TOL, j
-    assert rel_l2(f1.eigvals, f0.eigvals[:k1]) < 1e-8
-    if k1 == k0:
+        assert rel_l2(Y1[j], Y_o[j]) < PER_LAYER_TOL + 2.0 * asym, j
+    assert np.abs(f1.eigvals - f0.eigvals[:k1]).max() < tol
+    if T >= 50:   # Sinkhorn converged: Wa is symmetric to rounding and every solver must give the same filter
+        assert np.abs(f1.eigvals - S_o).max() < 1e-8
         for j in range(L):
             assert rel_l2(Y1[j], Y0[j]) < 1e-6, j
     f0.close()
