@@ -464,7 +464,13 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
         // (see ortho_ss_prepare for why any root of the pseudo-inverse serves and when Cholesky is admissible)
         build_Wa_host();
         nd = 0;
-        if (!dev_wa && !force_eig && inv_diag <= kCholMaxInvTrace) {
+        // A Cholesky attempt first only for small q: its small pivots come last, so on a matrix that does have eigenvalues
+        // below the cut -- ten of the reference's eleven README runs, every benchmark config -- it costs most of a
+        // factorisation before it proves futile (0.24 ms at q = 200).  From q = 64 on the eigenvalues come first and decide,
+        // as on the device route; none below the cut is then the deflated route with nothing to deflate, i.e. the same
+        // Cholesky factor.
+        const bool attempt_chol = q < 64 || std::getenv("NLE_NO_DEFLATE") != nullptr || q >= 512;
+        if (!dev_wa && !force_eig && attempt_chol && inv_diag <= kCholMaxInvTrace) {
             L.resize(qq);
             Li.resize(qq);
             double inv_trace = 0.0;
@@ -481,7 +487,7 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
         if (!dev_wa && !chol_wa && std::getenv("NLE_FORCE_EIG") == nullptr && std::getenv("NLE_NO_DEFLATE") == nullptr && q >= 16 && q < 512) {
             std::vector<double> Dall(q), Vd((size_t)q * (max_defl + 1));
             int kept = 0;
-            tr.mark("ss:   Wa built, Cholesky attempt");
+            tr.mark(attempt_chol ? "ss:   Wa built, Cholesky attempt" : "ss:   Wa built");
             if (nleh::sym_eigen_select(o.Wa.data(), q, Dall.data(), 0, 0, Vd.data(), NLE_EPS, max_defl, &kept)) {
                 tr.mark("ss:   Wa eigenvalues + dropped eigenvectors");
                 nd = q - kept;
@@ -524,7 +530,8 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
                             for (int k = 0; k < q; ++k)
                                 for (int a = 0; a < q; ++a) Fdefl[(size_t)k * q + a] -= v[a] * wv[k];
                         }
-                        deflated = true;
+                        deflated = nd > 0;
+                        chol_wa = nd == 0;  // nothing below the cut: F = L^-T of Wa itself
                         r2 = kept;
                         if (std::getenv("NLE_TRACE"))
                             fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e), %d deflated\n",

@@ -415,6 +415,17 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
             sf_n = first[(size_t)nrow * 258 + (tid < 258 ? tid : 257)];
             load_idx(idx_n, nrow, dsc_n);
         }
+        // MOM: the next row's table row too.  With it requested only after the loop, a workgroup's row is loop (2 us of
+        // arithmetic) + a memory round trip + combine + stores (5-7 us of waiting): two workgroups per CU keep the vector
+        // units busy for less than half of that.  The moment form leaves the registers for it (no column factor is kept).
+        constexpr bool PRE = MOM && (NC <= 11 || (NC > 12 && NC <= 24));  // where the registers allow it without spilling
+        double gvn[PRE ? NC : 1];
+        if constexpr (PRE) {
+            if (has_next && recip) {
+#pragma unroll
+                for (int b = 0; b < NC; ++b) gvn[b] = g[(size_t)nrow * n + b * kLevels + dsc_level(dsc_n)];
+            }
+        }
         // One pixel at a time (the column factors of one pixel fill the registers; the scheduling barrier keeps the
         // unrolled bodies from being interleaved), up to the longest chunk of the WAVE: a scalar bound, so that a wave
         // whose chunks are all short skips the rest without per-lane bookkeeping.  Lanes past their own chunk add zeros.
@@ -430,7 +441,8 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
         // SIMD their LATENCY, not their issue rate, is what the loop costs; four independent pixels give the scheduler
         // 8-16 chains to interleave, and the state of a pixel is 8 doubles now that no e_b is kept.  Lanes past their own
         // chunk (and the padding of the last block) work on column 0 and add exact zeros.
-        constexpr int PB = NC <= 12 ? 2 : 4;  // pixels in flight per thread (registers: 128 per thread at two workgroups per CU)
+        constexpr int PB = NC > 0 ? 1 : 2;  // pixels in flight per thread: interleaving 2 / 4 bought nothing (profiles/r4_pass_ablation.txt);
+                               // one leaves the registers for the next row's table row, requested BEFORE the loop (below)
         auto pixels = [&](const unsigned (&c8)[PB], const int base) {
             if constexpr (!MOM) return;
             else {
@@ -493,7 +505,8 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
             // moments: acc_b += sum_k y_k e_0k rho_k^b, even and odd chains per pixel, the pixels summed pairwise
             auto sum_pb = [](const double (&t)[PB]) {
                 if constexpr (PB == 4) return (t[0] + t[1]) + (t[2] + t[3]);
-                else return t[0] + t[1];
+                else if constexpr (PB == 2) return t[0] + t[1];
+                else return t[0];
             };
             double te[PB], to[PB];
 #pragma unroll
@@ -559,13 +572,23 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
                     const unsigned c8[PB] = {idx[b].x & 0xffffu, idx[b].x >> 16, idx[b].y & 0xffffu, idx[b].y >> 16};
                     pixels(c8, 4 * b);
                     NLE_PIXEL_FENCE();
-                } else {
+                } else if constexpr (PB == 2) {
                     const unsigned c8a[PB] = {idx[b].x & 0xffffu, idx[b].x >> 16}, c8b[PB] = {idx[b].y & 0xffffu, idx[b].y >> 16};
                     pixels(c8a, 4 * b);
                     NLE_PIXEL_FENCE();
                     if (4 * b + 2 < wlen) {
                         pixels(c8b, 4 * b + 2);
                         NLE_PIXEL_FENCE();
+                    }
+                } else {
+                    const unsigned cs4[4] = {idx[b].x & 0xffffu, idx[b].x >> 16, idx[b].y & 0xffffu, idx[b].y >> 16};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (4 * b + k < wlen) {
+                            const unsigned c8one[PB] = {cs4[k]};
+                            pixels(c8one, 4 * b + k);
+                            NLE_PIXEL_FENCE();
+                        }
                     }
                 }
             }
@@ -601,8 +624,13 @@ __global__ __launch_bounds__(kT, (NC <= 12 ? 4 : 2)) void k_sorted_pass(int mode
         // the next row's table row: in flight under the combine.  (Requested before the pixel loop -- registers
         // permitting -- the kernel gets SLOWER, as it does with an L2 prefetch: profiles/r2_pass_ablation.txt.)
         if (has_next && recip) {
+            if constexpr (PRE) {
 #pragma unroll
-            for (int b = 0; b < NC; ++b) gv[b] = g[(size_t)nrow * n + b * kLevels + dsc_level(dsc_n)];
+                for (int b = 0; b < NC; ++b) gv[b] = gvn[b];
+            } else {
+#pragma unroll
+                for (int b = 0; b < NC; ++b) gv[b] = g[(size_t)nrow * n + b * kLevels + dsc_level(dsc_n)];
+            }
         }
         double* hrow = hout + (size_t)lrow * n;
 #pragma unroll
