@@ -391,12 +391,15 @@ def test_host_buffer_entry_points_match_the_device_ones(nle, oracle, ctx, pinned
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["noise", "flat", "two-level", "tiny", "wide20", "wide36"])
+@pytest.mark.parametrize("kind", ["noise", "flat", "two-level", "tiny", "wide20", "wide36", "mixed", "mixed4k"])
 def test_level_sorted_rows_agree_with_the_histogram_kernels_and_are_bitwise_reproducible(nle, oracle, kind):
     """sorted.hip (level-sorted rows, register accumulation, fixed combine tree) against the LDS-atomic histogram
     kernels it replaces (NLE_NO_SORTED_ROWS=1), on images that stress the chunking: noise, one flat level (every
     thread of a row on one level), a two-level checkerboard, and an image narrower than a workgroup.  The sorted form
-    has no atomics, so two runs must agree bit for bit."""
+    has no atomics, so two runs must agree bit for bit.  "mixed": flat rows (a level of more than 64 chunks: the pass
+    kernel's eight waves meet at a barrier) interleaved with noisy and smooth rows (wave-aligned chunks: every wave
+    combines its own levels, no barrier, the waves drift apart) -- the two kinds of row alternate inside one workgroup's
+    row list; "mixed4k" the same at 4096 columns, two workgroups per CU and eight rows per workgroup."""
     rng = np.random.default_rng(5)
     if kind == "tiny":
         H, W, nr, nc = 40, 37, 4, 5
@@ -406,7 +409,15 @@ def test_level_sorted_rows_agree_with_the_histogram_kernels_and_are_bitwise_repr
         H, W, nr, nc = 150, 700, 4, 36
     else:
         H, W, nr, nc = 150, 700, 6, 10
-    if kind in ("noise", "tiny", "wide20", "wide36"):
+    if kind == "mixed4k":
+        H, W, nr, nc = 2100, 4096, 6, 10
+    if kind in ("mixed", "mixed4k"):
+        x = rng.integers(0, 256, (H, W)).astype(np.float32)
+        x[1::3] = 97.0                                        # flat rows ...
+        x[1::3, ::5] = 140.0
+        cc = np.arange(W, dtype=np.float32)[None, :]
+        x[2::3] = np.clip(np.rint(100.0 + 60.0 * np.sin(cc / 97.0) + rng.integers(-12, 13, x[2::3].shape)), 0, 255)   # ... and smooth + noise ones
+    elif kind in ("noise", "tiny", "wide20", "wide36"):
         x = rng.integers(0, 256, (H, W)).astype(np.float32)
     elif kind == "flat":
         x = np.full((H, W), 97.0, dtype=np.float32)
@@ -438,14 +449,14 @@ def test_level_sorted_rows_agree_with_the_histogram_kernels_and_are_bitwise_repr
     assert rel_l2(ev1, ev0) < 1e-9
     for j in range(L):
         assert rel_l2(Y1[j], Y0[j]) < 1e-6, (kind, j)
-    # column factors by recurrence (two table reads per pixel: the default for more than 12 sample columns, where it is
-    # safe) against all of them read from the table (NLE_SORTED_TABLE=1): O(nC^2) ulp apart
+    # the pass kernel on moments (two table reads per pixel, the default where no power leaves fp64's normal range) / column
+    # factors by recurrence, against all column factors read from the table (NLE_SORTED_TABLE=1): O(nC^2) ulp apart
     os.environ["NLE_SORTED_TABLE"] = "1"
     try:
         ev3, Y3 = run()
     finally:
         del os.environ["NLE_SORTED_TABLE"]
-    assert rel_l2(ev1, ev3) < 1e-11, rel_l2(ev1, ev3)
+    assert rel_l2(ev1, ev3) < 1e-10, rel_l2(ev1, ev3)   # (1.2e-11 on the ill-conditioned "mixed" image, 1e-13 on noise)
     for j in range(L):
         assert rel_l2(Y1[j], Y3[j]) < 1e-7, (kind, j, rel_l2(Y1[j], Y3[j]))
 
