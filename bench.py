@@ -461,6 +461,31 @@ def main():
                        "page-locked host memory, one image at a time (nle_train_host + nle_apply_layers_host)"
                        + ("; per rank: its own rows up, its own rows of the layers down; max over ranks" if world > 1 else ""),
                "matches_device_resident_output": same, "max_rel_diff_vs_device_resident_output": h2h_diff}
+        # the same path with what `enhance` actually brings home (src/filter.cpp:428-436): the weighted sum of the layers,
+        # clamped and rounded to ONE 8-bit plane on the device (nle_apply_u8_host) -- N bytes down instead of 4 L N
+        wts = {4: [2.0, 3.0, 4.0, 1.0], 6: [2.0, 3.0, 3.0, 4.0, 4.0, 1.0]}.get(L, [2.0] * (L - 1) + [1.0])
+        h_u8 = ctx.host_alloc((n_local,), dtype=np.uint8)
+        ts8 = []
+        for it in range(2 + args.h2h_runs):
+            fence()
+            t1 = time.perf_counter()
+            f2.train_filter_host(h_lum, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"], shape=(H, W))
+            f2.apply_u8_host(None, nle.transform_eigenvalues(f2.eigvals, wts), h_u8)
+            ts8.append(time.perf_counter() - t1)
+        ts8 = ts8[2:]
+        if dist is not None:
+            tt = torch.tensor(ts8, dtype=torch.float64, device=lum.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ts8 = tt.tolist()
+        want8 = torch.round(torch.clamp(sum(float(w_) * out[j] for j, w_ in enumerate(wts)), 0, 255))
+        d8 = (want8 - torch.as_tensor(h_u8, device=lum.device).float()).abs()
+        med8 = float(np.median(ts8))
+        h2h["u8_plane"] = {"value": (H * W / 1e6) / med8, "unit": "MP/s", "ms_median": med8 * 1e3, "ms_min": min(ts8) * 1e3,
+                           "runs": len(ts8), "bytes_h2d": int(h_lum.nbytes), "bytes_d2h": int(h_u8.nbytes), "weights": wts,
+                           "what": "the same host plane -> train -> ONE clamped, rounded 8-bit plane of the weighted layer sum back in "
+                                   "host memory (nle_train_host + nle_apply_u8_host): what NLEFilter::enhance merges back",
+                           "pixels_differing_from_the_rounded_sum_of_the_fp32_layers": int((d8 > 0).sum().item()),
+                           "max_level_difference": float(d8.max().item())}
         f2.close()
 
     # ---- roofline of the dominant kernel (this rank's launches)

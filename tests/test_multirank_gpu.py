@@ -285,3 +285,41 @@ def test_aborted_communicator_fails_collectives_until_rebound(nle, oracle):
     assert np.array_equal(f.apply_layers(x, L).cpu().numpy(), Y0)
     f.close()
     c.close()
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_emits_the_multi_gpu_line(tmp_path):
+    """The driver runs `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` on an 8-GPU node that this
+    round never sees.  Rehearsal on ONE GPU: two ranks over gloo, both on cuda:0 (--same-device; the all-reduces go through
+    the torch.distributed callback instead of RCCL, which cannot put two ranks on one device), on cfg2 so that it takes
+    seconds.  Asserts the plumbing the first real run depends on: exit code 0, exactly one JSON line from rank 0, the bench
+    contract's keys, the N > 1 legs (`shard_check` against the single-GPU result, `replicas`, slab-input `host_to_host`
+    with its one-plane figure) and `value` = pixels of the whole image over the slowest rank's time."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--config", "cfg2", "--backend", "gloo", "--same-device", "--h2h-runs", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "host_to_host", "replicas", "shard_check", "rccl_ranks",
+              "comm", "slab_input", "kernels"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "MP/s" and d["higher_is_better"] is True
+    assert d["scaling"] == "strong" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "cfg2" in d["config"]["workload"] and "row-slab x2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 512 * 512 / 1e6 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["shard_check"]["matches"] is True and d["shard_check"]["max_rel_l2_per_layer_vs_single_gpu"] <= 1e-6
+    assert d["slab_input"] is True and d["rccl_ranks"] == 0 and "callback" in d["comm"]          # gloo rehearsal: no RCCL
+    assert d["cpu_baseline"] is None                                                             # N = 1 only
+    assert d["replicas"]["scaling"] == "weak" and d["replicas"]["value"] > 0
+    h = d["host_to_host"]
+    assert h["matches_device_resident_output"] is True and h["value"] > 0 and h["u8_plane"]["value"] > 0
+    assert h["u8_plane"]["bytes_d2h"] * 4 * 4 == h["bytes_d2h"]                                  # one byte per pixel instead of L floats
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1.5
