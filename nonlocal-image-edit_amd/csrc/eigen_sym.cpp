@@ -703,11 +703,145 @@ NLE_SIMD_CLONES void gemm_tn_cols(const double* A, const double* B, double* C, i
         }
 }
 
+// ---- blocked Cholesky factor and inverse of a p x p matrix on one core (what the train path runs on Ka and on Wa's deflated
+// matrix below 288 samples: 0.45 + 0.33 ms of a 7 ms cfg4 step with the rank-1 / column-sweep forms above, which stream the
+// matrix from L2 once per column).  Register-blocked tiles (16 rows x 6 columns, the k loop innermost) on explicit leading
+// dimensions; triangular operands only trim the k range of a tile.
+namespace {
+// C[i0 .. i0 + 8 RV) x [j .. j + NR) += sign * sum_{l in [l0, l1)} A(i, l) B(l, j + q);  B(l, c) = TB ? B[c + l ldb] : B[l + c ldb]
+template <int RV, int NR, bool TB>
+static inline __attribute__((always_inline)) void mk_tile(double sign, const double* A, int lda, const double* B, int ldb, double* C,
+                                                          int ldc, int i0, int j, int l0, int l1) {
+    v8d acc[RV][NR];
+#pragma GCC unroll 2
+    for (int r = 0; r < RV; ++r)
+#pragma GCC unroll 6
+        for (int q = 0; q < NR; ++q) acc[r][q] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int l = l0; l < l1; ++l) {
+        v8d a[RV];
+#pragma GCC unroll 2
+        for (int r = 0; r < RV; ++r) a[r] = ld8(A + (size_t)l * lda + i0 + 8 * r);
+#pragma GCC unroll 6
+        for (int q = 0; q < NR; ++q) {
+            const double b = TB ? B[(size_t)l * ldb + j + q] : B[(size_t)(j + q) * ldb + l];
+#pragma GCC unroll 2
+            for (int r = 0; r < RV; ++r) acc[r][q] += a[r] * b;
+        }
+    }
+#pragma GCC unroll 2
+    for (int r = 0; r < RV; ++r)
+#pragma GCC unroll 6
+        for (int q = 0; q < NR; ++q) {
+            double* c = C + (size_t)(j + q) * ldc + i0 + 8 * r;
+            st8(c, ld8(c) + sign * acc[r][q]);
+        }
+}
+// C (m x n, ldc) += sign * A (m x k, lda) * op(B).  lower_c: only tiles that touch the lower triangle of a square C are
+// computed (entries above the diagonal inside such a tile are touched too: the caller does not keep anything there);
+// a_lower: A is square lower triangular (A(i, l) = 0 for l > i);  b_lower: op(B) is lower triangular (B(l, c) = 0 for l < c).
+template <bool TB>
+static inline __attribute__((always_inline)) void mk_gemm(double sign, const double* A, int lda, const double* B, int ldb, double* C, int ldc,
+                                                         int m, int n, int k, bool lower_c, bool a_lower, bool b_lower) {
+    for (int j = 0; j < n; j += 6) {
+        const int nr = std::min(6, n - j);
+        const int l0 = b_lower ? j : 0;
+        int i0 = lower_c ? (j / 16) * 16 : 0;
+        for (; i0 < m; i0 += 16) {
+            const int rows = std::min(16, m - i0);
+            const int l1 = a_lower ? std::min(k, i0 + rows) : k;
+            if (l1 <= l0) continue;
+            if (rows == 16 && nr == 6) {
+                mk_tile<2, 6, TB>(sign, A, lda, B, ldb, C, ldc, i0, j, l0, l1);
+            } else if (rows >= 8 && nr == 6) {
+                mk_tile<1, 6, TB>(sign, A, lda, B, ldb, C, ldc, i0, j, l0, l1);
+                for (int i = i0 + 8; i < i0 + rows; ++i)
+                    for (int q = 0; q < nr; ++q) {
+                        double sacc = 0.0;
+                        for (int l = l0; l < l1; ++l) sacc += A[(size_t)l * lda + i] * (TB ? B[(size_t)l * ldb + j + q] : B[(size_t)(j + q) * ldb + l]);
+                        C[(size_t)(j + q) * ldc + i] += sign * sacc;
+                    }
+            } else {
+                for (int i = i0; i < i0 + rows; ++i)
+                    for (int q = 0; q < nr; ++q) {
+                        double sacc = 0.0;
+                        for (int l = l0; l < l1; ++l) sacc += A[(size_t)l * lda + i] * (TB ? B[(size_t)l * ldb + j + q] : B[(size_t)(j + q) * ldb + l]);
+                        C[(size_t)(j + q) * ldc + i] += sign * sacc;
+                    }
+            }
+        }
+    }
+}
+
+// right-looking blocked Cholesky on the lower triangle (column-major, leading dimension n): 32 columns at a time by the
+// rank-1 form restricted to the block's columns, the trailing matrix by one tile product per block.  The strict upper
+// triangle is used as scratch by the tiles on the diagonal and zeroed at the end.  min_pivot as in cholesky_lower.
+NLE_SIMD_CLONES bool cholesky_lower_blocked(int n, double* A, double min_pivot) {
+    constexpr int NB = 32;
+    if (n < 96) return cholesky_lower(n, A, min_pivot);
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int kb = std::min(NB, n - k0), kend = k0 + kb, m = n - kend;
+        for (int j = k0; j < kend; ++j) {
+            const double djj = at(A, n, j, j);
+            if (!(djj > min_pivot)) return false;
+            const double d = std::sqrt(djj), inv = 1.0 / d;
+            double* cj = &at(A, n, 0, j);
+            cj[j] = d;
+#pragma omp simd
+            for (int i = j + 1; i < n; ++i) cj[i] *= inv;
+            for (int k = j + 1; k < kend; ++k) {
+                const double l = cj[k];
+                double* ck = &at(A, n, 0, k);
+#pragma omp simd
+                for (int i = k; i < n; ++i) ck[i] -= l * cj[i];
+            }
+        }
+        if (m > 0)  // A22 -= L21 L21^T, lower tiles only
+            mk_gemm<true>(-1.0, &at(A, n, kend, k0), n, &at(A, n, kend, k0), n, &at(A, n, kend, kend), n, m, m, kb, true, false, false);
+    }
+    for (int c = 1; c < n; ++c)
+        for (int r = 0; r < c; ++r) at(A, n, r, c) = 0.0;
+    return true;
+}
+
+// X = L^-1 (both n x n lower triangular, leading dimensions ldl / ldx; X's block must be zero on entry): halves recursively,
+// [L11 0; L21 L22]^-1 = [X11 0; -X22 (L21 X11) X22], the two products on the tile kernel with the triangles' zeros skipped
+NLE_SIMD_CLONES void lower_inverse_blocked(int n, const double* L, int ldl, double* X, int ldx, double* tmp) {
+    if (n <= 32) {
+        for (int j = 0; j < n; ++j) {
+            double* x = X + (size_t)j * ldx;
+            x[j] = 1.0;
+            for (int k = j; k < n; ++k) {
+                const double* lk = L + (size_t)k * ldl;
+                const double xk = x[k] / lk[k];
+                x[k] = xk;
+#pragma omp simd
+                for (int i = k + 1; i < n; ++i) x[i] -= xk * lk[i];
+            }
+        }
+        return;
+    }
+    const int n1 = ((n / 2) + 15) & ~15, n2 = n - n1;
+    lower_inverse_blocked(n1, L, ldl, X, ldx, tmp);
+    lower_inverse_blocked(n2, L + (size_t)n1 * ldl + n1, ldl, X + (size_t)n1 * ldx + n1, ldx, tmp);
+    // T (n2 x n1) = L21 X11 ;  X21 = -X22 T
+    double* T = tmp;
+    for (size_t i = 0; i < (size_t)n2 * n1; ++i) T[i] = 0.0;
+    mk_gemm<false>(1.0, L + n1, ldl, X, ldx, T, n2, n2, n1, n1, false, false, true);
+    mk_gemm<false>(-1.0, X + (size_t)n1 * ldx + n1, ldx, T, n2, X + n1, ldx, n2, n1, n2, false, true, false);
+}
+}  // namespace
+
 bool cholesky_with_inverse(const double* M, int n, double* L, double* Linv, double* inv_trace, double max_inv_trace) {
     for (int c = 0; c < n; ++c)
         for (int r = 0; r < n; ++r) L[(size_t)c * n + r] = (r >= c) ? M[(size_t)c * n + r] : 0.0;
-    if (!cholesky_lower(n, L, max_inv_trace > 0.0 ? 1.0 / max_inv_trace : 0.0)) return false;
-    lower_inverse(n, L, Linv);
+    if (!cholesky_lower_blocked(n, L, max_inv_trace > 0.0 ? 1.0 / max_inv_trace : 0.0)) return false;
+    if (n < 96) {
+        lower_inverse(n, L, Linv);
+    } else {
+        for (size_t i = 0; i < (size_t)n * n; ++i) Linv[i] = 0.0;
+        std::vector<double> tmp((size_t)(n / 2 + 16) * (n / 2 + 16));
+        lower_inverse_blocked(n, L, n, Linv, n, tmp.data());
+    }
     double t = 0.0;
     for (size_t i = 0; i < (size_t)n * n; ++i) t += Linv[i] * Linv[i];
     *inv_trace = t;
