@@ -9,5 +9,5 @@ rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --mode 1 --steps 2 --warmup 1 > $OUT/trace.log 2>&1 || { tail -20 $OUT/trace.log; exit 1; }
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ROOT/bench.py --no-cpu-baseline --mode 1 --steps 2 --warmup 1 > $OUT/pmc_mfma.log 2>&1 || { tail -20 $OUT/pmc_mfma.log; exit 1; }
-tail -1 $OUT/trace.log > $OUT/bench.json
+grep '^{"metric"' $OUT/trace.log | tail -1 > $OUT/bench.json   # the bench line, not rocprofv3's last log line
 find $OUT -name '*.csv' | head
