@@ -289,6 +289,10 @@ int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, 
  * convertTo(CV_8U) (round half to even, saturate) -- n_local BYTES instead of L fp32 planes: what `enhance` needs back from
  * the device (16 MB instead of 268 MB at 4096^2, four weights).  Device and host-buffer forms; h_x == NULL as above. */
 int nle_apply_u8(nle_filter* f, const float* d_x, int H, int W, const double* h_fS, unsigned char* d_out);
+/* the same plane as fp32 holding the 8-bit levels (the replacement-channel argument of nle_lab2bgr8 / _planes).  On the
+ * default path the clamp and the round-half-even act on the fp64 value of the filtered plane, before anything is rounded
+ * to fp32: `enhance` then rounds as the reference's fp64 pipeline does, not an fp32 plane's ties. */
+int nle_apply_rounded8(nle_filter* f, const float* d_x, int H, int W, const double* h_fS, float* d_y);
 int nle_apply_u8_host(nle_filter* f, const float* h_x, int H, int W, const double* h_fS, unsigned char* h_out);
 
 /* ---- colour wrapper on the device (the code either side of the path) ------------------------------- */

@@ -315,15 +315,24 @@ class Context:
                                           C.byref(r)), self._h)
         return np.ascontiguousarray(U[:, :count]), D, r.value
 
-    def cholesky_device(self, M):
-        """(L, L^-1, trace(M^-1), ok) of a symmetric matrix (lower triangle read) on the GPU (nle_cholesky_device)"""
+    def cholesky_device(self, M, out=None):
+        """(L, L^-1, trace(M^-1), ok) of a symmetric matrix (lower triangle read) on the GPU (nle_cholesky_device).
+        out = (L, Linv): caller's n x n float64 buffers (flat or 2-D, e.g. page-locked from host_alloc), filled
+        COLUMN-major and returned as they are"""
         M = np.asfortranarray(np.asarray(M, dtype=np.float64))
         n = M.shape[0]
-        L = np.zeros((n, n), dtype=np.float64, order="F")
-        Li = np.zeros((n, n), dtype=np.float64, order="F")
+        if out is None:
+            L = np.zeros((n, n), dtype=np.float64, order="F")
+            Li = np.zeros((n, n), dtype=np.float64, order="F")
+        else:
+            L, Li = out
+            if any(a.dtype != np.float64 or a.size != n * n for a in (L, Li)):
+                raise NLEError(NLE_ERR_INVALID, "cholesky_device: out buffers must hold n * n float64 values")
         tr = C.c_double()
         ok = C.c_int()
         _check(lib().nle_cholesky_device(self._h, _np_ptr(M), n, _np_ptr(L), _np_ptr(Li), C.byref(tr), C.byref(ok)), self._h)
+        if out is not None:
+            return L, Li, tr.value, bool(ok.value)
         return np.ascontiguousarray(L), np.ascontiguousarray(Li), tr.value, bool(ok.value)
 
     def set_slab_input(self, on: bool = True):
@@ -643,6 +652,21 @@ class NLEFilter:
         if not (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.flags.c_contiguous and out.size == n_local):
             raise NLEError(NLE_ERR_INVALID, f"apply_u8_host: out must be a C-contiguous uint8 array of {n_local} values")
         _check(lib().nle_apply_u8_host(self._f, xp, H, W, _np_ptr(fs), _np_ptr(out)), self.ctx._h)
+        return out
+
+    def apply_rounded8(self, x, f_s, out=None):
+        """nle_apply_rounded8: the clamped, rounded plane as fp32 levels (the replacement-channel argument of lab2bgr8)"""
+        torch = _torch()
+        x = self.ctx._lum(x)
+        H, W = self._full_shape(x, self.shape)
+        fs = np.ascontiguousarray(f_s, dtype=np.float64)
+        if fs.ndim != 1 or fs.size != self.info()["K"]:
+            raise NLEError(NLE_ERR_INVALID, f"f_s must hold K' = {self.info()['K']} values, got {fs.shape}")
+        n = self.info()["n_local"]
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=x.device)
+        _check(lib().nle_apply_rounded8(self._f, C.c_void_p(x.data_ptr()), H, W, _np_ptr(fs), C.c_void_p(out.data_ptr())),
+               self.ctx._h)
         return out
 
     def apply_u8(self, x, f_s, out=None):

@@ -137,6 +137,15 @@ hipError_t plane_to_u8(hipStream_t s, const float* d_y, long long n, unsigned ch
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void k_u8_to_plane(const unsigned char* __restrict__ in, long long n, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = (float)in[i];
+}
+hipError_t channel8_plane(hipStream_t s, const unsigned char* d_u8, long long n, float* d_out) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_u8_to_plane, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, s, d_u8, n, d_out);
+    return hipGetLastError();
+}
+
 // ---- cv::bilateralFilter on a single-channel 8-bit plane (d = -1, BORDER_DEFAULT), as the denoise wrapper
 // calls it (src/filter.cpp:371,535).  OpenCV's documented algorithm for CV_8UC1: radius = round(1.5 sigma_space)
 // (at least 1), circular window, weight = space[dy,dx] * colour[|v - v0|] from two fp32 tables, fp32 sums in

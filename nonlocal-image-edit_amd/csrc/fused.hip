@@ -1135,7 +1135,7 @@ template <int NC>
 __global__ __launch_bounds__(kDotThreads) void k_hist_dot(const float* __restrict__ lum, GridSpec gs, int row0,
                                                           const double* __restrict__ ecT, const double* __restrict__ g,
                                                           size_t gstride, int nl, const double* __restrict__ cvec,
-                                                          float* __restrict__ out, long long ostride) {
+                                                          float* __restrict__ out, long long ostride, int round8) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int n = kLevels * NC;
     constexpr int NS = NC | 1;  // odd row stride, as in k_hist_pix
@@ -1163,7 +1163,9 @@ __global__ __launch_bounds__(kDotThreads) void k_hist_dot(const float* __restric
                 if (b & 1) s1 += e[b] * t[b];
                 else s0 += e[b] * t[b];
             }
-            out[(size_t)l * ostride + (size_t)lrow * W + c] = (float)(cv * (s0 + s1));
+            double v = cv * (s0 + s1);
+            if (round8) v = rint(fmin(255.0, fmax(0.0, v)));  // src/filter.cpp:434-436 on the fp64 value (k_sorted_expand)
+            out[(size_t)l * ostride + (size_t)lrow * W + c] = (float)v;
         }
     }
 }
@@ -1224,11 +1226,13 @@ __global__ __launch_bounds__(256) void k_apply_small(int p, int K, int ldk, int 
 
 // Y[l][loc[a]] = YA[l][a] for the samples this rank owns (loc < 0: not local)
 __global__ void k_scatter_samples(int p, int L, const long long* __restrict__ loc, const double* __restrict__ YA,
-                                  float* __restrict__ Y, long long ystride) {
+                                  float* __restrict__ Y, long long ystride, int round8) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= L * p) return;
     const int l = o / p, a = o - l * p;
-    if (loc[a] >= 0) Y[(size_t)l * ystride + loc[a]] = (float)YA[o];
+    double v = YA[o];
+    if (round8) v = rint(fmin(255.0, fmax(0.0, v)));
+    if (loc[a] >= 0) Y[(size_t)l * ystride + loc[a]] = (float)v;
 }
 
 // HH[slab][a][col] = sum over the slab's image rows of er[r][a] h[r][col], col = x*nC + b: per slab a
@@ -1425,7 +1429,7 @@ int apply_layers_per_launch(GridSpec gs) {
 hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
                              const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_wl, int ldw,
                              int nl, const double* d_c, double* d_ws, float* d_out, long long ostride,
-                             LaunchObserver* obs, const SortedRows* sorted) {
+                             LaunchObserver* obs, const SortedRows* sorted, bool round8) {
     const int nC = gs.nSelCols, nR = gs.nSelRows;
     if (nC > 36 || nR > 32 || nrows_local <= 0) return nrows_local <= 0 ? hipSuccess : hipErrorInvalidValue;
     const bool use_sorted = sorted != nullptr && nC <= sorted_expand_max_cols() && gs.W <= sorted_expand_max_width() &&
@@ -1441,7 +1445,7 @@ hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int
     if (obs) obs->end(), obs->begin(SUB_HIST_PIX);
     if (use_sorted) {
         hipError_t ex = sorted_expand(s, gs, nrows_local, sorted->scol, sorted->desc, sorted->E, d_ws, gstride, nl, d_c, d_out,
-                                      ostride, sorted->rec, sorted->kappa);
+                                      ostride, sorted->rec, sorted->kappa, round8);
         if (obs) obs->end();
         return ex;
     }
@@ -1454,7 +1458,7 @@ hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int
             if (ea != hipSuccess) return ea;                                                                         \
         }                                                                                                            \
         hipLaunchKernelGGL((k_hist_dot<NCV>), dim3((unsigned)nrows_local), dim3(kDotThreads), shm_d, s, d_lum, gs,   \
-                           row0, d_ecT, d_ws, gstride, nl, d_c, d_out, ostride);                                     \
+                           row0, d_ecT, d_ws, gstride, nl, d_c, d_out, ostride, round8 ? 1 : 0);                     \
     } break;
     switch (nC) {
         NLE_HD(1) NLE_HD(2) NLE_HD(3) NLE_HD(4) NLE_HD(5) NLE_HD(6) NLE_HD(7) NLE_HD(8) NLE_HD(9) NLE_HD(10) NLE_HD(11)
@@ -1478,9 +1482,9 @@ hipError_t apply_small(hipStream_t s, int p, int K, int ldk, int L, int ldw, con
 }
 
 hipError_t scatter_samples(hipStream_t s, int p, int L, const long long* d_loc, const double* d_YA, float* d_Y,
-                           long long ystride) {
+                           long long ystride, bool round8) {
     hipLaunchKernelGGL(k_scatter_samples, dim3((unsigned)((L * p + 255) / 256)), dim3(256), 0, s, p, L, d_loc, d_YA, d_Y,
-                       ystride);
+                       ystride, round8 ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -226,7 +226,7 @@ int sorted_expand_max_width();
 int sorted_expand_layers(GridSpec gs);
 hipError_t sorted_expand(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
                          const double* d_E, const double* d_g, size_t gstride, int nl, const double* d_cvec, float* d_out,
-                         long long ostride, bool rec = false, double kappa = 0.0);
+                         long long ostride, bool rec = false, double kappa = 0.0, bool round8 = false);
 hipError_t dist_table(hipStream_t s, int W, double hx, double* d_E);
 hipError_t sort_rows(hipStream_t s, const float* d_lum, GridSpec gs, int row0, int nrows_local, unsigned short* d_scol,
                      uint2* d_desc, unsigned short* d_first);
@@ -254,12 +254,12 @@ int apply_layers_per_launch(GridSpec gs);
 hipError_t apply_hist_layers(hipStream_t s, const float* d_lum, GridSpec gs, int p, int row0, int nrows_local,
                              const double* d_er, const double* d_ecT, const double* d_Ep, const double* d_wl, int ldw,
                              int nl, const double* d_c, double* d_ws, float* d_out, long long ostride,
-                             LaunchObserver* obs, const SortedRows* sorted = nullptr);
+                             LaunchObserver* obs, const SortedRows* sorted = nullptr, bool round8 = false);
 hipError_t apply_small(hipStream_t s, int p, int K, int ldk, int L, int ldw, const double* d_m, const double* d_D,
                        const double* d_Vrows, const double* d_xA /* x at the p sample pixels */, const double* d_resp,
                        double* d_t, double* d_Wp, double* d_YA);
 hipError_t scatter_samples(hipStream_t s, int p, int L, const long long* d_loc, const double* d_YA, float* d_Y,
-                           long long ystride);
+                           long long ystride, bool round8 = false);  // round8: clamp to [0, 255], round half to even, in fp64
 
 // Gram in sample space through the same tables (quantised luminance, nSelCols <= ghist_max_cols())
 int ghist_max_cols();
@@ -282,6 +282,7 @@ hipError_t lab2bgr8(hipStream_t s, const unsigned char* d_lab, const float* d_L,
 hipError_t channel8(hipStream_t s, const unsigned char* d_img, long long n, int ch, float* d_out);
 // cv::max(y, 0) / cv::min(y, 255) / convertTo(CV_8U) of a filtered plane (src/filter.cpp:434-436): round half to even
 hipError_t plane_to_u8(hipStream_t s, const float* d_y, long long n, unsigned char* d_out);
+hipError_t channel8_plane(hipStream_t s, const unsigned char* d_u8, long long n, float* d_out);  // bytes -> fp32 levels
 // single-channel 8-bit bilateral filter (fp32 planes holding integers); tables from the host: space_w (2r+1)^2 with 0
 // outside the circle, colour_w 256 entries
 int bilateral8_max_radius();

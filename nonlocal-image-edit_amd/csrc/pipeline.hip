@@ -1010,7 +1010,7 @@ void ensure_V(nle_filter* f) {
 // points start their download there); `group` caps the layers per launch (0: as many as fit)
 using LayersDone = std::function<void(int, int)>;
 void apply_sample_space(nle_filter* f, const float* d_x, const double* h_g /* L x K */, int L, float* d_y,
-                        const LayersDone& done = nullptr, int group = 0) {
+                        const LayersDone& done = nullptr, int group = 0, bool round8 = false) {
     nle_ctx* c = f->ctx;
     const long long M = f->n_local, pix0 = (long long)f->row0 * f->W;
     const int p = f->p, K = f->K, P64 = f->P64, nrows_local = (int)(M / f->W);
@@ -1051,10 +1051,10 @@ void apply_sample_space(nle_filter* f, const float* d_x, const double* h_g /* L 
                 ProfObserver obs(c, emap);
                 HIP_OK(nlek::apply_hist_layers(c->stream, lum, f->gs, p, f->row0, nrows_local, f->d_er, f->d_ecT, f->d_Ep,
                                                d_Wp.p + (size_t)l * P64, P64, nl, f->d_c, d_gws.p, d_y + (size_t)l * M, M,
-                                               &obs, f->has_sorted ? &f->sorted : nullptr));
+                                               &obs, f->has_sorted ? &f->sorted : nullptr, round8));
             }
             PROFILED(c, NLE_K_SMALL, nlek::scatter_samples(c->stream, p, nl, f->d_sample_loc, d_YA.p + (size_t)l * p,
-                                                           d_y + (size_t)l * M, M));
+                                                           d_y + (size_t)l * M, M, round8));
             if (done) done(l, nl);
         }
     } else if (done) {
@@ -1173,8 +1173,10 @@ nle_filter* train_impl(nle_ctx* c, const float* d_lum_in, int H, int W, int nRow
 }
 
 // t = V^T x (all ranks), then Y[l] = V (g_l o t)
+// round8: the planes come out clamped to [0, 255] and rounded half to even (src/filter.cpp:434-436) -- on the default path from
+// the fp64 value, before anything is rounded to fp32 (other formulations: their fp32 planes, rounded by the caller)
 void apply_impl(nle_filter* f, const float* d_x_in, int H, int W, const double* h_g /* L x K */, int L,
-                float* d_y, const LayersDone& done = nullptr, int group = 0) {
+                float* d_y, const LayersDone& done = nullptr, int group = 0, bool round8 = false) {
     nle_ctx* c = f->ctx;
     // slab-input mode: d_x_in holds this rank's rows only; index it through the virtual base of the full image
     const float* d_x = (c->slab_input && c->world > 1) ? d_x_in - (size_t)f->row0 * f->W : d_x_in;
@@ -1183,7 +1185,7 @@ void apply_impl(nle_filter* f, const float* d_x_in, int H, int W, const double* 
     if (L < 1 || L > 64) throw Fail{NLE_ERR_INVALID, "number of layers must be in [1, 64]"};
     HIP_OK(hipSetDevice(c->device));
     if (f->lazy && std::getenv("NLE_APPLY_WITH_V") == nullptr) {
-        apply_sample_space(f, d_x, h_g, L, d_y, done, group);
+        apply_sample_space(f, d_x, h_g, L, d_y, done, group, round8);
         return;
     }
     if (!f->d_V64) ensure_V(f);
@@ -1639,13 +1641,27 @@ int nle_apply_layers_host(nle_filter* f, const float* h_x, int H, int W, int L, 
     });
 }
 
+// the same plane kept as fp32 levels (what nle_lab2bgr8 / nle_lab2bgr8_planes take for a replaced channel)
+int nle_apply_rounded8(nle_filter* f, const float* d_x, int H, int W, const double* h_fS, float* d_y) {
+    if (!f || !f->ctx || !d_x || !h_fS || !d_y) return NLE_ERR_INVALID;
+    return guard(f->ctx, [&] {
+        apply_impl(f, d_x, H, W, h_fS, 1, d_y, nullptr, 0, /*round8=*/true);
+        if (!(f->lazy && std::getenv("NLE_APPLY_WITH_V") == nullptr)) {  // formulations with fp32 planes: round those
+            DevBuf<unsigned char> d_o((size_t)std::max<long long>(f->n_local, 1));
+            HIP_OK(nlek::plane_to_u8(f->ctx->stream, d_y, f->n_local, d_o.p));
+            HIP_OK(nlek::channel8_plane(f->ctx->stream, d_o.p, f->n_local, d_y));
+            HIP_OK(hipStreamSynchronize(f->ctx->stream));
+        }
+    });
+}
+
 // NLEFilter::enhance's L plane (src/filter.cpp:428-436): apply, clamp, convertTo(CV_8U) -- one byte per pixel leaves the device
 int nle_apply_u8(nle_filter* f, const float* d_x, int H, int W, const double* h_fS, unsigned char* d_out) {
     if (!f || !f->ctx || !d_x || !h_fS || !d_out) return NLE_ERR_INVALID;
     return guard(f->ctx, [&] {
         nle_ctx* c = f->ctx;
         DevBuf<float> d_y((size_t)std::max<long long>(f->n_local, 1));
-        apply_impl(f, d_x, H, W, h_fS, 1, d_y.p);
+        apply_impl(f, d_x, H, W, h_fS, 1, d_y.p, nullptr, 0, /*round8=*/true);
         HIP_OK(nlek::plane_to_u8(c->stream, d_y.p, f->n_local, d_out));
         HIP_OK(hipStreamSynchronize(c->stream));   // d_y returns to the ctx's cache
     });
@@ -1674,7 +1690,7 @@ int nle_apply_u8_host(nle_filter* f, const float* h_x, int H, int W, const doubl
             nle_ctx* c;
             ~Drain() { (void)hipStreamSynchronize(c->stream); }
         } drain{c};
-        apply_impl(f, d_x, H, W, h_fS, 1, d_y.p);
+        apply_impl(f, d_x, H, W, h_fS, 1, d_y.p, nullptr, 0, /*round8=*/true);
         HIP_OK(nlek::plane_to_u8(c->stream, d_y.p, f->n_local, d_o.p));
         HIP_OK(hipMemcpyAsync(h_out, d_o.p, (size_t)f->n_local, hipMemcpyDeviceToHost, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));

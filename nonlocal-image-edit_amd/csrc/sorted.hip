@@ -785,7 +785,7 @@ __global__ __launch_bounds__(kT) void k_sorted_expand(const unsigned short* __re
                                                       GridSpec gs, int nrows, const double* __restrict__ Etab,
                                                       const double* __restrict__ g, size_t gstride, int nl,
                                                       const double* __restrict__ cvec, float* __restrict__ out,
-                                                      long long ostride, double kappa) {
+                                                      long long ostride, double kappa, int round8) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int n = kLevels * NC;
     const int W = gs.W;
@@ -831,7 +831,13 @@ __global__ __launch_bounds__(kT) void k_sorted_expand(const unsigned short* __re
                     if (b & 1) s1 += e[b] * gv[l][b];
                     else s0 += e[b] * gv[l][b];
                 }
-                if (on && l < nl) sOut[l * W + c] = (float)(cv * (s0 + s1));
+                if (on && l < nl) {
+                    double v = cv * (s0 + s1);
+                    // round8: cv::max(0) / cv::min(255) / convertTo(CV_8U) (src/filter.cpp:434-436) on the fp64 value --
+                    // the plane then holds the 8-bit levels exactly, no fp32 rounding in front of the round-half-even
+                    if (round8) v = rint(fmin(255.0, fmax(0.0, v)));
+                    sOut[l * W + c] = (float)v;
+                }
             }
         };
 #pragma unroll
@@ -868,7 +874,7 @@ int sorted_expand_layers(GridSpec gs) { return (gs.nSelCols <= 12 && gs.W <= 409
 
 hipError_t sorted_expand(hipStream_t s, GridSpec gs, int nrows_local, const unsigned short* d_scol, const uint2* d_desc,
                          const double* d_E, const double* d_g, size_t gstride, int nl, const double* d_cvec, float* d_out,
-                         long long ostride, bool rec, double kappa) {
+                         long long ostride, bool rec, double kappa, bool round8) {
     const int nC = gs.nSelCols;
     const int lmax = sorted_expand_layers(gs);
     if (nC < 1 || nC > sorted_expand_max_cols() || gs.W > sorted_expand_max_width() || nl < 1 || nl > lmax)
@@ -886,7 +892,7 @@ hipError_t sorted_expand(hipStream_t s, GridSpec gs, int nrows_local, const unsi
             if (ea != hipSuccess) return ea;                                                                           \
         }                                                                                                              \
         hipLaunchKernelGGL((k_sorted_expand<NCV, LV, RECV>), dim3((unsigned)grid), dim3(kT), shm, s, d_scol, d_desc,   \
-                           gs, nrows_local, d_E, d_g, gstride, nl, d_cvec, d_out, ostride, kappa);                     \
+                           gs, nrows_local, d_E, d_g, gstride, nl, d_cvec, d_out, ostride, kappa, round8 ? 1 : 0);     \
     }
 #define NLE_SX(NCV)                                                                                                    \
     case NCV:                                                                                                          \

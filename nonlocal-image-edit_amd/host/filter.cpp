@@ -707,7 +707,7 @@ Image NLEFilter::denoise(const Image& image, DType k, int sigmaColor, int sigmaS
     for (int ch = 1; ch <= 2; ++ch) {  // :390-391
         float* d_out = ch == 1 ? d_a.f() : d_b.f();
         check(nle_lab8_channel(ctx_, static_cast<unsigned char*>(d_lab.p), (long long)np, ch, d_c.f()), ctx_);
-        check(nle_apply(f_, d_c.f(), image.rows, image.cols, t.data(), d_out), ctx_);
+        check(nle_apply_rounded8(f_, d_c.f(), image.rows, image.cols, t.data(), d_out), ctx_);  // + :394-399
     }
     // max(0) / min(255) / convertTo(CV_8U) of the three planes, merge, Lab -> BGR (:393-409)
     check(nle_lab2bgr8_planes(ctx_, static_cast<unsigned char*>(d_lab.p), d_Y.f(), d_a.f(), d_b.f(), (long long)np,
@@ -817,7 +817,7 @@ Image NLEFilter::enhanceGroup(const Image& image, const std::vector<DType>& weig
         check(nle_dev_upload(c, d_bgr.p, image.ptr<unsigned char>() + (size_t)r0 * W * 3, nl * 3), c);
         check(nle_bgr2lab8(c, static_cast<unsigned char*>(d_bgr.p), (long long)nl, static_cast<unsigned char*>(d_lab.p),
                            d_L.f()), c);
-        check(nle_apply(group_[r].get(), d_L.f(), H, W, fS.data(), d_y.f()), c);
+        check(nle_apply_rounded8(group_[r].get(), d_L.f(), H, W, fS.data(), d_y.f()), c);  // :431-436
         check(nle_lab2bgr8(c, static_cast<unsigned char*>(d_lab.p), d_y.f(), (long long)nl,
                            static_cast<unsigned char*>(d_bgr.p)), c);
         check(nle_dev_download(c, out.ptr<unsigned char>() + (size_t)r0 * W * 3, d_bgr.p, nl * 3), c);
@@ -844,7 +844,7 @@ Image NLEFilter::enhance(const Image& image, const std::vector<DType>& weights) 
     check(nle_bgr2lab8(ctx_, static_cast<unsigned char*>(d_bgr.p), (long long)np, static_cast<unsigned char*>(d_lab.p),
                        d_L.f()), ctx_);
     Vec fS = transformEigenValues(eigvals(), weights);
-    check(nle_apply(f_, d_L.f(), image.rows, image.cols, fS.data(), d_y.f()), ctx_);
+    check(nle_apply_rounded8(f_, d_L.f(), image.rows, image.cols, fS.data(), d_y.f()), ctx_);  // :431-436
     check(nle_lab2bgr8(ctx_, static_cast<unsigned char*>(d_lab.p), d_y.f(), (long long)np,
                        static_cast<unsigned char*>(d_bgr.p)), ctx_);
     Image out(image.rows, image.cols, NLE_8U, 3);

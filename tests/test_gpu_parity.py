@@ -367,21 +367,27 @@ def test_host_buffer_entry_points_match_the_device_ones(nle, oracle, ctx, pinned
     # a filter trained from a device pointer keeps no plane: NULL is refused, loudly
     with pytest.raises(nle.NLEError):
         f_dev.apply_layers_host(None, L, h_y)
-    # the one-plane return `enhance` needs (src/filter.cpp:428-436): weighted sum, clamp, convertTo(CV_8U) on the device,
-    # n bytes home -- equal to doing the clamp and round-half-even on the fp32 weighted sum, bit for bit, device and host forms
+    # the one-plane return `enhance` needs (src/filter.cpp:428-436): apply, clamp, convertTo(CV_8U) on the device, n bytes
+    # home.  The clamp and the round-half-even act on the fp64 value of the plane (nothing is rounded to fp32 first), so the
+    # bytes are the ORACLE's fp64 pipeline's -- not merely the rounding of the fp32 plane, from which they may differ at ties
     w = [2.0, 3.0, 3.0, 4.0, 1.0]
     fs = nle.transform_eigenvalues(f.eigvals, w)
-    y = f_dev.apply(x, fs).cpu().numpy()
-    want = np.rint(np.clip(y, 0, 255)).astype(np.uint8)
+    V_o, S_o = oracle.train_filter(x.astype(np.float64), nr, nc, hx, hy, T, K)
+    want = np.rint(np.clip(oracle.apply_filter(V_o, x.astype(np.float64), oracle.transform_eigenvalues(S_o, w)), 0, 255)).astype(np.uint8).ravel()
     assert 0 in want and 255 in want                      # the weights push parts of the plane out of range: the clamp is exercised
-    assert np.array_equal(f_dev.apply_u8(x, fs).cpu().numpy(), want)
+    got = f_dev.apply_u8(x, fs).cpu().numpy()
+    assert int((got != want).sum()) <= 1 and np.abs(got.astype(int) - want.astype(int)).max() <= 1      # a tie at 1e-9 at most
+    y32 = np.rint(np.clip(f_dev.apply(x, fs).cpu().numpy(), 0, 255)).astype(np.uint8)
+    assert (got != y32).mean() < 1e-3 and np.abs(got.astype(int) - y32.astype(int)).max() <= 1          # the fp32 plane's ties
+    lv = f_dev.apply_rounded8(x, fs).cpu().numpy()                                                      # the same levels as fp32
+    assert lv.dtype == np.float32 and np.array_equal(lv, got.astype(np.float32))
     h_o = ctx.host_alloc((H * W,), dtype=np.uint8) if pinned else np.empty(H * W, dtype=np.uint8)
     h_o[...] = 7
     f.apply_u8_host(None, fs, h_o)
-    assert np.array_equal(h_o, want)
+    assert np.array_equal(h_o, got)
     h_o[...] = 7
     f.apply_u8_host(h_x, fs, h_o)
-    assert np.array_equal(h_o, want)
+    assert np.array_equal(h_o, got)
     with pytest.raises(nle.NLEError):
         f_dev.apply_u8_host(None, fs, h_o)
     with pytest.raises(nle.NLEError):
