@@ -160,6 +160,11 @@ int nle_eigen_decomposition(const double* h_M, int n, double eps, double* h_U, d
  * h_D receives ALL n eigenvalues (descending), h_U (n x min(kmax, n)) the first min(kmax, n) eigenvectors, *r the length
  * of the leading run >= eps.  For kmax <= n / 2 the eigenvectors come from inverse iteration on the tridiagonal form. */
 int nle_eigen_decomposition_top(const double* h_M, int n, double eps, int kmax, double* h_U, double* h_D, int* r);
+/* the form the train path itself uses for Q on the host: h_Dk receives only the min(kmax, n) LARGEST eigenvalues (descending),
+ * h_U (n x min(kmax, n)) their eigenvectors, *r the number of eigenvalues >= eps -- all orthogonalize reads of Q's
+ * decomposition (:313-316).  For 2 kmax <= n the eigenvalues come from bisection on Sturm counts of the tridiagonal form
+ * (the count at eps is *r) instead of a QL run for all n; otherwise this is nle_eigen_decomposition_top. */
+int nle_eigen_decomposition_topk(const double* h_M, int n, double eps, int kmax, double* h_U, double* h_Dk, int* r);
 /* the same with the Householder reduction to tridiagonal form on the GPU (one workgroup, the matrix in registers; n <= 224)
  * and the O(n^2) rest on the host -- what nle_train* uses for Q when K <= q / 2 and q <= 224 (NLE_HOST_TRIDIAG=1 keeps
  * the whole solve on the host).  Same conventions; results agree with the host form to rounding. */

@@ -161,6 +161,21 @@ def eigen_decomposition_top(M: np.ndarray, kmax: int, eps: float = EPS):
     return np.ascontiguousarray(U), D, r.value
 
 
+def eigen_decomposition_topk(M: np.ndarray, kmax: int, eps: float = EPS):
+    """the min(kmax, n) largest eigenvalues (descending), their eigenvectors and the number of eigenvalues >= eps, as the
+    train path computes them for Q on the host (bisection when 2 kmax <= n): (U [n x k], Dk [k], r)"""
+    M = np.asfortranarray(np.asarray(M, dtype=np.float64))
+    n = M.shape[0]
+    k = min(int(kmax), n)
+    U = np.zeros((n, k), dtype=np.float64, order="F")
+    D = np.zeros(k, dtype=np.float64)
+    r = C.c_int()
+    st = lib().nle_eigen_decomposition_topk(_np_ptr(M), n, float(eps), int(kmax), _np_ptr(U), _np_ptr(D), C.byref(r))
+    if st != NLE_OK:
+        raise NLEError(st, "eigensolver did not converge")
+    return np.ascontiguousarray(U), D, r.value
+
+
 def topk_eigen_decomposition(M: np.ndarray, n_largest: int, eps: float = EPS):
     """`topkEigenDecomposition` (src/filter.cpp:170-199, the USE_SPECTRA build): Lanczos top-k; returns (U, D)."""
     M = np.asfortranarray(np.asarray(M, dtype=np.float64))

@@ -259,6 +259,11 @@ int nle_eigen_decomposition_top(const double* h_M, int n, double eps, int kmax, 
     return nleh::eigen_decomposition_top(h_M, n, eps, kmax, h_U, h_D, r) ? NLE_OK : NLE_ERR_NUMERIC;
 }
 
+int nle_eigen_decomposition_topk(const double* h_M, int n, double eps, int kmax, double* h_U, double* h_Dk, int* r) {
+    if (!h_M || !h_U || !h_Dk || !r || n < 1 || kmax < 1) return NLE_ERR_INVALID;
+    return nleh::eigen_decomposition_topk(h_M, n, eps, kmax, h_U, h_Dk, r) ? NLE_OK : NLE_ERR_NUMERIC;
+}
+
 int nle_eigen_decomposition_top_device(nle_ctx* ctx, const double* h_M, int n, double eps, int kmax, double* h_U, double* h_D,
                                        int* r) {
     if (!ctx || !h_M || !h_U || !h_D || !r || n < 2 || kmax < 1) return NLE_ERR_INVALID;

@@ -201,6 +201,22 @@ NLE_SIMD_CLONES bool ql_implicit(int n, double* V, double* d, double* e) {
 //      back-transformed with the Householder vectors, by independent column blocks.
 // Phases 3a/3b split over threads without any synchronisation, which the per-sweep update of the classic
 // loop does not allow.
+// (v8d: eight doubles; defined here because the two inner loops below are written on it)
+typedef double v8d __attribute__((vector_size(64)));
+static inline __attribute__((always_inline)) v8d ld8(const double* p) {
+    v8d v;
+    __builtin_memcpy(&v, p, sizeof(v));
+    return v;
+}
+static inline __attribute__((always_inline)) void st8(double* p, v8d v) { __builtin_memcpy(p, &v, sizeof(v)); }
+static inline __attribute__((always_inline)) double hsum8(v8d v) {
+    return ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
+}
+
+// The two O(i^2) loops of a step -- p = A u on the lower triangle and the rank-2 update A -= u q^T + q u^T -- take FOUR
+// columns at a time: every vector of u and of the running product is loaded once for four columns' multiply-adds (the
+// one-column loops spend their time on loads, stores and loop control of vectors a dozen long: 10 GFLOP/s on a core that
+// does 40 on the tile products), the small triangle where the four columns start is done in scalar code.
 NLE_SIMD_CLONES void tridiag_reduce(int n, double* V, double* d, double* e, double* hs) {
     for (int j = 0; j < n; ++j) d[j] = at(V, n, n - 1, j);
     for (int i = n - 1; i > 0; --i) {
@@ -225,18 +241,51 @@ NLE_SIMD_CLONES void tridiag_reduce(int n, double* V, double* d, double* e, doub
             h -= f * g;
             d[i - 1] = f - g;
             for (int j = 0; j < i; ++j) e[j] = 0.0;
-            for (int j = 0; j < i; ++j) {
-                f = d[j];
-                at(V, n, j, i) = f;
-                g = e[j] + at(V, n, j, j) * f;
-                const double* col = &at(V, n, 0, j);
-                double gs = 0.0;
-#pragma omp simd reduction(+ : gs)
-                for (int k = j + 1; k <= i - 1; ++k) {
-                    gs += col[k] * d[k];
-                    e[k] += col[k] * f;
+            // e = A d on the leading i x i block (lower triangle stored)
+            for (int j0 = 0; j0 < i; j0 += 4) {
+                const int nc = std::min(4, i - j0), kk = j0 + nc;
+                double* col[4];
+                double fc[4], gc[4];
+                for (int c = 0; c < nc; ++c) {
+                    const int j = j0 + c;
+                    col[c] = &at(V, n, 0, j);
+                    fc[c] = d[j];
+                    at(V, n, j, i) = fc[c];
+                    gc[c] = e[j] + col[c][j] * fc[c];
+                    for (int k = j + 1; k < kk; ++k) {  // the triangle between the block's columns
+                        gc[c] += col[c][k] * d[k];
+                        e[k] += col[c][k] * fc[c];
+                    }
                 }
-                e[j] = g + gs;
+                for (int c = nc; c < 4; ++c) {
+                    col[c] = col[0];
+                    fc[c] = 0.0;
+                    gc[c] = 0.0;
+                }
+                v8d a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+                int k = kk;
+                for (; k + 8 <= i; k += 8) {
+                    const v8d dv = ld8(d + k);
+                    v8d ev = ld8(e + k);
+                    const v8d c0 = ld8(col[0] + k), c1 = ld8(col[1] + k), c2 = ld8(col[2] + k), c3 = ld8(col[3] + k);
+                    a0 += c0 * dv;
+                    a1 += c1 * dv;
+                    a2 += c2 * dv;
+                    a3 += c3 * dv;
+                    ev += c0 * fc[0] + c1 * fc[1] + c2 * fc[2] + c3 * fc[3];
+                    st8(e + k, ev);
+                }
+                double t0 = hsum8(a0), t1 = hsum8(a1), t2 = hsum8(a2), t3 = hsum8(a3);
+                for (; k < i; ++k) {
+                    const double dk = d[k];
+                    t0 += col[0][k] * dk;
+                    t1 += col[1][k] * dk;
+                    t2 += col[2][k] * dk;
+                    t3 += col[3][k] * dk;
+                    e[k] += col[0][k] * fc[0] + col[1][k] * fc[1] + col[2][k] * fc[2] + col[3][k] * fc[3];
+                }
+                const double tt[4] = {t0, t1, t2, t3};
+                for (int c = 0; c < nc; ++c) e[j0 + c] = gc[c] + tt[c];
             }
             f = 0.0;
             for (int j = 0; j < i; ++j) {
@@ -245,12 +294,35 @@ NLE_SIMD_CLONES void tridiag_reduce(int n, double* V, double* d, double* e, doub
             }
             const double hh = f / (h + h);
             for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+            // A -= d e^T + e d^T on the block, then the next row into d
+            for (int j0 = 0; j0 < i; j0 += 4) {
+                const int nc = std::min(4, i - j0), kk = j0 + nc;
+                double* col[4];
+                double fc[4], gc[4];
+                for (int c = 0; c < nc; ++c) {
+                    const int j = j0 + c;
+                    col[c] = &at(V, n, 0, j);
+                    fc[c] = d[j];
+                    gc[c] = e[j];
+                    for (int k = j; k < kk; ++k) col[c][k] -= (fc[c] * e[k] + gc[c] * d[k]);
+                }
+                if (nc == 4) {
+                    int k = kk;
+                    for (; k + 8 <= i; k += 8) {
+                        const v8d dv = ld8(d + k), ev = ld8(e + k);
+                        st8(col[0] + k, ld8(col[0] + k) - (ev * fc[0] + dv * gc[0]));
+                        st8(col[1] + k, ld8(col[1] + k) - (ev * fc[1] + dv * gc[1]));
+                        st8(col[2] + k, ld8(col[2] + k) - (ev * fc[2] + dv * gc[2]));
+                        st8(col[3] + k, ld8(col[3] + k) - (ev * fc[3] + dv * gc[3]));
+                    }
+                    for (; k < i; ++k)
+                        for (int c = 0; c < 4; ++c) col[c][k] -= (fc[c] * e[k] + gc[c] * d[k]);
+                } else {
+                    for (int c = 0; c < nc; ++c)
+                        for (int k = kk; k < i; ++k) col[c][k] -= (fc[c] * e[k] + gc[c] * d[k]);
+                }
+            }
             for (int j = 0; j < i; ++j) {
-                f = d[j];
-                g = e[j];
-                double* col = &at(V, n, 0, j);
-#pragma omp simd
-                for (int k = j; k <= i - 1; ++k) col[k] -= (f * e[k] + g * d[k]);
                 d[j] = at(V, n, i - 1, j);
                 at(V, n, i, j) = 0.0;
             }
@@ -420,13 +492,6 @@ bool ql_values(int n, double* d, double* e2) {
 // Rows [k0, k0 + 8 NV) of Z (column-major, leading dimension ldz, a multiple of 8): every sweep's rotations,
 // in order.  Consecutive rotations share a column; its running value stays in NV vector registers, so each
 // column is loaded and stored once per sweep, and NV independent dependency chains hide the FMA latency.
-typedef double v8d __attribute__((vector_size(64)));
-static inline __attribute__((always_inline)) v8d ld8(const double* p) {
-    v8d v;
-    __builtin_memcpy(&v, p, sizeof(v));
-    return v;
-}
-static inline __attribute__((always_inline)) void st8(double* p, v8d v) { __builtin_memcpy(p, &v, sizeof(v)); }
 
 template <int NV>
 static inline __attribute__((always_inline)) void rotate_rows(int ldz, double* Z, int k0, const Sweep* sweeps,
@@ -1326,6 +1391,145 @@ bool eigen_decomposition_top_reduced(int n, double eps, int kmax, const double* 
     return true;
 }
 
+// ---- a FEW eigenvalues of the tridiagonal form by bisection on Sturm counts, up to 64 shifts per sweep of T.
+// What the train path needs of Q is its K leading eigenpairs and the NUMBER of eigenvalues >= 1e-10 (src/filter.cpp:313-316), of
+// Wa the number below 1e-10, those few eigenvalues, and the largest (the deflated root): an implicit QL run for all n
+// eigenvalues (0.31 ms at n = 200 on the GPU box's host, a chain of dependent rotations) is replaced by counts.  A count is
+// a chain of n - 1 dependent divisions (~20 cycles each): eight shifts ride in one AVX-512 vector and up to eight vectors are
+// interleaved so the divider stays busy -- 50 eigenvalues are ONE sweep of T per halving, ~55 halvings.  Accuracy: the
+// count is exact for a tridiagonal matrix within a few ulp ||T|| of T (dstebz's recurrence with its pivmin guard), the same
+// backward error the QL iteration has; the rank cut at eps is one more count.
+namespace {
+typedef long long v8l __attribute__((vector_size(64)));
+struct SturmT {
+    int n;
+    const double* d;
+    std::vector<double> e2;  // e2[i] = e[i]^2 couples i - 1 and i (e2[0] = 0)
+    double pivmin, lo, hi;   // Gershgorin bounds, widened
+};
+SturmT sturm_setup(int n, const double* d, const double* e) {
+    SturmT t{n, d, std::vector<double>(n, 0.0), 0.0, 0.0, 0.0};
+    double emax2 = 0.0, lo = d[0], hi = d[0];
+    for (int i = 1; i < n; ++i) {
+        t.e2[i] = e[i] * e[i];
+        emax2 = std::max(emax2, t.e2[i]);
+    }
+    for (int i = 0; i < n; ++i) {
+        const double r = (i > 0 ? std::fabs(e[i]) : 0.0) + (i + 1 < n ? std::fabs(e[i + 1]) : 0.0);
+        lo = std::min(lo, d[i] - r);
+        hi = std::max(hi, d[i] + r);
+    }
+    const double nrm = std::max(std::fabs(lo), std::fabs(hi));
+    t.pivmin = 2.2250738585072014e-308 * std::max(1.0, emax2);
+    t.lo = lo - 2.0 * 2.220446049250313e-16 * nrm * n - 2.0 * t.pivmin;
+    t.hi = hi + 2.0 * 2.220446049250313e-16 * nrm * n + 2.0 * t.pivmin;
+    return t;
+}
+// cnt[v] = number of eigenvalues of T smaller than each of the shifts s[v] (NV vectors of eight).  Intrinsics, not vector
+// extensions: GCC scalarises 512-bit vector comparisons inside target_clones (measured: 48 cycles per vector step).
+template <int NV>
+__attribute__((target("avx512f"))) static void sturm_counts_avx512(int n, const double* d, const double* e2, double pivmin,
+                                                                    const v8d* s, v8l* cnt) {
+    const __m512d pm = _mm512_set1_pd(pivmin), npm = _mm512_set1_pd(-pivmin), zero = _mm512_setzero_pd();
+    const __m512i one = _mm512_set1_epi64(1);
+    __m512d q[NV], sv[NV];
+    __m512i c[NV];
+    for (int v = 0; v < NV; ++v) {
+        sv[v] = _mm512_loadu_pd(&s[v]);
+        q[v] = _mm512_sub_pd(_mm512_set1_pd(d[0]), sv[v]);
+        q[v] = _mm512_mask_mov_pd(q[v], _mm512_cmp_pd_mask(_mm512_abs_pd(q[v]), pm, _CMP_LT_OQ), npm);
+        c[v] = _mm512_maskz_mov_epi64(_mm512_cmp_pd_mask(q[v], zero, _CMP_LT_OQ), one);
+    }
+    for (int i = 1; i < n; ++i) {
+        const __m512d di = _mm512_set1_pd(d[i]), ei = _mm512_set1_pd(e2[i]);
+        for (int v = 0; v < NV; ++v) {
+            q[v] = _mm512_sub_pd(_mm512_sub_pd(di, sv[v]), _mm512_div_pd(ei, q[v]));
+            q[v] = _mm512_mask_mov_pd(q[v], _mm512_cmp_pd_mask(_mm512_abs_pd(q[v]), pm, _CMP_LT_OQ), npm);
+            c[v] = _mm512_mask_add_epi64(c[v], _mm512_cmp_pd_mask(q[v], zero, _CMP_LT_OQ), c[v], one);
+        }
+    }
+    for (int v = 0; v < NV; ++v) _mm512_storeu_si512(&cnt[v], c[v]);
+}
+void sturm_counts_scalar(int n, const double* d, const double* e2, double pivmin, const v8d* s, int nv, v8l* cnt) {
+    for (int v = 0; v < nv; ++v) {
+        double q[8], sh[8];
+        long long c[8];
+        for (int l = 0; l < 8; ++l) {
+            sh[l] = s[v][l];
+            q[l] = d[0] - sh[l];
+            if (std::fabs(q[l]) < pivmin) q[l] = -pivmin;
+            c[l] = q[l] < 0.0;
+        }
+        for (int i = 1; i < n; ++i)
+            for (int l = 0; l < 8; ++l) {
+                q[l] = (d[i] - sh[l]) - e2[i] / q[l];
+                if (std::fabs(q[l]) < pivmin) q[l] = -pivmin;
+                c[l] += q[l] < 0.0;
+            }
+        for (int l = 0; l < 8; ++l) cnt[v][l] = c[l];
+    }
+}
+void sturm_counts(const SturmT& t, const v8d* s, int nv, v8l* cnt) {
+    static const bool avx512 = __builtin_cpu_supports("avx512f");
+    if (!avx512) return sturm_counts_scalar(t.n, t.d, t.e2.data(), t.pivmin, s, nv, cnt);
+    switch (nv) {
+        case 1: sturm_counts_avx512<1>(t.n, t.d, t.e2.data(), t.pivmin, s, cnt); break;
+        case 2: sturm_counts_avx512<2>(t.n, t.d, t.e2.data(), t.pivmin, s, cnt); break;
+        case 3: sturm_counts_avx512<3>(t.n, t.d, t.e2.data(), t.pivmin, s, cnt); break;
+        case 4: sturm_counts_avx512<4>(t.n, t.d, t.e2.data(), t.pivmin, s, cnt); break;
+        case 5: sturm_counts_avx512<5>(t.n, t.d, t.e2.data(), t.pivmin, s, cnt); break;
+        case 6: sturm_counts_avx512<6>(t.n, t.d, t.e2.data(), t.pivmin, s, cnt); break;
+        case 7: sturm_counts_avx512<7>(t.n, t.d, t.e2.data(), t.pivmin, s, cnt); break;
+        default: sturm_counts_avx512<8>(t.n, t.d, t.e2.data(), t.pivmin, s, cnt); break;
+    }
+}
+int sturm_count1(const SturmT& t, double s) {
+    const v8d sv = {s, s, s, s, s, s, s, s};
+    v8l c;
+    sturm_counts(t, &sv, 1, &c);
+    return (int)c[0];
+}
+// the eigenvalues number k[0 .. m) of T counted from the SMALLEST (k = 0), m <= 64, to the last bit the counts resolve
+void sturm_bisect(const SturmT& t, const int* k, int m, double* out) {
+    const int nv = (m + 7) / 8;
+    v8d lo[8], hi[8], mid[8];
+    v8l kk[8], c[8];
+    for (int l = 0; l < 8 * nv; ++l) {
+        lo[l / 8][l % 8] = t.lo;
+        hi[l / 8][l % 8] = t.hi;
+        kk[l / 8][l % 8] = k[l < m ? l : m - 1];
+    }
+    // to one ulp of ||T|| (what any eigenvalue of T is defined to; a relative criterion would spend 40 more halvings on the
+    // eigenvalues near the 1e-10 cut for digits the reduction never had)
+    const double tol = 2.220446049250313e-16 * std::max(std::fabs(t.lo), std::fabs(t.hi)) + 2.0 * t.pivmin;
+    for (int it = 0; it < 1100; ++it) {  // a double has 2098 binades at most; ~55 halvings when lambda is O(||T||)
+        for (int v = 0; v < nv; ++v) mid[v] = 0.5 * (lo[v] + hi[v]);
+        sturm_counts(t, mid, nv, c);
+        bool done = true;
+        for (int v = 0; v < nv; ++v) {
+            const v8l up = c[v] > kk[v];  // more than k eigenvalues below mid: lambda_k < mid
+            hi[v] = up ? mid[v] : hi[v];
+            lo[v] = up ? lo[v] : mid[v];
+            for (int l = 0; l < 8; ++l) {
+                const double m2 = 0.5 * (lo[v][l] + hi[v][l]);
+                if (hi[v][l] - lo[v][l] > tol && m2 > lo[v][l] && m2 < hi[v][l]) done = false;
+            }
+        }
+        if (done) break;
+    }
+    for (int l = 0; l < m; ++l) out[l] = 0.5 * (lo[l / 8][l % 8] + hi[l / 8][l % 8]);
+}
+// eigenvalues with DESCENDING numbers [first, first + count) (number 0 = the largest) into out[0 .. count)
+void sturm_eigenvalues_desc(const SturmT& t, int first, int count, double* out) {
+    for (int j0 = 0; j0 < count; j0 += 64) {
+        const int m = std::min(64, count - j0);
+        int k[64];
+        for (int l = 0; l < m; ++l) k[l] = t.n - 1 - (first + j0 + l);
+        sturm_bisect(t, k, m, out + j0);
+    }
+}
+}  // namespace
+
 // All eigenvalues (DESCENDING, in D) and the eigenvectors of D[first .. first + count) only (U: n x count): the reduction
 // without the orthogonal factor, QL on (d, e) for the values, inverse iteration on T for the selected vectors, and their
 // back-transformation.  What the deflated root of Wa needs: the few eigenpairs the 1e-10 cut removes (pipeline.hip).
@@ -1360,6 +1564,46 @@ bool sym_eigen_select(const double* M, int n, double* D, int first, int count, d
     return true;
 }
 
+// What the deflated root of Wa needs and no more (ortho.hip): *kept_out = the number of eigenvalues >= eps (one Sturm
+// count); if between 1 and max_below fall below it, those eigenvalues DESCENDING in Dbelow and their eigenvectors in U
+// (n x max_below), the largest eigenvalue in *lam_max and the smallest kept one in *lam_min_kept, all by bisection.
+bool sym_eigen_below(const double* M, int n, double eps, int max_below, int* kept_out, double* lam_max, double* lam_min_kept,
+                     double* Dbelow, double* U) {
+    if (n < 8 || std::getenv("NLE_EIG_NO_BISECT") != nullptr) {
+        std::vector<double> D(n);
+        if (!sym_eigen_select(M, n, D.data(), 0, 0, U, eps, max_below, kept_out)) return false;
+        const int kept = *kept_out;
+        *lam_max = D[0];
+        *lam_min_kept = kept > 0 ? D[kept - 1] : 0.0;
+        if (n - kept <= max_below) std::copy(D.begin() + kept, D.end(), Dbelow);
+        return true;
+    }
+    std::vector<double> V((size_t)n * n), d(n), e(n), hs(n);
+    for (int c = 0; c < n; ++c)
+        for (int r = 0; r < n; ++r) V[(size_t)c * n + r] = (r >= c) ? M[(size_t)c * n + r] : M[(size_t)r * n + c];
+    tridiag_reduce(n, V.data(), d.data(), e.data(), hs.data());
+    const SturmT t = sturm_setup(n, d.data(), e.data());
+    const int kept = n - sturm_count1(t, eps);
+    *kept_out = kept;
+    const int nb = n - kept;
+    {   // lambda_max, the smallest kept, and (if few) the ones below the cut: one or two vectors of shifts
+        std::vector<int> k;
+        k.push_back(n - 1);
+        k.push_back(kept > 0 ? n - kept : n - 1);
+        if (nb <= max_below)
+            for (int j = 0; j < nb; ++j) k.push_back(nb - 1 - j);
+        std::vector<double> out(k.size());
+        for (size_t j0 = 0; j0 < k.size(); j0 += 64) sturm_bisect(t, k.data() + j0, (int)std::min<size_t>(64, k.size() - j0), out.data() + j0);
+        *lam_max = out[0];
+        *lam_min_kept = kept > 0 ? out[1] : 0.0;
+        if (nb <= max_below) std::copy(out.begin() + 2, out.end(), Dbelow);
+    }
+    if (nb == 0 || nb > max_below) return true;
+    if (!tridiag_inverse_iteration(n, d.data(), e.data(), Dbelow, nb, U)) return false;
+    back_transform_cols(n, V.data(), hs.data(), U, 0, nb);
+    return true;
+}
+
 // All eigenvectors on one thread: the classic reduction WITH accumulation of the orthogonal factor (cheaper than
 // back-transforming n vectors one reflector at a time), then the recorded rotations applied to it by cache-resident
 // row blocks instead of column pair by column pair.  U: n x n, D: n, both ASCENDING like sym_eigen.
@@ -1389,6 +1633,45 @@ bool sym_eigen_blocked(const double* M, int n, double* U, double* D) {
         D[j] = d[idx[j]];
         std::copy(Z + (size_t)idx[j] * ldz, Z + (size_t)idx[j] * ldz + n, U + (size_t)j * n);
     }
+    return true;
+}
+
+// eigenDecomposition (src/filter.cpp:204-228) when only the leading kmax eigenpairs and the count of the cut are used
+// (orthogonalize on Q, :313-316): Dk[0 .. kmax) = the kmax largest eigenvalues DESCENDING, U (n x kmax) their eigenvectors,
+// *r_out = number of eigenvalues >= eps.  Householder reduction, eigenvalues by bisection, eigenvectors by inverse iteration
+// and back-transformation.  For 2 kmax <= n (else, and should the inverse iteration give up: eigen_decomposition_top).
+bool eigen_decomposition_topk(const double* M, int n, double eps, int kmax, double* U, double* Dk, int* r_out) {
+    kmax = std::max(0, std::min(kmax, n));
+    if (n < 8 || 2 * kmax > n || std::getenv("NLE_EIG_NO_BISECT") != nullptr) {
+        std::vector<double> D(n);
+        if (!eigen_decomposition_top(M, n, eps, kmax, U, D.data(), r_out)) return false;
+        std::copy(D.begin(), D.begin() + kmax, Dk);
+        return true;
+    }
+    static const bool trace = std::getenv("NLE_EIG_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = trace ? now() : 0.0;
+    std::vector<double> V((size_t)n * n), d(n), e(n), hs(n);
+    for (int c = 0; c < n; ++c)  // mirror the lower triangle (SelfAdjointEigenSolver reads only the lower one)
+        for (int r = 0; r < n; ++r) V[(size_t)c * n + r] = (r >= c) ? M[(size_t)c * n + r] : M[(size_t)r * n + c];
+    tridiag_reduce(n, V.data(), d.data(), e.data(), hs.data());
+    const double t1 = trace ? now() : 0.0;
+    const SturmT t = sturm_setup(n, d.data(), e.data());
+    *r_out = n - sturm_count1(t, eps);  // descending order: the leading run >= eps IS the count of eigenvalues >= eps
+    sturm_eigenvalues_desc(t, 0, kmax, Dk);
+    const double t2 = trace ? now() : 0.0;
+    if (kmax == 0) return true;
+    if (!tridiag_inverse_iteration(n, d.data(), e.data(), Dk, kmax, U)) {
+        std::vector<double> D(n);
+        if (!eigen_decomposition_top(M, n, eps, kmax, U, D.data(), r_out)) return false;
+        std::copy(D.begin(), D.begin() + kmax, Dk);
+        return true;
+    }
+    const double t3 = trace ? now() : 0.0;
+    back_transform_cols(n, V.data(), hs.data(), U, 0, kmax);
+    if (trace)
+        std::fprintf(stderr, "[nle eig] n = %d, %d pairs: reduction %.3f ms, bisection %.3f ms, inverse iteration %.3f ms, back-transformation %.3f ms\n",
+                     n, kmax, t1 - t0, t2 - t1, t3 - t2, now() - t3);
     return true;
 }
 

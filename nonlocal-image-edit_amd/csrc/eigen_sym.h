@@ -40,6 +40,16 @@ bool eigen_decomposition_top_reduced(int n, double eps, int kmax, const double* 
 bool sym_eigen_select(const double* M, int n, double* D, int first, int count, double* U, double below_eps = 0.0,
                       int max_below = 0, int* kept_out = nullptr);
 
+// The same by bisection (Sturm counts on the tridiagonal form) for callers that use only the count of the cut, the few
+// eigenvalues below it, the largest and the smallest kept one: *kept_out = number of eigenvalues >= eps; if 1 .. max_below
+// lie below, Dbelow (DESCENDING) and U (n x max_below) hold them and their eigenvectors.
+bool sym_eigen_below(const double* M, int n, double eps, int max_below, int* kept_out, double* lam_max, double* lam_min_kept,
+                     double* Dbelow, double* U);
+// eigen_decomposition_top computing only what orthogonalize uses of Q (src/filter.cpp:313-316): Dk[0 .. kmax) the kmax
+// largest eigenvalues, U (n x kmax) their eigenvectors, *r = number of eigenvalues >= eps -- eigenvalues by bisection
+// when 2 kmax <= n (otherwise, or with NLE_EIG_NO_BISECT set, through eigen_decomposition_top).
+bool eigen_decomposition_topk(const double* M, int n, double eps, int kmax, double* U, double* Dk, int* r);
+
 // Eigenvectors of the symmetric tridiagonal T (d[0..n) diagonal, e[1..n) sub-diagonal) for its eigenvalues
 // lam_all[first .. first + count) (lam_all: all n eigenvalues DESCENDING, accurate to rounding): inverse iteration
 // (dstein's scheme), falling back to the QL iteration with accumulated rotations if a vector does not converge.

@@ -58,8 +58,8 @@ void top_eigenpairs(const std::vector<double>& Qm, int q, int n_eig, int solver,
         return;
     }
     Vq->assign((size_t)q * std::min(q, std::max(n_eig, 1)), 0.0);  // only the kept eigenvectors (:314)
-    Sq->assign(q, 0.0);
-    if (!nleh::eigen_decomposition_top(Qm.data(), q, NLE_EPS, n_eig, Vq->data(), Sq->data(), rq))
+    Sq->assign(q, 0.0);  // the leading min(n_eig, q) eigenvalues; the count of the cut comes back in *rq (:313-316 use no more)
+    if (!nleh::eigen_decomposition_topk(Qm.data(), q, NLE_EPS, n_eig, Vq->data(), Sq->data(), rq))
         throw Fail{NLE_ERR_NUMERIC, "eigensolver did not converge on Q"};
 }
 
@@ -485,20 +485,21 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
         // (on the host tried only where it pays: below q = 512, where the eigensolver is single threaded -- at q = 900 with 100
         // dropped eigenvalues it lost 40 ms to the threaded full solve -- and for at most q / 8 dropped eigenvalues)
         if (!dev_wa && !chol_wa && std::getenv("NLE_FORCE_EIG") == nullptr && std::getenv("NLE_NO_DEFLATE") == nullptr && q >= 16 && q < 512) {
-            std::vector<double> Dall(q), Vd((size_t)q * (max_defl + 1));
+            std::vector<double> Dbelow(max_defl + 1), Vd((size_t)q * (max_defl + 1));
             int kept = 0;
+            double lam_max = 0.0, lam_min_kept = 0.0;
             tr.mark(attempt_chol ? "ss:   Wa built, Cholesky attempt" : "ss:   Wa built");
-            if (nleh::sym_eigen_select(o.Wa.data(), q, Dall.data(), 0, 0, Vd.data(), NLE_EPS, max_defl, &kept)) {
+            if (nleh::sym_eigen_below(o.Wa.data(), q, NLE_EPS, max_defl, &kept, &lam_max, &lam_min_kept, Dbelow.data(), Vd.data())) {
                 tr.mark("ss:   Wa eigenvalues + dropped eigenvectors");
                 nd = q - kept;
-                if (kept > 0 && nd <= max_defl && Dall[0] > 0.0) {
-                    const double sig = Dall[0];
+                if (kept > 0 && nd <= max_defl && lam_max > 0.0) {
+                    const double sig = lam_max;
                     std::vector<double> Ah(qq);
                     for (int cidx = 0; cidx < q; ++cidx)  // the symmetric matrix the reference's solver sees: lower triangle
                         for (int ridx = 0; ridx < q; ++ridx)
                             Ah[(size_t)cidx * q + ridx] = ridx >= cidx ? o.Wa[(size_t)cidx * q + ridx] : o.Wa[(size_t)ridx * q + cidx];
                     for (int t = 0; t < nd; ++t) {
-                        const double wgt = sig - Dall[kept + t];
+                        const double wgt = sig - Dbelow[t];
                         const double* v = Vd.data() + (size_t)t * q;
                         for (int cidx = 0; cidx < q; ++cidx) {
                             const double vc = wgt * v[cidx];
@@ -535,7 +536,7 @@ void ortho_ss_device(nle_ctx* c, OrthoSS& o, const Nystrom& ny, int p, const std
                         r2 = kept;
                         if (std::getenv("NLE_TRACE"))
                             fprintf(stderr, "[nle trace] Wa: %d of %d eigenvalues >= 1e-10 (largest %.3e, smallest kept %.3e), %d deflated\n",
-                                    kept, q, Dall[0], Dall[kept - 1], nd);
+                                    kept, q, lam_max, lam_min_kept, nd);
                     }
                 }
             }

@@ -212,6 +212,53 @@ def test_topk_lanczos_matches_the_full_solver(nle, oracle):
         assert np.abs(U[:, :kk] @ U[:, :kk].T - v[:, :kk] @ v[:, :kk].T).max() < 1e-6
 
 
+def test_leading_eigenpairs_by_bisection(nle):
+    """nle_eigen_decomposition_topk: what the train path computes of Q on the host -- the K largest eigenvalues by bisection
+    on Sturm counts of the tridiagonal form, the rank of the 1e-10 cut (src/filter.cpp:214) as one more count, the
+    eigenvectors by inverse iteration.  Against LAPACK and against the QL form (nle_eigen_decomposition_top) on spectra
+    that cross the cut, cluster, repeat, and on the degenerate matrices."""
+    rng = np.random.default_rng(19)
+    cases = []
+    for n, k in ((200, 50), (196, 50), (64, 32), (333, 100), (30, 3), (16, 8), (9, 1)):
+        lam = np.concatenate([np.geomspace(1.5, 1.2e-10, n - n // 10), np.geomspace(9e-11, 1e-14, n // 10)])
+        cases.append(("through the cut", n, k, lam))
+    lam = np.sort(np.concatenate([1.0 - 1e-9 * np.arange(6), 0.5 + 1e-12 * np.arange(5), rng.uniform(0, 0.4, 109)]))[::-1]
+    cases.append(("clusters", 120, 40, lam))
+    lam = np.sort(np.concatenate([[0.9] * 4, [0.7] * 3, rng.uniform(0, 0.5, 93)]))[::-1]
+    cases.append(("repeated", 100, 20, lam))
+    cases.append(("wa", 200, 60, 1.5e-5 * 0.9 ** np.arange(200)))
+    cases.append(("scaled up", 80, 20, 3e7 * 0.8 ** np.arange(80)))
+    cases.append(("indefinite", 90, 30, np.linspace(2.0, -1.0, 90)))
+    for name, n, k, lam in cases:
+        X = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        A = (X * lam) @ X.T
+        A = (A + A.T) / 2
+        U, Dk, r = nle.eigen_decomposition_topk(A, k)
+        Uq, Dq, rq = nle.eigen_decomposition_top(A, k)
+        w = np.linalg.eigvalsh(A)[::-1]
+        scale = np.abs(w).max()
+        # the count of the cut: LAPACK's, unless an eigenvalue sits within rounding of 1e-10 (none of these spectra does)
+        assert r == rq == int((w >= 1e-10).sum()), (name, n, r, rq)
+        assert Dk.shape == (k,) and np.all(np.diff(Dk) <= 0)
+        assert np.abs(Dk - w[:k]).max() < 1e-13 * scale * n, (name, np.abs(Dk - w[:k]).max())
+        assert np.abs(Dk - Dq[:k]).max() < 1e-13 * scale * n
+        assert U.shape == (n, k)
+        assert np.abs(U.T @ U - np.eye(k)).max() < 1e-10, (name, np.abs(U.T @ U - np.eye(k)).max())
+        res = np.abs(A @ U - U * Dk).max()
+        assert res < 1e-12 * scale * n, (name, res)
+    # 2 kmax > n: the QL form, same contract
+    A = np.diag(np.linspace(1.0, 0.01, 50))
+    U, Dk, r = nle.eigen_decomposition_topk(A, 40)
+    assert r == 50 and np.allclose(Dk, np.linspace(1.0, 0.01, 50)[:40], atol=1e-14)
+    # diagonal (every off-diagonal of T is zero), identity (all eigenvalues equal), zero matrix (no eigenvalue kept)
+    U, Dk, r = nle.eigen_decomposition_topk(A, 7)
+    assert r == 50 and np.abs(np.abs(U[:7, :7]) - np.eye(7)).max() < 1e-12
+    U, Dk, r = nle.eigen_decomposition_topk(np.eye(40), 5)
+    assert r == 40 and np.allclose(Dk, 1.0, atol=1e-15) and np.abs(U.T @ U - np.eye(5)).max() < 1e-12
+    U, Dk, r = nle.eigen_decomposition_topk(np.zeros((40, 40)), 5)
+    assert r == 0 and np.abs(Dk).max() < 1e-300
+
+
 def test_leading_eigenvectors_by_inverse_iteration(nle):
     """nle_eigen_decomposition_top with kmax <= n / 2 takes the eigenvectors from inverse iteration on the tridiagonal
     form (csrc/eigen_sym.cpp): against LAPACK on spectra like Q's (decaying from 1), with tight clusters, with exactly

@@ -112,6 +112,16 @@ DRIVER = textwrap.dedent(r"""
             std::vector<double> Uk((size_t)n * n), Dk(n);
             if (!nleh::eigen_decomposition_top(A.data(), n, 1e-10, std::max(1, n / 4), Uk.data(), Dk.data(), &rt) || rt < 1) ++bad;
             for (int j = 1; j < n; ++j) if (Dk[j] > Dk[j - 1] + 1e-12 * std::fabs(Dk[0])) ++bad;
+            // and the bisection form of it (Sturm counts; eight shifts a vector, up to eight vectors a sweep), and the
+            // few-below-the-cut form the deflated root of Wa uses
+            int rb = 0, kept = 0;
+            const int kb = std::max(1, n / 4);
+            std::vector<double> Ub((size_t)n * n), Db(n), Dlow(n), Ulow((size_t)n * n);
+            double lmax = 0, lmin = 0;
+            if (!nleh::eigen_decomposition_topk(A.data(), n, 1e-10, kb, Ub.data(), Db.data(), &rb) || rb != rt) { std::printf("n=%d: bisection rank %d vs %d\n", n, rb, rt); ++bad; }
+            for (int j = 0; j < std::min(kb, n); ++j) if (std::fabs(Db[j] - Dk[j]) > 1e-11 * (std::fabs(Dk[0]) + 1e-300)) ++bad;
+            if (!nleh::sym_eigen_below(A.data(), n, 1e-10, n / 8, &kept, &lmax, &lmin, Dlow.data(), Ulow.data()) || kept != rt) ++bad;
+            if (std::fabs(lmax - Dk[0]) > 1e-11 * (std::fabs(Dk[0]) + 1e-300)) ++bad;
         }
         {   // not positive definite: must be refused
             std::vector<double> A = {1, 2, 2, 1}, L(4), Li(4);
