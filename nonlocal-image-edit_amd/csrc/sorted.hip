@@ -713,12 +713,14 @@ bool sorted_recurrence(GridSpec gs, double hx, double* kappa) {
 
 // Where the moment form of k_sorted_pass stays inside the normal range of fp64 with a wide margin: e_0 = exp(-u^2 / hx^2)
 // (u = c - cb0), the powers rho^b = exp(b (2 cs u - cs^2) / hx^2), b < nC, and the running products y e_0 rho^b =
-// y e_b / C_b <= y exp(nC^2 cs^2 / hx^2).  Very narrow kernels (W / hx beyond ~14) keep the table / recurrence forms.
+// y e_b / C_b <= y exp(nC^2 cs^2 / hx^2): every intermediate lies within exp(+-span^2 / hx^2), span = umax + nC cs, times the
+// Sinkhorn scalings (<= 1 / eps = 1e10 each).  The bound 500 (1e217) leaves 1e90 on either side; cfg5's 30 columns at
+// hx = W / 8 sit at 251.  Very narrow kernels (W / hx beyond ~20) keep the table / recurrence forms.
 bool sorted_moments_ok(GridSpec gs, double hx) {
     if (std::getenv("NLE_SORTED_TABLE") != nullptr || std::getenv("NLE_SORTED_NO_MOMENTS") != nullptr) return false;
     const double cs = gs.colStep, umax = std::max<double>(gs.colOff, gs.W - 1 - gs.colOff), nC = gs.nSelCols;
     const double span = umax + nC * cs;
-    return span * span / (hx * hx) < 200.0 && nC * (2.0 * cs * umax + nC * cs * cs) / (hx * hx) < 400.0;
+    return span * span / (hx * hx) < 500.0;
 }
 
 hipError_t sorted_pass(hipStream_t s, int mode, GridSpec gs, int row0, int nrows_local, const unsigned short* d_scol,
