@@ -554,25 +554,41 @@ NLE_SIMD_CLONES void apply_rotations_rows(int ldz, double* Z, int k0, int nvec, 
 
 // Y (n x ncols, column-major, ld n) <- Q Y with Q = P_{n-1} ... P_1, P_i = I - u_i u_i^T / h_i on rows 0..i-1
 // (u_i = column i of V, rows 0..i-1): the product `tridiagonalize` accumulates, applied to a few columns.
-NLE_SIMD_CLONES void back_transform_cols(int n, const double* V, const double* hs, double* Y, int j0, int j1) {
-    constexpr int CB = 4;
-    for (int jb = j0; jb < j1; jb += CB) {
-        const int nb = std::min(CB, j1 - jb);
-        for (int i = 1; i < n; ++i) {
-            const double h = hs[i];
-            if (h == 0.0) continue;
-            const double* u = V + (size_t)i * n;
-            for (int jj = 0; jj < nb; ++jj) {
-                double* y = Y + (size_t)(jb + jj) * n;
-                double g = 0.0;
-#pragma omp simd reduction(+ : g)
-                for (int k = 0; k < i; ++k) g += u[k] * y[k];
-                g /= h;
-#pragma omp simd
-                for (int k = 0; k < i; ++k) y[k] -= g * u[k];
-            }
+// Eight columns share every load of a reflector (their eight dot products are independent chains; vector by vector the
+// loop waited on one horizontal sum and one division per reflector and column): 0.20 -> 0.0x ms for 50 vectors at n = 200.
+template <int NB>
+static inline __attribute__((always_inline)) void back_transform_block(int n, const double* V, const double* hs, double* Y0, int nb) {
+    double* y[NB];
+    for (int jj = 0; jj < NB; ++jj) y[jj] = Y0 + (size_t)(jj < nb ? jj : nb - 1) * n;  // (columns >= nb: recomputed, not stored)
+    for (int i = 1; i < n; ++i) {
+        const double h = hs[i];
+        if (h == 0.0) continue;
+        const double* u = V + (size_t)i * n;
+        const int i8 = i & ~7;
+        v8d acc[NB];
+        for (int jj = 0; jj < NB; ++jj) acc[jj] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < i8; k += 8) {
+            const v8d uv = ld8(u + k);
+            for (int jj = 0; jj < NB; ++jj) acc[jj] += uv * ld8(y[jj] + k);
         }
+        double g[NB];
+        for (int jj = 0; jj < NB; ++jj) g[jj] = hsum8(acc[jj]);
+        for (int k = i8; k < i; ++k)
+            for (int jj = 0; jj < NB; ++jj) g[jj] += u[k] * y[jj][k];
+        const double rh = 1.0 / h;
+        for (int jj = 0; jj < NB; ++jj) g[jj] *= rh;
+        for (int k = 0; k < i8; k += 8) {
+            const v8d uv = ld8(u + k);
+            for (int jj = 0; jj < NB; ++jj)
+                if (jj < nb) st8(y[jj] + k, ld8(y[jj] + k) - g[jj] * uv);
+        }
+        for (int k = i8; k < i; ++k)
+            for (int jj = 0; jj < nb; ++jj) y[jj][k] -= g[jj] * u[k];
     }
+}
+NLE_SIMD_CLONES void back_transform_cols(int n, const double* V, const double* hs, double* Y, int j0, int j1) {
+    constexpr int CB = 8;
+    for (int jb = j0; jb < j1; jb += CB) back_transform_block<CB>(n, V, hs, Y + (size_t)jb * n, std::min(CB, j1 - jb));
 }
 
 // CPUs that share the calling thread's last-level cache (Linux sysfs), empty if unknown: where helper threads are
@@ -989,6 +1005,140 @@ NLE_SIMD_CLONES static void orth_against_cluster(int n, const double* Zc, int m,
     }
 }
 
+// Inverse iteration (the scheme of tridiag_inverse_iteration below, operation for operation) for EIGHT isolated eigenvalues
+// at once, one per AVX-512 lane: the LU factorisation with partial pivoting and the two substitutions are chains of n
+// dependent steps, so eight shifts cost what one does.  Pivot choices differ per lane: both branches are formed and
+// blended.  Same operations in the same order as the scalar code (whose compiler may contract or reorder a sum or two: the
+// vectors agree to a few ulp, tools/micro/bisect_check.py).  lam8: the shifts (m <= 8 used, the rest repeat the last), idx8: their vector numbers (seeds), Zcols: where the
+// vectors go.  false: a lane did not converge (the caller falls back exactly as for the scalar path).
+#if defined(__x86_64__)
+__attribute__((target("avx512f"))) static inline __m512d x8_fix_tiny(__m512d v, __m512d vtiny) {  // |v| < tiny: copysign(tiny, v == 0 ? 1 : v)
+    const __m512d zero = _mm512_setzero_pd();
+    const __m512i signbit = _mm512_set1_epi64((long long)0x8000000000000000ull);
+    const __mmask8 small = _mm512_cmp_pd_mask(_mm512_abs_pd(v), vtiny, _CMP_LT_OQ);
+    const __mmask8 iszero = _mm512_cmp_pd_mask(v, zero, _CMP_EQ_OQ);
+    __m512i sg = _mm512_and_epi64(_mm512_castpd_si512(v), signbit);
+    sg = _mm512_mask_mov_epi64(sg, iszero, _mm512_setzero_si512());
+    const __m512d t = _mm512_castsi512_pd(_mm512_or_epi64(_mm512_castpd_si512(vtiny), sg));
+    return _mm512_mask_mov_pd(v, small, t);
+}
+struct X8Arr {  // n vectors of eight doubles in 64-byte aligned storage (std::vector<__m512d> drops the alignment)
+    double* p;
+    __attribute__((target("avx512f"))) inline __m512d operator()(int i) const { return _mm512_load_pd(p + (size_t)8 * i); }
+    __attribute__((target("avx512f"))) inline void set(int i, __m512d v) const { _mm512_store_pd(p + (size_t)8 * i, v); }
+};
+__attribute__((target("avx512f"))) static bool inverse_iteration_x8(int n, const double* d, const double* e, const double* lam8,
+                                                                   const int* idx8, int m, double onenrm, double* const* Zcols) {
+    const double eps = std::ldexp(1.0, -52), tiny = eps * onenrm;
+    std::vector<double> store((size_t)7 * n * 8 + 8);
+    double* base = store.data();
+    while (reinterpret_cast<uintptr_t>(base) & 63) ++base;
+    X8Arr a{base}, ra{base + (size_t)8 * n}, b{base + (size_t)16 * n}, c{base + (size_t)24 * n}, dd{base + (size_t)32 * n},
+        x{base + (size_t)40 * n}, y{base + (size_t)48 * n};
+    std::vector<__mmask8> piv(n);
+    const __m512d vtiny = _mm512_set1_pd(tiny), zero = _mm512_setzero_pd();
+    double lamv[8];
+    for (int l = 0; l < 8; ++l) lamv[l] = lam8[l < m ? l : m - 1];
+    const __m512d xj = _mm512_loadu_pd(lamv);
+    for (int i = 0; i < n; ++i) {
+        a.set(i, _mm512_sub_pd(_mm512_set1_pd(d[i]), xj));
+        {
+            const __m512d ev = _mm512_set1_pd(i + 1 < n ? e[i + 1] : 0.0);
+            b.set(i, ev);
+            c.set(i, ev);
+        }
+        dd.set(i, zero);
+    }
+    for (int i = 0; i + 1 < n; ++i) {
+        const __m512d ai = a(i), ci = c(i), an = a(i + 1), bi = b(i);
+        const __mmask8 ge = _mm512_cmp_pd_mask(_mm512_abs_pd(ai), _mm512_abs_pd(ci), _CMP_GE_OQ);
+        const __m512d af = x8_fix_tiny(ai, vtiny);
+        const __m512d num = _mm512_mask_blend_pd(ge, ai, ci), den = _mm512_mask_blend_pd(ge, ci, af);
+        const __m512d mult = _mm512_div_pd(num, den);
+        const __m512d X = _mm512_mask_blend_pd(ge, bi, an), Yv = _mm512_mask_blend_pd(ge, an, bi);
+        a.set(i + 1, _mm512_sub_pd(X, _mm512_mul_pd(mult, Yv)));
+        a.set(i, _mm512_mask_blend_pd(ge, ci, af));
+        if (i + 2 < n) {
+            const __m512d bn = b(i + 1);
+            dd.set(i, _mm512_mask_blend_pd(ge, bn, zero));
+            b.set(i + 1, _mm512_mask_blend_pd(ge, _mm512_mul_pd(_mm512_sub_pd(zero, mult), bn), bn));
+        }
+        b.set(i, _mm512_mask_blend_pd(ge, an, bi));
+        c.set(i, mult);
+        piv[i] = (__mmask8)~ge;
+    }
+    a.set(n - 1, x8_fix_tiny(a(n - 1), vtiny));
+    const __m512d one = _mm512_set1_pd(1.0);
+    for (int i = 0; i < n; ++i) ra.set(i, _mm512_div_pd(one, a(i)));
+    {
+        unsigned long long seed[8];
+        for (int l = 0; l < 8; ++l) seed[l] = 0x2545F4914F6CDD1Dull ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(idx8[l < m ? l : m - 1] + 1));
+        double xs[8];
+        for (int i = 0; i < n; ++i) {
+            for (int l = 0; l < 8; ++l) {
+                seed[l] ^= seed[l] << 13, seed[l] ^= seed[l] >> 7, seed[l] ^= seed[l] << 17;
+                xs[l] = (double)(seed[l] >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+            }
+            x.set(i, _mm512_loadu_pd(xs));
+        }
+    }
+    const __m512d veps = _mm512_set1_pd(eps), vfloor = _mm512_set1_pd(1e-300), vn = _mm512_set1_pd((double)n * onenrm);
+    const __m512d an1 = _mm512_max_pd(veps, _mm512_abs_pd(a(n - 1)));
+    __mmask8 done = 0;
+    const __mmask8 want = (__mmask8)((1u << m) - 1u);
+    for (int it = 0; it < 8 && (done & want) != want; ++it) {
+        __m512d s1 = zero;
+        for (int i = 0; i < n; ++i) s1 = _mm512_add_pd(s1, _mm512_abs_pd(x(i)));
+        const __m512d scl = _mm512_div_pd(_mm512_mul_pd(vn, an1), _mm512_max_pd(s1, vfloor));
+        __m512d yi = _mm512_mul_pd(x(0), scl);
+        for (int i = 0; i + 1 < n; ++i) {  // forward: row interchanges and multipliers
+            const __m512d yn = _mm512_mul_pd(x(i + 1), scl);
+            const __m512d p0 = _mm512_mask_blend_pd(piv[i], yi, yn), p1 = _mm512_mask_blend_pd(piv[i], yn, yi);
+            y.set(i, p0);
+            yi = _mm512_sub_pd(p1, _mm512_mul_pd(c(i), p0));
+        }
+        y.set(n - 1, yi);
+        for (int i = n - 1; i >= 0; --i) {  // back substitution with the three upper diagonals
+            __m512d t = y(i);
+            if (i + 1 < n) t = _mm512_sub_pd(t, _mm512_mul_pd(b(i), x(i + 1)));
+            if (i + 2 < n) t = _mm512_sub_pd(t, _mm512_mul_pd(dd(i), x(i + 2)));
+            x.set(i, _mm512_mul_pd(t, ra(i)));
+        }
+        __m512d nrm = zero;
+        for (int i = 0; i < n; ++i) nrm = _mm512_add_pd(nrm, _mm512_mul_pd(x(i), x(i)));
+        nrm = _mm512_sqrt_pd(nrm);
+        {
+            double nv[8];
+            _mm512_storeu_pd(nv, nrm);
+            for (int l = 0; l < m; ++l)
+                if (!(nv[l] > 0.0) || !std::isfinite(nv[l])) return false;
+        }
+        for (int i = 0; i < n; ++i) x.set(i, _mm512_div_pd(x(i), nrm));
+        if (it >= 1) {  // residual ||(T - lam I) x||_2 against the ORIGINAL eigenvalue
+            __m512d res = zero;
+            for (int i = 0; i < n; ++i) {
+                __m512d t = _mm512_mul_pd(_mm512_sub_pd(_mm512_set1_pd(d[i]), xj), x(i));
+                if (i > 0) t = _mm512_add_pd(t, _mm512_mul_pd(_mm512_set1_pd(e[i]), x(i - 1)));
+                if (i + 1 < n) t = _mm512_add_pd(t, _mm512_mul_pd(_mm512_set1_pd(e[i + 1]), x(i + 1)));
+                res = _mm512_add_pd(res, _mm512_mul_pd(t, t));
+            }
+            const __mmask8 ok = _mm512_cmp_pd_mask(_mm512_sqrt_pd(res), _mm512_set1_pd(1e3 * eps * onenrm), _CMP_LE_OQ);
+            const __mmask8 fresh = (__mmask8)(ok & ~done & want);
+            if (fresh) {
+                double xs[8];
+                for (int i = 0; i < n; ++i) {
+                    _mm512_storeu_pd(xs, x(i));
+                    for (int l = 0; l < m; ++l)
+                        if (fresh & (1u << l)) Zcols[l][i] = xs[l];
+                }
+                done |= fresh;
+            }
+        }
+    }
+    return (done & want) == want;
+}
+#endif
+
 // Eigenvectors of the symmetric tridiagonal T (diagonal d[0..n), sub-diagonal e[1..n)) for k of its eigenvalues
 // lam[0..k), given in DESCENDING order and accurate to rounding, by inverse iteration -- the scheme of LAPACK's dstein:
 // LU of T - lam I with partial pivoting (tiny pivots perturbed), a few solves from a pseudo-random start, vectors of
@@ -1239,6 +1389,30 @@ bool tridiag_inverse_iteration(int n, const double* d, const double* e, const do
                 if (!blk && !do_group(starts[g], starts[g + 1])) return false;
                 done_group[g] = 1;
             }
+#if defined(__x86_64__)
+    {   // isolated eigenvalues (clusters of one: nothing to orthogonalise against), eight per sweep
+        static const bool x8 = __builtin_cpu_supports("avx512f") && std::getenv("NLE_EIG_NO_X8") == nullptr;
+        std::vector<int> single;
+        if (x8 && n >= 16)
+            for (int g = 0; g < ngroups; ++g)
+                if (!done_group[g] && starts[g + 1] - starts[g] == 1) single.push_back(g);
+        if (single.size() >= 3)
+            for (size_t s0 = 0; s0 < single.size(); s0 += 8) {
+                const int m8 = (int)std::min<size_t>(8, single.size() - s0);
+                double lam8[8];
+                int idx8[8];
+                double* zc[8];
+                for (int l = 0; l < m8; ++l) {
+                    const int j = starts[single[s0 + l]];
+                    lam8[l] = lam[j];
+                    idx8[l] = j;
+                    zc[l] = Z + (size_t)j * n;
+                }
+                if (!inverse_iteration_x8(n, d, e, lam8, idx8, m8, onenrm, zc)) return false;
+                for (int l = 0; l < m8; ++l) done_group[single[s0 + l]] = 1;
+            }
+    }
+#endif
     // work of a cluster of m vectors ~ m n (8 + m) (solves + re-orthogonalisation), ~2.6 ns per unit on the GPU box's cores;
     // threads (~0.1 ms to start and join) pay off from ~0.8 ms of it
     double work = 0.0;
