@@ -213,118 +213,100 @@ static inline __attribute__((always_inline)) double hsum8(v8d v) {
     return ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
 }
 
-// The two O(i^2) loops of a step -- p = A u on the lower triangle and the rank-2 update A -= u q^T + q u^T -- take FOUR
-// columns at a time: every vector of u and of the running product is loaded once for four columns' multiply-adds (the
-// one-column loops spend their time on loads, stores and loop control of vectors a dozen long: 10 GFLOP/s on a core that
-// does 40 on the tile products), the small triangle where the four columns start is done in scalar code.
-NLE_SIMD_CLONES void tridiag_reduce(int n, double* V, double* d, double* e, double* hs) {
-    for (int j = 0; j < n; ++j) d[j] = at(V, n, n - 1, j);
+// Householder reduction on the UPPER triangle, column-major, eight columns per sweep.  Step i annihilates column i above the
+// sub-diagonal entry: the vector x = A(0..i-1, i), the columns' active parts A(0..j, j) and the stored reflector u_i (column
+// i, rows < i) are all CONTIGUOUS -- the row-oriented classic (tred2) gathers and scatters a strided row every step.  The two
+// O(i^2) loops of a step, p = A u and A -= u q^T + q u^T, take eight columns at a time over full vectors of eight rows; where
+// a block of columns crosses the diagonal the 8 x 8 triangle is one more vector per column under a 0/1 mask, and the
+// work vectors are zero beyond i: no scalar remainder loops anywhere (they, the strided copies and the scalar O(i) loops
+// were two thirds of the four-column form's 0.33 ms at n = 200).  Reads the whole of V (both triangles mirrored by the
+// caller); on return column i, rows < i, holds u_i with H_i = I - u_i u_i^T / hs[i], d and e the tridiagonal matrix
+// (e[i] couples i - 1 and i): the layout back_transform_cols and the tridiagonal routines take.
+NLE_SIMD_CLONES static void tridiag_reduce_impl(int n, double* V, double* d, double* e, double* hs, const double (*kLe)[8], const double (*kLt)[8]) {
+    std::vector<double> work((size_t)2 * (n + 16), 0.0);
+    double* u = work.data();      // the scaled vector / reflector, zero from i on
+    double* q = u + n + 16;       // p = A u, then q
     for (int i = n - 1; i > 0; --i) {
+        double* x = V + (size_t)i * n;
+        const int i8 = (i + 7) & ~7;
         double scale = 0.0, h = 0.0;
-        for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+#pragma omp simd reduction(+ : scale)
+        for (int k = 0; k < i; ++k) scale += std::fabs(x[k]);
         if (scale == 0.0) {
-            e[i] = d[i - 1];
-            for (int j = 0; j < i; ++j) {
-                d[j] = at(V, n, i - 1, j);
-                at(V, n, i, j) = 0.0;
-                at(V, n, j, i) = 0.0;
+            e[i] = x[i - 1];
+            for (int k = 0; k < i; ++k) x[k] = 0.0;
+            hs[i] = 0.0;
+            continue;
+        }
+        const double rscale = 1.0 / scale;
+#pragma omp simd reduction(+ : h)
+        for (int k = 0; k < i; ++k) {
+            const double t = x[k] * rscale;
+            u[k] = t;
+            h += t * t;
+        }
+        const double f0 = u[i - 1];
+        double g = std::sqrt(h);
+        if (f0 > 0) g = -g;
+        e[i] = scale * g;
+        h -= f0 * g;
+        u[i - 1] = f0 - g;
+        for (int k = i; k < i8; ++k) u[k] = 0.0;
+        for (int k = 0; k < i8; ++k) q[k] = 0.0;
+#pragma omp simd
+        for (int k = 0; k < i; ++k) x[k] = u[k];
+        // q = A u on the leading i x i block
+        for (int j0 = 0; j0 < i; j0 += 8) {
+            const int nc = std::min(8, i - j0);
+            const double* col[8];
+            double uj[8];
+            for (int c = 0; c < 8; ++c) {
+                col[c] = V + (size_t)(j0 + (c < nc ? c : 0)) * n;
+                uj[c] = c < nc ? u[j0 + c] : 0.0;
             }
-        } else {
-            for (int k = 0; k < i; ++k) {
-                d[k] /= scale;
-                h += d[k] * d[k];
+            v8d acc[8];
+            for (int c = 0; c < 8; ++c) acc[c] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < j0; k += 8) {
+                const v8d uv = ld8(u + k);
+                v8d qv = ld8(q + k);
+                for (int c = 0; c < 8; ++c) {
+                    const v8d cv = ld8(col[c] + k);
+                    acc[c] += cv * uv;
+                    qv += cv * uj[c];
+                }
+                st8(q + k, qv);
             }
-            double f = d[i - 1];
-            double g = std::sqrt(h);
-            if (f > 0) g = -g;
-            e[i] = scale * g;
-            h -= f * g;
-            d[i - 1] = f - g;
-            for (int j = 0; j < i; ++j) e[j] = 0.0;
-            // e = A d on the leading i x i block (lower triangle stored)
-            for (int j0 = 0; j0 < i; j0 += 4) {
-                const int nc = std::min(4, i - j0), kk = j0 + nc;
-                double* col[4];
-                double fc[4], gc[4];
-                for (int c = 0; c < nc; ++c) {
-                    const int j = j0 + c;
-                    col[c] = &at(V, n, 0, j);
-                    fc[c] = d[j];
-                    at(V, n, j, i) = fc[c];
-                    gc[c] = e[j] + col[c][j] * fc[c];
-                    for (int k = j + 1; k < kk; ++k) {  // the triangle between the block's columns
-                        gc[c] += col[c][k] * d[k];
-                        e[k] += col[c][k] * fc[c];
-                    }
+            {
+                const v8d uv = ld8(u + j0);
+                v8d qv = ld8(q + j0);
+                for (int c = 0; c < 8; ++c) {
+                    const v8d cv = ld8(col[c] + j0);
+                    acc[c] += (cv * ld8(kLe[c])) * uv;
+                    qv += (cv * ld8(kLt[c])) * uj[c];
                 }
-                for (int c = nc; c < 4; ++c) {
-                    col[c] = col[0];
-                    fc[c] = 0.0;
-                    gc[c] = 0.0;
-                }
-                v8d a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
-                int k = kk;
-                for (; k + 8 <= i; k += 8) {
-                    const v8d dv = ld8(d + k);
-                    v8d ev = ld8(e + k);
-                    const v8d c0 = ld8(col[0] + k), c1 = ld8(col[1] + k), c2 = ld8(col[2] + k), c3 = ld8(col[3] + k);
-                    a0 += c0 * dv;
-                    a1 += c1 * dv;
-                    a2 += c2 * dv;
-                    a3 += c3 * dv;
-                    ev += c0 * fc[0] + c1 * fc[1] + c2 * fc[2] + c3 * fc[3];
-                    st8(e + k, ev);
-                }
-                double t0 = hsum8(a0), t1 = hsum8(a1), t2 = hsum8(a2), t3 = hsum8(a3);
-                for (; k < i; ++k) {
-                    const double dk = d[k];
-                    t0 += col[0][k] * dk;
-                    t1 += col[1][k] * dk;
-                    t2 += col[2][k] * dk;
-                    t3 += col[3][k] * dk;
-                    e[k] += col[0][k] * fc[0] + col[1][k] * fc[1] + col[2][k] * fc[2] + col[3][k] * fc[3];
-                }
-                const double tt[4] = {t0, t1, t2, t3};
-                for (int c = 0; c < nc; ++c) e[j0 + c] = gc[c] + tt[c];
+                st8(q + j0, qv);
             }
-            f = 0.0;
-            for (int j = 0; j < i; ++j) {
-                e[j] /= h;
-                f += e[j] * d[j];
-            }
-            const double hh = f / (h + h);
-            for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
-            // A -= d e^T + e d^T on the block, then the next row into d
-            for (int j0 = 0; j0 < i; j0 += 4) {
-                const int nc = std::min(4, i - j0), kk = j0 + nc;
-                double* col[4];
-                double fc[4], gc[4];
-                for (int c = 0; c < nc; ++c) {
-                    const int j = j0 + c;
-                    col[c] = &at(V, n, 0, j);
-                    fc[c] = d[j];
-                    gc[c] = e[j];
-                    for (int k = j; k < kk; ++k) col[c][k] -= (fc[c] * e[k] + gc[c] * d[k]);
-                }
-                if (nc == 4) {
-                    int k = kk;
-                    for (; k + 8 <= i; k += 8) {
-                        const v8d dv = ld8(d + k), ev = ld8(e + k);
-                        st8(col[0] + k, ld8(col[0] + k) - (ev * fc[0] + dv * gc[0]));
-                        st8(col[1] + k, ld8(col[1] + k) - (ev * fc[1] + dv * gc[1]));
-                        st8(col[2] + k, ld8(col[2] + k) - (ev * fc[2] + dv * gc[2]));
-                        st8(col[3] + k, ld8(col[3] + k) - (ev * fc[3] + dv * gc[3]));
-                    }
-                    for (; k < i; ++k)
-                        for (int c = 0; c < 4; ++c) col[c][k] -= (fc[c] * e[k] + gc[c] * d[k]);
-                } else {
-                    for (int c = 0; c < nc; ++c)
-                        for (int k = kk; k < i; ++k) col[c][k] -= (fc[c] * e[k] + gc[c] * d[k]);
-                }
-            }
-            for (int j = 0; j < i; ++j) {
-                d[j] = at(V, n, i - 1, j);
-                at(V, n, i, j) = 0.0;
+            for (int c = 0; c < nc; ++c) q[j0 + c] += hsum8(acc[c]);
+        }
+        const double rh = 1.0 / h;
+        double f = 0.0;
+#pragma omp simd reduction(+ : f)
+        for (int k = 0; k < i; ++k) {
+            q[k] *= rh;
+            f += q[k] * u[k];
+        }
+        const double hh = f / (h + h);
+#pragma omp simd
+        for (int k = 0; k < i; ++k) q[k] -= hh * u[k];
+        for (int k = i; k < i8; ++k) q[k] = 0.0;
+        // A -= u q^T + q u^T on the block's upper triangle
+        for (int j0 = 0; j0 < i; j0 += 8) {
+            const int nc = std::min(8, i - j0);
+            for (int c = 0; c < nc; ++c) {
+                double* cj = V + (size_t)(j0 + c) * n;
+                const double ujc = u[j0 + c], qjc = q[j0 + c];
+                for (int k = 0; k < j0; k += 8) st8(cj + k, ld8(cj + k) - (ld8(u + k) * qjc + ld8(q + k) * ujc));
+                st8(cj + j0, ld8(cj + j0) - ld8(kLe[c]) * (ld8(u + j0) * qjc + ld8(q + j0) * ujc));
             }
         }
         hs[i] = h;
@@ -332,6 +314,21 @@ NLE_SIMD_CLONES void tridiag_reduce(int n, double* V, double* d, double* e, doub
     hs[0] = 0.0;
     for (int j = 0; j < n; ++j) d[j] = at(V, n, j, j);  // the diagonal of T
     e[0] = 0.0;
+}
+
+void tridiag_reduce(int n, double* V, double* d, double* e, double* hs) {
+    static const double kLe[8][8] = {{1, 0, 0, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0, 0, 0}, {1, 1, 1, 0, 0, 0, 0, 0}, {1, 1, 1, 1, 0, 0, 0, 0},
+                                     {1, 1, 1, 1, 1, 0, 0, 0}, {1, 1, 1, 1, 1, 1, 0, 0}, {1, 1, 1, 1, 1, 1, 1, 0}, {1, 1, 1, 1, 1, 1, 1, 1}};
+    static const double kLt[8][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {1, 0, 0, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0, 0, 0}, {1, 1, 1, 0, 0, 0, 0, 0},
+                                     {1, 1, 1, 1, 0, 0, 0, 0}, {1, 1, 1, 1, 1, 0, 0, 0}, {1, 1, 1, 1, 1, 1, 0, 0}, {1, 1, 1, 1, 1, 1, 1, 0}};
+    if (n < 16) {  // the sweeps read (and rewrite unchanged) up to seven entries past a column's end: give a tiny matrix room
+        std::vector<double> Vp((size_t)n * n + 16, 0.0);
+        std::copy(V, V + (size_t)n * n, Vp.begin());
+        tridiag_reduce_impl(n, Vp.data(), d, e, hs, kLe, kLt);
+        std::copy(Vp.begin(), Vp.begin() + (size_t)n * n, V);
+        return;
+    }
+    tridiag_reduce_impl(n, V, d, e, hs, kLe, kLt);
 }
 
 struct Sweep {
