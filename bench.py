@@ -486,6 +486,28 @@ def main():
                                    "host memory (nle_train_host + nle_apply_u8_host): what NLEFilter::enhance merges back",
                            "pixels_differing_from_the_rounded_sum_of_the_fp32_layers": int((d8 > 0).sum().item()),
                            "max_level_difference": float(d8.max().item())}
+        # and from the 8-bit plane itself (what getLuminanceChannel hands over, src/filter.cpp:460-469): N bytes up, N bytes down
+        h_in8 = ctx.host_alloc((rows1 - rows0, W), dtype=np.uint8)
+        h_in8[...] = h_lum.astype(np.uint8)
+        h_u8b = ctx.host_alloc((n_local,), dtype=np.uint8)
+        ts88 = []
+        for it in range(2 + args.h2h_runs):
+            fence()
+            t1 = time.perf_counter()
+            f2.train_filter_host_u8(h_in8, cfg["n_row"], cfg["n_col"], cfg["hx"], cfg["hy"], cfg["T"], cfg["K"], shape=(H, W))
+            f2.apply_u8_host(None, nle.transform_eigenvalues(f2.eigvals, wts), h_u8b)
+            ts88.append(time.perf_counter() - t1)
+        ts88 = ts88[2:]
+        if dist is not None:
+            tt = torch.tensor(ts88, dtype=torch.float64, device=lum.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ts88 = tt.tolist()
+        med88 = float(np.median(ts88))
+        h2h["u8_in_u8_out"] = {"value": (H * W / 1e6) / med88, "unit": "MP/s", "ms_median": med88 * 1e3, "ms_min": min(ts88) * 1e3,
+                               "runs": len(ts88), "bytes_h2d": int(h_in8.nbytes), "bytes_d2h": int(h_u8b.nbytes),
+                               "what": "the 8-bit luminance plane up (nle_train_host_u8), the 8-bit filtered plane down "
+                                       "(nle_apply_u8_host): one byte per pixel each way",
+                               "equals_the_fp32_input_path": bool(np.array_equal(h_u8b, h_u8))}
         f2.close()
 
     # ---- roofline of the dominant kernel (this rank's launches)

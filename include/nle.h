@@ -249,6 +249,13 @@ int nle_train(nle_ctx* ctx, const float* d_lum, int H, int W, int n_row_samples,
 int nle_train_host(nle_ctx* ctx, const float* h_lum, int H, int W, int n_row_samples,
                    int n_col_samples, double hx, double hy, int n_sinkhorn_iter,
                    int n_eigen_vectors, nle_filter** out);
+/* same, from the 8-bit plane itself: what getLuminanceChannel (src/filter.cpp:460-469) hands trainFilter is the L channel of
+ * an 8-bit Lab image converted to double -- h_lum8 holds those bytes (H x W, this rank's rows in slab-input mode), one byte
+ * per pixel crosses PCIe instead of four and the device widens them.  The filter is the one nle_train_host builds from the
+ * same levels as floats (bit-identical), and it keeps the plane likewise for nle_apply*_host(h_x == NULL). */
+int nle_train_host_u8(nle_ctx* ctx, const unsigned char* h_lum8, int H, int W, int n_row_samples,
+                      int n_col_samples, double hx, double hy, int n_sinkhorn_iter,
+                      int n_eigen_vectors, nle_filter** out);
 void nle_filter_destroy(nle_filter* f);
 /* any out pointer may be NULL.  n_local = pixels of this rank's slab, K = kept eigenpairs
  * (K' of src/filter.cpp:314), r = retained rank of Ka, p = realised sample count. */

@@ -622,6 +622,18 @@ class NLEFilter:
         self.shape = (H, W)
         return self
 
+    def train_filter_host_u8(self, lum8, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter=10, n_eigen_vectors=5,
+                             shape=None):
+        """nle_train_host_u8: the plane as the 8-bit levels themselves (a HOST uint8 array): a quarter of the upload; the
+        same filter as train_filter_host on those levels as floats"""
+        self.close()
+        lum8 = np.ascontiguousarray(lum8, dtype=np.uint8)
+        H, W = self._full_shape(lum8, shape)
+        _check(lib().nle_train_host_u8(self.ctx._h, _np_ptr(lum8), H, W, int(n_row_samples), int(n_col_samples), float(hx),
+                                       float(hy), int(n_sinkhorn_iter), int(n_eigen_vectors), C.byref(self._f)), self.ctx._h)
+        self.shape = (H, W)
+        return self
+
     def apply_layers_host(self, x, n_layers, out):
         """nle_apply_layers_host: x a HOST H x W fp32 array or None (= the training plane kept by
         train_filter_host); out: HOST (L, n_local) fp32 array"""

@@ -1457,6 +1457,30 @@ int nle_train_host(nle_ctx* ctx, const float* h_lum, int H, int W, int n_row_sam
     });
 }
 
+int nle_train_host_u8(nle_ctx* ctx, const unsigned char* h_lum8, int H, int W, int n_row_samples, int n_col_samples, double hx,
+                      double hy, int n_sinkhorn_iter, int n_eigen_vectors, nle_filter** out) {
+    if (!ctx || !h_lum8 || !out) return NLE_ERR_INVALID;
+    *out = nullptr;
+    return guard(ctx, [&] {
+        check_image_size(H, W);
+        HIP_OK(hipSetDevice(ctx->device));
+        size_t npx = (size_t)H * W;  // slab-input mode: h_lum8 holds this rank's rows only
+        if (ctx->slab_input && ctx->world > 1) {
+            int r0, r1;
+            slab(H, ctx->rank, ctx->world, &r0, &r1);
+            npx = (size_t)(r1 - r0) * W;
+        }
+        DevBuf<float> d_lum(std::max<size_t>(npx, 1));
+        DevBuf<unsigned char> d_u8(std::max<size_t>(npx, 1));  // released after train_impl, which has drained the stream by then
+        HIP_OK(hipMemcpyAsync(d_u8.p, h_lum8, npx, hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(nlek::channel8_plane(ctx->stream, d_u8.p, (long long)npx, d_lum.p));
+        nle_filter* f = train_impl(ctx, d_lum.p, H, W, n_row_samples, n_col_samples, hx, hy, n_sinkhorn_iter, n_eigen_vectors);
+        f->plane_bytes = d_lum.n * sizeof(float);
+        f->d_plane = d_lum.take();
+        *out = f;
+    });
+}
+
 void nle_filter_destroy(nle_filter* f) {
     if (!f) return;
     if (f->ctx) f->ctx->filters.erase(f);

@@ -392,6 +392,20 @@ def test_host_buffer_entry_points_match_the_device_ones(nle, oracle, ctx, pinned
         f_dev.apply_u8_host(None, fs, h_o)
     with pytest.raises(nle.NLEError):
         f.apply_u8_host(None, fs, np.empty(H * W - 1, dtype=np.uint8))
+    # the 8-bit plane itself as input (nle_train_host_u8: what getLuminanceChannel hands over, src/filter.cpp:460-469):
+    # the same filter bit for bit, and it keeps the plane for the NULL forms like nle_train_host
+    if np.array_equal(x, np.rint(x)) and x.min() >= 0 and x.max() <= 255:
+        h_x8 = ctx.host_alloc((H, W), dtype=np.uint8) if pinned else np.empty((H, W), dtype=np.uint8)
+        h_x8[...] = x.astype(np.uint8)
+        f8 = nle.NLEFilter(ctx).train_filter_host_u8(h_x8, nr, nc, hx, hy, T, K)
+        assert np.array_equal(f8.eigvals, f.eigvals) and f8.diag() == f.diag()
+        h_o[...] = 7
+        f8.apply_u8_host(None, fs, h_o)
+        assert np.array_equal(h_o, got)
+        h_y[...] = -1.0
+        f8.apply_layers_host(None, L, h_y)
+        assert rel_l2(h_y, Y_dev) < 1e-6
+        f8.close()
     f.close()
     f_dev.close()
 
