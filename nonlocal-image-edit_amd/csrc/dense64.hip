@@ -2,16 +2,13 @@
 // called at :262, :287, :313) and of the Cholesky shortcuts once everything N-sized is fast -- at p = 400..900 samples the two
 // symmetric eigen-computations and the factorisation of K_A were half of a train step on one host core.
 //
-//   sytrd_dist        Householder tridiagonalisation, ONE persistent launch of G workgroups.  The matrix lives in LDS, whole
-//                     columns dealt cyclically (column j -> workgroup j % G, both triangles stored, so y = A v needs no
-//                     cross-workgroup sum: a workgroup forms the entries of y that belong to its own columns).  Per step k two
-//                     hand-offs through global memory, both "the data is the flag" (MI355X_MICROARCH.md, visibility: 8-byte
-//                     agent-scope atomic stores and loads on both sides, every word written once per launch into a buffer
-//                     pre-filled with an impossible bit pattern, consumers re-read until no word is unset):
-//                       v_k, tau_k  from the owner of column k to everybody      (one -> all)
-//                       y_j         from the owner of column j to everybody      (all -> all)
-//                     The owner of column k+1 updates that column first, forms v_{k+1} and publishes it before it touches its
-//                     other columns, so the next step's vector is in flight under the rank-2 update.
+//   sytrd_dist        Householder tridiagonalisation, ONE persistent launch of G workgroups, every WAVE autonomous: whole
+//                     columns dealt cyclically to waves (both triangles stored), vectors in registers, ONE hand-off per
+//                     step through global memory, "the data is the flag" (MI355X_MICROARCH.md, visibility: 8-byte
+//                     agent-scope atomic stores and loads, every word written once per launch into a buffer pre-filled with
+//                     an impossible bit pattern, consumers re-read until no word is unset): the y values of the step and
+//                     the next column as it stands; v, tau, beta and w are then formed redundantly by every wave
+//                     (k_sytrd_wave below; round 3's form had two hand-offs and five barriers per step).
 //   tridiag_bisect    all eigenvalues of the tridiagonal matrix by Sturm counts, one wave per eigenvalue, 64 section points
 //                     per round (the interval shrinks 65x per pass over d, e): ~10 rounds.
 //   sytrd_back        back-transformation of K eigenvectors of T (one wave per vector, the vector in registers).
@@ -38,197 +35,391 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// The same sum on the DPP network (row shifts inside the 16-lane rows, then the two row broadcasts): ~20 vector instructions
+// instead of six dependent LDS permutes per half of the double (~900 cycles measured in the reduction's step).  Every lane
+// receives the total (read from lane 63 through a scalar register).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return x + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double x) {
+    x = dpp_add<0x111, 0xf>(x);  // row_shr:1
+    x = dpp_add<0x112, 0xf>(x);  // row_shr:2
+    x = dpp_add<0x114, 0xf>(x);  // row_shr:4
+    x = dpp_add<0x118, 0xf>(x);  // row_shr:8   -> lane 15 of every row holds the row's sum
+    x = dpp_add<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
+    x = dpp_add<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_bcast(double x, int src_lane /* wave-uniform */) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ tridiagonalisation
 // pub: (n - 2) records of 2 n + 2 doubles, one per step k: v_k (entries k+1 .. n-1, v_k[k+1] = 1), tau_k at [n], beta_k at
 // [n + 1], then y (entries k+1 .. n-1) from [n + 2].  H_k = I - tau_k v_k v_k^T; T = Q^T A Q, Q = H_0 H_1 .. H_{n-3};
 // d_out[i] = T(i, i), e_out[i] = T(i, i-1) (e_out[0] = 0): the layout eigen_sym.cpp's tridiagonal routines take.
-size_t sytrd_pub_elems(int n) { return n > 2 ? (size_t)(n - 2) * (2 * (size_t)n + 2) : 1; }
 
-__global__ __launch_bounds__(kSyT) void k_sytrd_dist(int n, int G, int ldp, const double* __restrict__ A,
+// ------------------------------------------------------------------------- tridiagonalisation, ONE hand-off per step
+// Round 3's kernel (k_sytrd_dist, workgroup-wide: v_k out from the owner of column k, y back from everybody) spent 7 us per
+// step at n = 900 on two hand-offs, five barriers and eleven polls in sequence.  Here every WAVE is autonomous and a step has
+// one hand-off (4.9 ms instead of 6.4 at n = 900, 1.9 instead of 2.3 at n = 400; profiles/r4_dense_solver_timing.txt):
+//   * columns are dealt cyclically to waves (column j -> wave j % (4 G)), whole columns in LDS, both triangles;
+//   * with the y values of step k the owner of column k+1 also publishes that column as it stands (before update k).  Every
+//     wave then forms w_k, the updated column a' = c - v w_{k+1} - w v_{k+1}, and from it v_{k+1}, tau_{k+1}, beta_{k+1}
+//     REDUNDANTLY -- same instructions on the same words in every wave, so all copies agree bit for bit -- instead of waiting
+//     for an owner to broadcast them;
+//   * the rank-2 update of a wave's own columns with (v_k, w_k) and their products with v_{k+1} are one sweep, whose results
+//     are the next step's published y.
+// Vectors live in registers (lane l holds rows l, l + 64, ...), reductions are wave-wide shuffles, the only barrier of a step
+// is the one behind the poll of the published words into LDS (double-buffered by step parity).  Same hand-off discipline as
+// above (handoff.h): every word written once into a buffer pre-filled with an impossible pattern, bounded spins.
+// pub: the records of k_sytrd_dist (v_k, tau_k, beta_k, y_k: what k_sytrd_back and the host read) followed by n - 1 records
+// of n doubles, record k = column k (rows k ..) as published.
+template <int RPL>
+__device__ __forceinline__ double row_bcast(const double (&a)[RPL], int row) {
+    double t = 0.0;
+    const int ms = row >> 6;  // wave-uniform
+#pragma unroll
+    for (int m = 0; m < RPL; ++m)
+        if (m == ms) t = a[m];
+    return lane_bcast(t, row & 63);
+}
+
+template <int RPL>
+__global__ __launch_bounds__(kSyT) void k_sytrd_wave(int n, int G, int cw, int ldc, const double* __restrict__ A,
                                                     const double* __restrict__ diag_add, double* pub,
                                                     double* __restrict__ d_out, double* __restrict__ e_out, int* status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int cloc = (n + G - 1) / G;
-    double* panel = reinterpret_cast<double*>(smem_raw);  // [cloc][ldp]: column g + l G, all rows
-    double* sv0 = panel + (size_t)cloc * ldp;             // v_k, double-buffered by step parity
-    double* sv1 = sv0 + ldp;
-    double* sw = sv1 + ldp;                               // w_k
-    double* sred = sw + ldp;                              // [0..3] norm partials, [4..7] y.v partials
-    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* cols = reinterpret_cast<double*>(smem_raw);       // [4 waves][cw][ldc], rows n .. ldc-1 zero
+    double* land = cols + (size_t)4 * cw * ldc;                // [2 parities][y: ldc | c: ldc]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NW = 4 * G, gw = blockIdx.x * 4 + wave;
     const size_t S = 2 * (size_t)n + 2;
+    double* cbase = pub + (size_t)(n - 2) * S;                 // column records, stride ldc
+    double* mycols = cols + (size_t)wave * cw * ldc;
+    const bool writer = gw == 0;
 
-    for (int l = 0; l < cloc; ++l) {  // lower triangle read, mirrored (SelfAdjointEigenSolver's convention, :207)
-        const int j = g + l * G;
-        if (j >= n) break;
-        for (int i = tid; i < n; i += kSyT) {
-            double v = (i >= j) ? A[(size_t)j * n + i] : A[(size_t)i * n + j];
-            if (i == j && diag_add != nullptr) v += diag_add[i];
-            panel[(size_t)l * ldp + i] = v;
+    // No per-lane predicate guards a memory operation in the step loop (every such `if` is an exec-mask branch, and ~360 of
+    // them per step were most of a first version's 9 us): LDS rows are padded to 64 RPL and zero beyond n, rows that are
+    // done with stay finite and meet a zero of v, w or v', and what must be masked is masked by a select on the VALUE.
+    for (int i = tid; i < 4 * ldc; i += kSyT) land[i] = 0.0;
+    for (int c = 0; c < cw; ++c) {  // lower triangle read, mirrored (SelfAdjointEigenSolver's convention, :207)
+        const int j = gw + c * NW;
+        for (int i = lane; i < ldc; i += 64) {
+            double x = 0.0;
+            if (j < n && i < n) {
+                x = (i >= j) ? A[(size_t)j * n + i] : A[(size_t)i * n + j];
+                if (i == j && diag_add != nullptr) x += diag_add[i];
+            }
+            mycols[(size_t)c * ldc + i] = x;
         }
     }
-    __syncthreads();
-
-    // v_k, tau_k, beta_k from column k (local column l) as it stands; published, and d_k, e_{k+1} written
-    auto householder = [&](int k, int l) {
-        const double* col = panel + (size_t)l * ldp;
+    // v_0, tau_0, beta_0 from column 0 (every wave reads it from the input)
+    double v[RPL], w[RPL], vn[RPL];
+    double tau, beta, dk;
+    {
         double part = 0.0;
-        for (int i = k + 2 + tid; i < n; i += kSyT) part += col[i] * col[i];
-        part = wave_sum(part);
-        if (lane == 0) sred[wave] = part;
-        __syncthreads();
-        const double xn2 = (sred[0] + sred[1]) + (sred[2] + sred[3]);
-        const double alpha = col[k + 1];
-        double tau = 0.0, beta = alpha, scale = 0.0;
-        if (xn2 != 0.0) {
-            beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
+#pragma unroll
+        for (int m = 0; m < RPL; ++m) {
+            const int i = lane + 64 * m;
+            double x = 0.0;
+            if (i >= 1 && i < n) x = A[i];  // column 0, rows >= 1 (lower triangle)
+            v[m] = x;
+            part += i >= 2 ? x * x : 0.0;
+        }
+        part = wave_sum_dpp(part);
+        const double alpha = row_bcast<RPL>(v, 1);
+        dk = A[0] + (diag_add != nullptr ? diag_add[0] : 0.0);
+        double scale = 0.0;
+        tau = 0.0;
+        beta = alpha;
+        if (part != 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + part), alpha);
             tau = (beta - alpha) / beta;
             scale = 1.0 / (alpha - beta);
         }
-        double* rec = pub + (size_t)k * S;
-        for (int i = k + 2 + tid; i < n; i += kSyT) st_pub(rec + i, col[i] * scale);
-        if (tid == 0) {
-            st_pub(rec + k + 1, 1.0);
-            st_pub(rec + n, tau);
-            st_pub(rec + n + 1, beta);
-            d_out[k] = col[k];
-            e_out[k + 1] = beta;
+#pragma unroll
+        for (int m = 0; m < RPL; ++m) {
+            const int i = lane + 64 * m;
+            v[m] = i == 1 ? 1.0 : (i >= 2 && i < n ? v[m] * scale : 0.0);
         }
-    };
-
-    if (g == 0) householder(0, 0);
+    }
+    __syncthreads();  // (land zeroed)
+    // y_0 of the own columns (j >= 1), and column 1 as it stands
+    for (int c = 0; c < cw; ++c) {
+        const int j = gw + c * NW;
+        if (j < 1 || j >= n) continue;  // wave-uniform
+        const double* col = mycols + (size_t)c * ldc;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < RPL; ++m) acc += col[lane + 64 * m] * v[m];
+        acc = wave_sum_dpp(acc);
+        if (lane == 0) st_pub(pub + n + 2 + j, acc);
+        if (j == 1) {
+#pragma unroll
+            for (int m = 0; m < RPL; ++m) st_pub(cbase + (size_t)1 * ldc + lane + 64 * m, col[lane + 64 * m]);
+        }
+    }
+#ifdef NLE_SYTRD_PROBE
+    unsigned long long tp0 = 0, tp1 = 0, tp2 = 0, t_a, t_b;
+#endif
     for (int k = 0; k + 2 < n; ++k) {
-        const double* rec = pub + (size_t)k * S;
-        double* sv = (k & 1) ? sv1 : sv0;
+#ifdef NLE_SYTRD_PROBE
+        t_a = wall_clock64();
+#endif
+        // (1) the published y_k (j = k+1 ..) and column k+1 (rows k+1 ..) into LDS.  All of a thread's words are requested
+        // together and re-requested until none is unset: a poll is a round trip to the coherent level of the memory system.
+        double* ly = land + (size_t)(k & 1) * 2 * ldc;
+        double* lc = ly + ldc;
+        const double* yrec = pub + (size_t)k * S + n + 2;
+        const double* crec = cbase + (size_t)(k + 1) * ldc;
         bool fail = false;
-        double vr[kSyRows], wr[kSyRows];
-        // (1) v_k and tau_k
+        {
+            // (straight-line rounds: a thread's words beyond n - 1 poll word n - 1 again instead of being guarded)
+            constexpr int NP = (RPL + 3) / 4;
+            u64 vy[NP], vc[NP];
+            int idx[NP];
 #pragma unroll
-        for (int m = 0; m < kSyRows; ++m) {
-            const int i = k + 1 + tid + kSyT * m;
-            vr[m] = 0.0;
-            if (i < n) {
-                vr[m] = wait_pub(rec + i, status, fail);
-                sv[i] = vr[m];
+            for (int q = 0; q < NP; ++q) {
+                idx[q] = min(k + 1 + tid + kSyT * q, n - 1);
+                vy[q] = ld_pub(yrec + idx[q]);
+                vc[q] = ld_pub(crec + idx[q]);
+            }
+            // Up to 640 rows TWO sets of requests are in flight, half a round trip apart: a word that lands just after one
+            // request passed is seen by the next ~0.3 us later instead of a whole round trip (~1 us) later (n = 200: 1.01 ->
+            // 0.84 ms, n = 400: 2.07 -> 1.91).  Above, the doubled traffic of more pollers on more words eats the gain.
+            constexpr bool DUAL = RPL <= 10;
+            unsigned spins = 0;
+            u64 ny[NP], nc[NP];
+            if constexpr (DUAL) {
+                __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    ny[q] = ld_pub(yrec + idx[q]);
+                    nc[q] = ld_pub(crec + idx[q]);
+                }
+            }
+            for (;;) {
+                bool missing = false;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) missing = missing || vy[q] == kUnset || vc[q] == kUnset;  // (waits for the older set only)
+                if (!missing) break;
+                if (++spins > kSpinLimit ||
+                    ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    fail = true;
+                    break;
+                }
+                if constexpr (!DUAL) __builtin_amdgcn_s_sleep(1);
+                // (DUAL: the younger set becomes the older one, merged into what is already known; a new set goes out)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const u64 oy = vy[q], oc = vc[q];
+                    u64 fy, fc;
+                    if constexpr (DUAL) {
+                        fy = ny[q];
+                        fc = nc[q];
+                        ny[q] = ld_pub(yrec + idx[q]);
+                        nc[q] = ld_pub(crec + idx[q]);
+                    } else {
+                        fy = ld_pub(yrec + idx[q]);
+                        fc = ld_pub(crec + idx[q]);
+                    }
+                    vy[q] = oy == kUnset ? fy : oy;
+                    vc[q] = oc == kUnset ? fc : oc;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                ly[idx[q]] = __longlong_as_double((long long)vy[q]);
+                lc[idx[q]] = __longlong_as_double((long long)vc[q]);
             }
         }
-        const double tau = wait_pub(rec + n, status, fail);
-        if (__syncthreads_or(fail)) {  // (also: every thread is done with the previous step's update of the panel)
-            if (tid == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        // (2) y_j = A(:, j) . v for this workgroup's columns j > k, published
-        double* yrec = pub + (size_t)k * S + n + 2;
-        for (int l = wave; l < cloc; l += 4) {
-            const int j = g + l * G;
-            if (j <= k || j >= n) continue;
-            const double* col = panel + (size_t)l * ldp;
-            double acc = 0.0;
-            for (int i = k + 1 + lane; i < n; i += 64) acc += col[i] * sv[i];
-            acc = wave_sum(acc);
-            if (lane == 0) st_pub(yrec + j, acc);
-        }
-        // (3) all of y; s = y . v; w = tau (y - (tau s / 2) v)
-        double part = 0.0;
-#pragma unroll
-        for (int m = 0; m < kSyRows; ++m) {
-            const int i = k + 1 + tid + kSyT * m;
-            wr[m] = 0.0;
-            if (i < n) {
-                wr[m] = wait_pub(yrec + i, status, fail);
-                part += wr[m] * vr[m];
-            }
-        }
-        part = wave_sum(part);
-        if (lane == 0) sred[4 + wave] = part;
         if (__syncthreads_or(fail)) {
             if (tid == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        const double s = (sred[4] + sred[5]) + (sred[6] + sred[7]);
+#ifdef NLE_SYTRD_PROBE
+        t_b = wall_clock64(); tp0 += t_b - t_a; t_a = t_b;
+#endif
+        // (2) s = y . v, w = tau (y - (tau s / 2) v) on the active rows (i > k), zero elsewhere.  (Skipping the blocks of 64
+        // rows that are done with costs more than it saves: 15 wave-uniform branches per loop, +1.3 us per step measured --
+        // with one wave per SIMD nothing hides a branch's refetch.  The step loop is kept as straight as it can be.)
+        double yl[RPL], cl[RPL];  // both LDS vectors requested up front
+#pragma unroll
+        for (int m = 0; m < RPL; ++m) {
+            yl[m] = ly[lane + 64 * m];
+            cl[m] = lc[lane + 64 * m];
+        }
+        const double yk1 = ly[k + 1];
+        double pa = 0.0, pb = 0.0;  // two chains of dependent adds instead of one
+#pragma unroll
+        for (int m = 0; m < RPL; ++m) {
+            const int i = lane + 64 * m;
+            w[m] = (i > k && i < n) ? yl[m] : 0.0;
+            if (m & 1) pb += w[m] * v[m];
+            else pa += w[m] * v[m];
+        }
+        const double s = wave_sum_dpp(pa + pb);
         const double hs = 0.5 * tau * s;
 #pragma unroll
-        for (int m = 0; m < kSyRows; ++m) {
-            const int i = k + 1 + tid + kSyT * m;
-            if (i < n) {
-                wr[m] = tau * (wr[m] - hs * vr[m]);
-                sw[i] = wr[m];
-            }
-        }
-        __syncthreads();
-        // (4) A -= v w^T + w v^T on rows and columns > k.  Products rounded separately (no fused multiply-add), so that the
-        // two stored copies of an entry, A(i, j) here and A(j, i) in column i's workgroup, stay bitwise equal.
-        auto update_col = [&](int l) {
-            const int j = g + l * G;
-            double* col = panel + (size_t)l * ldp;
-            const double vj = sv[j], wj = sw[j];
+        for (int m = 0; m < RPL; ++m) w[m] = tau * (w[m] - hs * v[m]);  // (both zero on the other rows)
+        const double wk1 = tau * (yk1 - hs);  // w at row k+1, where v is 1
+        // (3) column k+1 after update k, and from it v_{k+1}, tau_{k+1}, beta_{k+1}
+        pa = 0.0;
+        pb = 0.0;
 #pragma unroll
-            for (int m = 0; m < kSyRows; ++m) {
-                const int i = k + 1 + tid + kSyT * m;
-                if (i < n) col[i] -= __dadd_rn(__dmul_rn(vr[m], wj), __dmul_rn(wr[m], vj));
-            }
-        };
-        const bool next_owner = (k + 3 < n) && ((k + 1) % G == g);  // column k+1 is reduced in step k+1 <= n-3
-        const int l1 = (k + 1) / G;
-        if (next_owner) {
-            if (tau != 0.0) update_col(l1);
-            __syncthreads();
-            householder(k + 1, l1);
+        for (int m = 0; m < RPL; ++m) {
+            const int i = lane + 64 * m;
+            const double cv = cl[m] - __dadd_rn(__dmul_rn(v[m], wk1), w[m]);  // v_{k+1} of v_k is 1
+            vn[m] = (i > k && i < n) ? cv : 0.0;
+            const double sq = i > k + 2 ? vn[m] * vn[m] : 0.0;
+            if (m & 1) pb += sq;
+            else pa += sq;
         }
-        if (tau != 0.0)
-            for (int l = 0; l < cloc; ++l) {
-                const int j = g + l * G;
-                if (j <= k || j >= n || (next_owner && l == l1)) continue;
-                update_col(l);
-            }
-    }
-    __syncthreads();
-    // the trailing 2 x 2 block
-    if (tid == 0) {
-        if ((n - 2) % G == g) {
-            const double* col = panel + (size_t)((n - 2) / G) * ldp;
-            d_out[n - 2] = col[n - 2];
-            e_out[n - 1] = col[n - 1];
+        const double part2 = wave_sum_dpp(pa + pb);
+        const double dk1 = row_bcast<RPL>(vn, k + 1);
+        const double alpha = row_bcast<RPL>(vn, k + 2);
+        // (selects, not a branch: with part2 == 0 the quotients may be 0 / 0 and are discarded; reciprocals by v_rcp_f64 and
+        // two Newton steps -- every wave computes the same bits, and H = I - tau v v^T only needs tau to an ulp or two)
+        const bool nz = part2 != 0.0;
+        const double bq = -copysign(sqrt(alpha * alpha + part2), alpha);
+        double rb = __builtin_amdgcn_rcp(bq), rs = __builtin_amdgcn_rcp(alpha - bq);
+        rb = fma(fma(-bq, rb, 1.0), rb, rb);
+        rs = fma(fma(-(alpha - bq), rs, 1.0), rs, rs);
+        rb = fma(fma(-bq, rb, 1.0), rb, rb);
+        rs = fma(fma(-(alpha - bq), rs, 1.0), rs, rs);
+        const double beta1 = nz ? bq : alpha;
+        const double tau1 = nz ? (bq - alpha) * rb : 0.0;
+        const double scale1 = nz ? rs : 0.0;
+        const bool more = k + 3 < n;
+        if (!more && writer && lane == 0) {  // the trailing 2 x 2 block: column n-2 after the last update is (d_{n-2}, e_{n-1})
+            d_out[n - 2] = dk1;
+            e_out[n - 1] = alpha;
         }
-        if ((n - 1) % G == g) d_out[n - 1] = panel[(size_t)((n - 1) / G) * ldp + n - 1];
-        if (g == 0) e_out[0] = 0.0;
+#pragma unroll
+        for (int m = 0; m < RPL; ++m) {
+            const int i = lane + 64 * m;
+            vn[m] = i == k + 2 ? 1.0 : (i > k + 2 ? vn[m] * scale1 : 0.0);
+        }
+#ifdef NLE_SYTRD_PROBE
+        t_b = wall_clock64(); tp1 += t_b - t_a; t_a = t_b;
+#endif
+        // (4) own columns j >= k+2: A -= v w^T + w v^T (products rounded separately: the two stored copies of an entry stay
+        // bitwise equal), their products with v_{k+1} published as y_{k+1}; column k+2 published as it now stands
+        double* yrec1 = pub + (size_t)(k + 1) * S + n + 2;
+        double* crec1 = cbase + (size_t)(k + 2) * ldc;
+        const int c0 = (k + 2 > gw) ? (k + 2 - gw + NW - 1) / NW : 0;
+        for (int cc = c0; cc < cw; ++cc) {
+            const int j = gw + cc * NW;
+            if (j >= n) break;  // wave-uniform
+            double* col = mycols + (size_t)cc * ldc;
+            const double vj = row_bcast<RPL>(v, j), wj = row_bcast<RPL>(w, j);
+            double x[RPL];  // all of the column's loads in flight together, then the arithmetic, then the stores
+#pragma unroll
+            for (int m = 0; m < RPL; ++m) x[m] = col[lane + 64 * m];
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < RPL; ++m) {
+                x[m] -= __dadd_rn(__dmul_rn(v[m], wj), __dmul_rn(w[m], vj));
+                acc += x[m] * vn[m];
+            }
+#pragma unroll
+            for (int m = 0; m < RPL; ++m) col[lane + 64 * m] = x[m];
+            if (more) {
+                if (j == k + 2) {
+#pragma unroll
+                    for (int m = 0; m < RPL; ++m) st_pub(crec1 + lane + 64 * m, x[m]);
+                }
+                acc = wave_sum_dpp(acc);
+                if (lane == 0) st_pub(yrec1 + j, acc);
+            } else if (j == n - 1) {
+                const double dl = row_bcast<RPL>(x, n - 1);
+                if (lane == 0) d_out[n - 1] = dl;
+            }
+        }
+#ifdef NLE_SYTRD_PROBE
+        t_b = wall_clock64(); tp2 += t_b - t_a;
+#endif
+        if (writer) {  // the record the back-transformation and the host read (after this wave's part of the hand-off)
+            double* rec = pub + (size_t)k * S;
+#pragma unroll
+            for (int m = 0; m < RPL; ++m) {
+                const int i = lane + 64 * m;
+                if (i > k && i < n) rec[i] = v[m];
+            }
+            if (lane == 0) {
+                rec[n] = tau;
+                rec[n + 1] = beta;
+                d_out[k] = dk;
+                e_out[k + 1] = beta;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < RPL; ++m) v[m] = vn[m];
+        tau = tau1;
+        beta = beta1;
+        dk = dk1;
     }
+    if (writer && lane == 0) e_out[0] = 0.0;
+#ifdef NLE_SYTRD_PROBE
+    if (lane == 0 && (gw == 0 || gw == NW - 1)) printf("[sytrd probe] n=%d gw=%d: poll+barrier %.1f us, (2)(3) %.1f us, (4) %.1f us (wall clock, 100 MHz)\n", n, gw, tp0 * 0.01, tp1 * 0.01, tp2 * 0.01);
+#endif
 }
 
 int sytrd_max_n() { return 1152; }
 
-// number of workgroups.  Measured (profiles/r3_dense_solver_timing.txt): the rank-2 update of a workgroup's own columns is a
-// third of a step, so more workgroups win until the all-to-all hand-off of y grows: 32 below n = 256, 64 up to 832, 128
-// above (also what the LDS then allows).
-int sytrd_groups(int n) {
-    const int want = n < 256 ? 32 : (n <= 832 ? 64 : 128);
-    for (int G : {16, 32, 64, 128}) {
-        if (G < want) continue;
-        const size_t cloc = (size_t)(n + G - 1) / G;
-        const size_t bytes = (cloc + 3) * (size_t)((n + 1) & ~1) * 8 + 64;
-        if (bytes <= 150 * 1024) return G;
-    }
+// Distribution of the one-hand-off form: four waves a workgroup, at most `cw` whole columns a wave (4; 3 above n = 960, where
+// four no longer fit in LDS beside the landing zone), as few workgroups as that allows -- every additional one is 256 more
+// pollers of every published word.  n = 900: 57 workgroups; n = 400: 25; n = 1152: 96.
+static int sytrd_cols_per_wave(int n) { return n > 960 ? 3 : 4; }
+// rows per lane the kernel is instantiated for, and with it the padded column length in LDS and in the published records
+static int sytrd_rpl(int n) {
+    const int r = (n + 63) / 64;
+    for (int R : {5, 7, 10, 13, 15, 18})
+        if (r <= R) return R;
     return 0;
 }
+int sytrd_groups(int n) {
+    const int cw = sytrd_cols_per_wave(n);
+    return (n + 4 * cw - 1) / (4 * cw);
+}
+size_t sytrd_pub_elems(int n) { return n > 2 ? (size_t)(n - 2) * (2 * (size_t)n + 2) + (size_t)n * 64 * sytrd_rpl(n) : 1; }
 
 hipError_t sytrd_dist(hipStream_t s, int n, int G, const double* d_A, const double* d_diag_add, double* d_pub, double* d_d,
                       double* d_e, int* d_status) {
     if (n < 3 || n > sytrd_max_n()) return hipErrorInvalidValue;
     if (G <= 0) G = sytrd_groups(n);
-    const int ldp = (n + 1) & ~1;
-    const size_t cloc = (size_t)(n + G - 1) / G;
-    size_t shm = (cloc + 3) * (size_t)ldp * 8 + 64;
-    if (G <= 0 || G > 128 || shm > 160 * 1024) return hipErrorInvalidValue;
+    const int cw = (n + 4 * G - 1) / (4 * G);
+    const int rpl = sytrd_rpl(n), ldc = 64 * rpl;
+    size_t shm = (size_t)(4 * cw + 4) * ldc * 8;
+    if (G > 128 || shm > 160 * 1024) return hipErrorInvalidValue;
     shm = std::max<size_t>(shm, 82 * 1024);  // more than half of a compute unit's LDS: one workgroup per compute unit
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sytrd_dist), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)shm);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(d_pub, 0xFF, sytrd_pub_elems(n) * sizeof(double), s);
+    hipError_t e = hipMemsetAsync(d_pub, 0xFF, sytrd_pub_elems(n) * sizeof(double), s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(d_status, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sytrd_dist, dim3(G), dim3(kSyT), shm, s, n, G, ldp, d_A, d_diag_add, d_pub, d_d, d_e, d_status);
+#define NLE_SYW(R)                                                                                                          \
+    {                                                                                                                       \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sytrd_wave<R>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)shm);                                                                                  \
+        if (e != hipSuccess) return e;                                                                                      \
+        hipLaunchKernelGGL((k_sytrd_wave<R>), dim3(G), dim3(kSyT), shm, s, n, G, cw, ldc, d_A, d_diag_add, d_pub, d_d, d_e,  \
+                           d_status);                                                                                       \
+    }
+    if (rpl == 5) NLE_SYW(5)
+    else if (rpl == 7) NLE_SYW(7)
+    else if (rpl == 10) NLE_SYW(10)
+    else if (rpl == 13) NLE_SYW(13)
+    else if (rpl == 15) NLE_SYW(15)
+    else NLE_SYW(18)
+#undef NLE_SYW
     return hipGetLastError();
 }
 
