@@ -20,6 +20,7 @@
 #include "handoff.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace nlek {
 
@@ -375,10 +376,14 @@ __global__ __launch_bounds__(kSyT) void k_sytrd_wave(int n, int G, int cw, int l
 
 int sytrd_max_n() { return 1152; }
 
-// Distribution of the one-hand-off form: four waves a workgroup, at most `cw` whole columns a wave (4; 3 above n = 960, where
-// four no longer fit in LDS beside the landing zone), as few workgroups as that allows -- every additional one is 256 more
-// pollers of every published word.  n = 900: 57 workgroups; n = 400: 25; n = 1152: 96.
-static int sytrd_cols_per_wave(int n) { return n > 960 ? 3 : 4; }
+// Distribution of the one-hand-off form: four waves a workgroup, `cw` whole columns a wave.  Few workgroups mean few pollers
+// of every published word, many mean a short sweep over the own columns on the critical path: measured (NLE_SYTRD_CW), four
+// columns a wave up to n = 640 (n = 400: 25 workgroups), two above (n = 900: 113 workgroups, 5.9 against 6.6 ms with the
+// upload; one column a wave is slower again).
+static int sytrd_cols_per_wave(int n) {
+    if (const char* e = std::getenv("NLE_SYTRD_CW")) return std::max(1, std::min(4, std::atoi(e)));
+    return n > 640 ? 2 : 4;
+}
 // rows per lane the kernel is instantiated for, and with it the padded column length in LDS and in the published records
 static int sytrd_rpl(int n) {
     const int r = (n + 63) / 64;
@@ -399,7 +404,7 @@ hipError_t sytrd_dist(hipStream_t s, int n, int G, const double* d_A, const doub
     const int cw = (n + 4 * G - 1) / (4 * G);
     const int rpl = sytrd_rpl(n), ldc = 64 * rpl;
     size_t shm = (size_t)(4 * cw + 4) * ldc * 8;
-    if (G > 128 || shm > 160 * 1024) return hipErrorInvalidValue;
+    if (G > 240 || shm > 160 * 1024) return hipErrorInvalidValue;
     shm = std::max<size_t>(shm, 82 * 1024);  // more than half of a compute unit's LDS: one workgroup per compute unit
     hipError_t e = hipMemsetAsync(d_pub, 0xFF, sytrd_pub_elems(n) * sizeof(double), s);
     if (e != hipSuccess) return e;
