@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kSyT) void k_sytrd_wave(int n, int G, int cw, int l
         }
     }
 #ifdef NLE_SYTRD_PROBE
-    unsigned long long tp0 = 0, tp1 = 0, tp2 = 0, t_a, t_b;
+    unsigned long long tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, nspin = 0, t_a, t_b;
 #endif
     for (int k = 0; k + 2 < n; ++k) {
 #ifdef NLE_SYTRD_PROBE
@@ -182,6 +182,9 @@ __global__ __launch_bounds__(kSyT) void k_sytrd_wave(int n, int G, int cw, int l
         const double* yrec = pub + (size_t)k * S + n + 2;
         const double* crec = cbase + (size_t)(k + 1) * ldc;
         bool fail = false;
+#ifdef NLE_SYTRD_PROBE
+        unsigned spins_probe = 0;
+#endif
         {
             // (straight-line rounds: a thread's words beyond n - 1 poll word n - 1 again instead of being guarded)
             constexpr int NP = (RPL + 3) / 4;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(kSyT) void k_sytrd_wave(int n, int G, int cw, int l
             // Up to 640 rows TWO sets of requests are in flight, half a round trip apart: a word that lands just after one
             // request passed is seen by the next ~0.3 us later instead of a whole round trip (~1 us) later (n = 200: 1.01 ->
             // 0.84 ms, n = 400: 2.07 -> 1.91).  Above, the doubled traffic of more pollers on more words eats the gain.
-            constexpr bool DUAL = RPL <= 10;
+            constexpr bool DUAL = RPL <= 10;  // (measured again at n = 900 / 1152 with the probes: two sets there add 0.3 ms of poll time)
             unsigned spins = 0;
             u64 ny[NP], nc[NP];
             if constexpr (DUAL) {
@@ -236,12 +239,18 @@ __global__ __launch_bounds__(kSyT) void k_sytrd_wave(int n, int G, int cw, int l
                     vc[q] = oc == kUnset ? fc : oc;
                 }
             }
+#ifdef NLE_SYTRD_PROBE
+            spins_probe = spins;
+#endif
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 ly[idx[q]] = __longlong_as_double((long long)vy[q]);
                 lc[idx[q]] = __longlong_as_double((long long)vc[q]);
             }
         }
+#ifdef NLE_SYTRD_PROBE
+        t_b = wall_clock64(); tp3 += t_b - t_a; t_a = t_b; nspin += spins_probe;
+#endif
         if (__syncthreads_or(fail)) {
             if (tid == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(kSyT) void k_sytrd_wave(int n, int G, int cw, int l
     }
     if (writer && lane == 0) e_out[0] = 0.0;
 #ifdef NLE_SYTRD_PROBE
-    if (lane == 0 && (gw == 0 || gw == NW - 1)) printf("[sytrd probe] n=%d gw=%d: poll+barrier %.1f us, (2)(3) %.1f us, (4) %.1f us (wall clock, 100 MHz)\n", n, gw, tp0 * 0.01, tp1 * 0.01, tp2 * 0.01);
+    if (lane == 0 && (gw == 0 || gw == NW - 1)) printf("[sytrd probe] n=%d gw=%d: poll %.1f us (%llu extra rounds), barrier %.1f us, (2)(3) %.1f us, (4) %.1f us (wall clock, 100 MHz)\n", n, gw, tp3 * 0.01, nspin, tp0 * 0.01, tp1 * 0.01, tp2 * 0.01);
 #endif
 }
 
