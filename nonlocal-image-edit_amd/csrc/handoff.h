@@ -2,7 +2,7 @@
 // (MI355X_MICROARCH.md, visibility): every word is written once per launch with an 8-byte agent-scope atomic store into a
 // buffer pre-filled with a bit pattern no arithmetic produces, and consumers re-read it with agent-scope atomic loads until
 // it is set.  Spins are bounded; a time-out (or another workgroup's) marks the launch as failed through `status`.
-// Used by the Householder reduction (dense64.hip) and by the fused tail of a Sinkhorn half-iteration (fused.hip).
+// Used by the Householder reduction (dense64.hip: k_sytrd_wave).
 #pragma once
 #include <hip/hip_runtime.h>
 
