@@ -223,93 +223,104 @@ static inline __attribute__((always_inline)) double hsum8(v8d v) {
 // caller); on return column i, rows < i, holds u_i with H_i = I - u_i u_i^T / hs[i], d and e the tridiagonal matrix
 // (e[i] couples i - 1 and i): the layout back_transform_cols and the tridiagonal routines take.
 NLE_SIMD_CLONES static void tridiag_reduce_impl(int n, double* V, double* d, double* e, double* hs, const double (*kLe)[8], const double (*kLt)[8]) {
-    std::vector<double> work((size_t)2 * (n + 16), 0.0);
-    double* u = work.data();      // the scaled vector / reflector, zero from i on
-    double* q = u + n + 16;       // p = A u, then q
-    for (int i = n - 1; i > 0; --i) {
+    // The rank-2 update of step i+1 and the product A u of step i are ONE sweep over the block: an entry is loaded, updated,
+    // stored and multiplied while it is in a register (the two-sweep form loaded it twice; same operations on the same operands
+    // in the same order, bit for bit the same T).  Column i itself is brought up to date first (O(i)): its reflector must be
+    // known before the sweep starts.
+    std::vector<double> work((size_t)4 * (n + 16), 0.0);
+    double* u = work.data();       // the pending update's vectors (step i+1), zero from i+1 on; zero at the start
+    double* q = u + (n + 16);
+    double* un = q + (n + 16);     // this step's reflector and product
+    double* qn = un + (n + 16);
+    for (int i = n - 1; i >= 0; --i) {
         double* x = V + (size_t)i * n;
         const int i8 = (i + 7) & ~7;
+        if (i < n - 1) {  // column i and its diagonal entry after the pending update (u, q are zero beyond row i: the rows below
+                          // the diagonal, and the entries of the next column a last vector reaches, are rewritten unchanged)
+            const double ui = u[i], qi = q[i];
+            for (int k = 0; k <= i; k += 8) st8(x + k, ld8(x + k) - (ld8(u + k) * qi + ld8(q + k) * ui));
+        }
+        if (i == 0) break;
         double scale = 0.0, h = 0.0;
 #pragma omp simd reduction(+ : scale)
         for (int k = 0; k < i; ++k) scale += std::fabs(x[k]);
+        for (int k = 0; k < i8 + 8; ++k) un[k] = 0.0;
+        for (int k = 0; k < i8 + 8; ++k) qn[k] = 0.0;
         if (scale == 0.0) {
             e[i] = x[i - 1];
             for (int k = 0; k < i; ++k) x[k] = 0.0;
-            hs[i] = 0.0;
-            continue;
-        }
-        const double rscale = 1.0 / scale;
+        } else {
+            const double rscale = 1.0 / scale;
 #pragma omp simd reduction(+ : h)
-        for (int k = 0; k < i; ++k) {
-            const double t = x[k] * rscale;
-            u[k] = t;
-            h += t * t;
-        }
-        const double f0 = u[i - 1];
-        double g = std::sqrt(h);
-        if (f0 > 0) g = -g;
-        e[i] = scale * g;
-        h -= f0 * g;
-        u[i - 1] = f0 - g;
-        for (int k = i; k < i8; ++k) u[k] = 0.0;
-        for (int k = 0; k < i8; ++k) q[k] = 0.0;
+            for (int k = 0; k < i; ++k) {
+                const double t = x[k] * rscale;
+                un[k] = t;
+                h += t * t;
+            }
+            const double f0 = un[i - 1];
+            double g = std::sqrt(h);
+            if (f0 > 0) g = -g;
+            e[i] = scale * g;
+            h -= f0 * g;
+            un[i - 1] = f0 - g;
 #pragma omp simd
-        for (int k = 0; k < i; ++k) x[k] = u[k];
-        // q = A u on the leading i x i block
+            for (int k = 0; k < i; ++k) x[k] = un[k];
+        }
+        // the block's upper triangle: A -= u q^T + q u^T (pending), then qn = A un on what was just stored
         for (int j0 = 0; j0 < i; j0 += 8) {
             const int nc = std::min(8, i - j0);
-            const double* col[8];
-            double uj[8];
+            double* col[8];
+            double uj[8], qj[8], unj[8];
             for (int c = 0; c < 8; ++c) {
                 col[c] = V + (size_t)(j0 + (c < nc ? c : 0)) * n;
                 uj[c] = c < nc ? u[j0 + c] : 0.0;
+                qj[c] = c < nc ? q[j0 + c] : 0.0;
+                unj[c] = c < nc ? un[j0 + c] : 0.0;
             }
             v8d acc[8];
             for (int c = 0; c < 8; ++c) acc[c] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
             for (int k = 0; k < j0; k += 8) {
-                const v8d uv = ld8(u + k);
-                v8d qv = ld8(q + k);
+                const v8d uv = ld8(u + k), qv = ld8(q + k), nv = ld8(un + k);
+                v8d pv = ld8(qn + k);
                 for (int c = 0; c < 8; ++c) {
-                    const v8d cv = ld8(col[c] + k);
-                    acc[c] += cv * uv;
-                    qv += cv * uj[c];
+                    const v8d cv = ld8(col[c] + k) - (uv * qj[c] + qv * uj[c]);
+                    if (c < nc) st8(col[c] + k, cv);
+                    acc[c] += cv * nv;
+                    pv += cv * unj[c];
                 }
-                st8(q + k, qv);
+                st8(qn + k, pv);
             }
             {
-                const v8d uv = ld8(u + j0);
-                v8d qv = ld8(q + j0);
+                const v8d uv = ld8(u + j0), qv = ld8(q + j0), nv = ld8(un + j0);
+                v8d pv = ld8(qn + j0);
                 for (int c = 0; c < 8; ++c) {
-                    const v8d cv = ld8(col[c] + j0);
-                    acc[c] += (cv * ld8(kLe[c])) * uv;
-                    qv += (cv * ld8(kLt[c])) * uj[c];
+                    const v8d cv = ld8(col[c] + j0) - ld8(kLe[c]) * (uv * qj[c] + qv * uj[c]);
+                    if (c < nc) st8(col[c] + j0, cv);
+                    acc[c] += (cv * ld8(kLe[c])) * nv;
+                    pv += (cv * ld8(kLt[c])) * unj[c];
                 }
-                st8(q + j0, qv);
+                st8(qn + j0, pv);
             }
-            for (int c = 0; c < nc; ++c) q[j0 + c] += hsum8(acc[c]);
+            for (int c = 0; c < nc; ++c) qn[j0 + c] += hsum8(acc[c]);
         }
-        const double rh = 1.0 / h;
-        double f = 0.0;
+        if (scale != 0.0) {
+            const double rh = 1.0 / h;
+            double f = 0.0;
 #pragma omp simd reduction(+ : f)
-        for (int k = 0; k < i; ++k) {
-            q[k] *= rh;
-            f += q[k] * u[k];
-        }
-        const double hh = f / (h + h);
-#pragma omp simd
-        for (int k = 0; k < i; ++k) q[k] -= hh * u[k];
-        for (int k = i; k < i8; ++k) q[k] = 0.0;
-        // A -= u q^T + q u^T on the block's upper triangle
-        for (int j0 = 0; j0 < i; j0 += 8) {
-            const int nc = std::min(8, i - j0);
-            for (int c = 0; c < nc; ++c) {
-                double* cj = V + (size_t)(j0 + c) * n;
-                const double ujc = u[j0 + c], qjc = q[j0 + c];
-                for (int k = 0; k < j0; k += 8) st8(cj + k, ld8(cj + k) - (ld8(u + k) * qjc + ld8(q + k) * ujc));
-                st8(cj + j0, ld8(cj + j0) - ld8(kLe[c]) * (ld8(u + j0) * qjc + ld8(q + j0) * ujc));
+            for (int k = 0; k < i; ++k) {
+                qn[k] *= rh;
+                f += qn[k] * un[k];
             }
+            const double hh = f / (h + h);
+#pragma omp simd
+            for (int k = 0; k < i; ++k) qn[k] -= hh * un[k];
+            for (int k = i; k < i8 + 8; ++k) qn[k] = 0.0;
+        } else {
+            for (int k = 0; k < i8 + 8; ++k) qn[k] = 0.0;  // no reflector: nothing pending for the next step
         }
         hs[i] = h;
+        std::swap(u, un);
+        std::swap(q, qn);
     }
     hs[0] = 0.0;
     for (int j = 0; j < n; ++j) d[j] = at(V, n, j, j);  // the diagonal of T
