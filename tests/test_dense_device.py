@@ -57,6 +57,23 @@ def test_device_eigensolver_rank_cut_matches_host_solver(nle, ctx):
     assert np.abs(Dd - Dh).max() <= 1e-19
 
 
+@pytest.mark.parametrize("n", [4, 5, 15, 16, 63, 64, 65, 128, 129, 320, 321, 448, 449, 640, 641, 832, 833, 960, 961])
+def test_device_reduction_at_the_switches_of_its_distribution(nle, ctx, n):
+    """k_sytrd_wave (csrc/dense64.hip) is instantiated per padded column length (64 x {5, 7, 10, 13, 15, 18} rows), deals
+    four columns a wave up to n = 640 and two above, polls with two request sets up to 640 rows, and its lanes own rows
+    l, l + 64, ...: the orders on either side of each of those switches, and the smallest ones (one or two workgroups,
+    waves that own no column at all), against LAPACK"""
+    M, lam = _spectrum_matrix(n, 7000 + n, "q" if n % 2 else "mixed")
+    M = 0.5 * (M + M.T)
+    w = np.linalg.eigvalsh(M)[::-1]
+    scale = np.abs(w).max()
+    k = min(n, 8)
+    U, D, r = ctx.sym_eigen_device(M, 0, k)
+    assert np.abs(D - w).max() <= 64 * n * np.finfo(float).eps * scale
+    assert np.abs(M @ U - U * D[:k]).max() <= 1e3 * n * np.finfo(float).eps * scale
+    assert np.abs(U.T @ U - np.eye(k)).max() <= 1e-11
+
+
 @pytest.mark.parametrize("n", [1, 5, 32, 33, 200, 449, 900])
 def test_device_cholesky_with_inverse(nle, ctx, n):
     rng = np.random.default_rng(n)
