@@ -20,6 +20,7 @@
 #include "handoff.h"
 
 #include <algorithm>
+#include <utility>
 #include <cstdlib>
 
 namespace nlek {
@@ -91,6 +92,15 @@ __device__ __forceinline__ double row_bcast(const double (&a)[RPL], int row) {
     for (int m = 0; m < RPL; ++m)
         if (m == ms) t = a[m];
     return lane_bcast(t, row & 63);
+}
+
+template <int RPL, typename F, int... Is>
+__device__ __forceinline__ void segments_impl(F& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int RPL, typename F>
+__device__ __forceinline__ void segments(F& f) {
+    segments_impl<RPL>(f, std::make_integer_sequence<int, RPL>{});
 }
 
 template <int RPL>
@@ -171,212 +181,223 @@ __global__ __launch_bounds__(kSyT) void k_sytrd_wave(int n, int G, int cw, int l
 #ifdef NLE_SYTRD_PROBE
     unsigned long long tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, nspin = 0, t_a, t_b;
 #endif
-    for (int k = 0; k + 2 < n; ++k) {
+    // The step loop in RPL segments of (up to) 64 steps: in segment M0 the blocks of 64 rows below 64 M0 are done with, and
+    // every row loop of the body starts at M0 AT COMPILE TIME -- half the instructions on average, and no branch (a run-time
+    // skip of those blocks costs more than it saves, see above).  The row-(m < M0) entries of v, w, vn are never read.
+    bool dead = false;  // a hand-off timed out (workgroup-uniform): the remaining segments do nothing
+    auto segment = [&](auto M0c) __attribute__((always_inline)) {
+        constexpr int M0 = decltype(M0c)::value;
+        const int k_lo = max(0, 64 * M0 - 1), k_hi = dead ? -1 : min(n - 3, 64 * M0 + 62);
+        for (int k = k_lo; k <= k_hi; ++k) {
 #ifdef NLE_SYTRD_PROBE
-        t_a = wall_clock64();
+            t_a = wall_clock64();
 #endif
-        // (1) the published y_k (j = k+1 ..) and column k+1 (rows k+1 ..) into LDS.  All of a thread's words are requested
-        // together and re-requested until none is unset: a poll is a round trip to the coherent level of the memory system.
-        double* ly = land + (size_t)(k & 1) * 2 * ldc;
-        double* lc = ly + ldc;
-        const double* yrec = pub + (size_t)k * S + n + 2;
-        const double* crec = cbase + (size_t)(k + 1) * ldc;
-        bool fail = false;
+            // (1) the published y_k (j = k+1 ..) and column k+1 (rows k+1 ..) into LDS.  All of a thread's words are requested
+            // together and re-requested until none is unset: a poll is a round trip to the coherent level of the memory system.
+            double* ly = land + (size_t)(k & 1) * 2 * ldc;
+            double* lc = ly + ldc;
+            const double* yrec = pub + (size_t)k * S + n + 2;
+            const double* crec = cbase + (size_t)(k + 1) * ldc;
+            bool fail = false;
 #ifdef NLE_SYTRD_PROBE
-        unsigned spins_probe = 0;
+            unsigned spins_probe = 0;
 #endif
-        {
-            // (straight-line rounds: a thread's words beyond n - 1 poll word n - 1 again instead of being guarded)
-            constexpr int NP = (RPL + 3) / 4;
-            u64 vy[NP], vc[NP];
-            int idx[NP];
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                idx[q] = min(k + 1 + tid + kSyT * q, n - 1);
-                vy[q] = ld_pub(yrec + idx[q]);
-                vc[q] = ld_pub(crec + idx[q]);
-            }
-            // Up to 640 rows TWO sets of requests are in flight, half a round trip apart: a word that lands just after one
-            // request passed is seen by the next ~0.3 us later instead of a whole round trip (~1 us) later (n = 200: 1.01 ->
-            // 0.84 ms, n = 400: 2.07 -> 1.91).  Above, the doubled traffic of more pollers on more words eats the gain.
-            constexpr bool DUAL = RPL <= 10;  // (measured again at n = 900 / 1152 with the probes: two sets there add 0.3 ms of poll time)
-            unsigned spins = 0;
-            u64 ny[NP], nc[NP];
-            if constexpr (DUAL) {
-                __builtin_amdgcn_s_sleep(4);
+            {
+                // (straight-line rounds: a thread's words beyond n - 1 poll word n - 1 again instead of being guarded)
+                constexpr int NP = (RPL + 3) / 4;
+                u64 vy[NP], vc[NP];
+                int idx[NP];
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
-                    ny[q] = ld_pub(yrec + idx[q]);
-                    nc[q] = ld_pub(crec + idx[q]);
+                    idx[q] = min(k + 1 + tid + kSyT * q, n - 1);
+                    vy[q] = ld_pub(yrec + idx[q]);
+                    vc[q] = ld_pub(crec + idx[q]);
                 }
-            }
-            for (;;) {
-                bool missing = false;
+                // Up to 640 rows TWO sets of requests are in flight, half a round trip apart: a word that lands just after one
+                // request passed is seen by the next ~0.3 us later instead of a whole round trip (~1 us) later (n = 200: 1.01 ->
+                // 0.84 ms, n = 400: 2.07 -> 1.91).  Above, the doubled traffic of more pollers on more words eats the gain.
+                constexpr bool DUAL = RPL <= 10;  // (measured again at n = 900 / 1152 with the probes: two sets there add 0.3 ms of poll time)
+                unsigned spins = 0;
+                u64 ny[NP], nc[NP];
+                if constexpr (DUAL) {
+                    __builtin_amdgcn_s_sleep(4);
 #pragma unroll
-                for (int q = 0; q < NP; ++q) missing = missing || vy[q] == kUnset || vc[q] == kUnset;  // (waits for the older set only)
-                if (!missing) break;
-                if (++spins > kSpinLimit ||
-                    ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                    fail = true;
-                    break;
-                }
-                if constexpr (!DUAL) __builtin_amdgcn_s_sleep(1);
-                // (DUAL: the younger set becomes the older one, merged into what is already known; a new set goes out)
-#pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    const u64 oy = vy[q], oc = vc[q];
-                    u64 fy, fc;
-                    if constexpr (DUAL) {
-                        fy = ny[q];
-                        fc = nc[q];
+                    for (int q = 0; q < NP; ++q) {
                         ny[q] = ld_pub(yrec + idx[q]);
                         nc[q] = ld_pub(crec + idx[q]);
-                    } else {
-                        fy = ld_pub(yrec + idx[q]);
-                        fc = ld_pub(crec + idx[q]);
                     }
-                    vy[q] = oy == kUnset ? fy : oy;
-                    vc[q] = oc == kUnset ? fc : oc;
+                }
+                for (;;) {
+                    bool missing = false;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) missing = missing || vy[q] == kUnset || vc[q] == kUnset;  // (waits for the older set only)
+                    if (!missing) break;
+                    if (++spins > kSpinLimit ||
+                        ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        fail = true;
+                        break;
+                    }
+                    if constexpr (!DUAL) __builtin_amdgcn_s_sleep(1);
+                    // (DUAL: the younger set becomes the older one, merged into what is already known; a new set goes out)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const u64 oy = vy[q], oc = vc[q];
+                        u64 fy, fc;
+                        if constexpr (DUAL) {
+                            fy = ny[q];
+                            fc = nc[q];
+                            ny[q] = ld_pub(yrec + idx[q]);
+                            nc[q] = ld_pub(crec + idx[q]);
+                        } else {
+                            fy = ld_pub(yrec + idx[q]);
+                            fc = ld_pub(crec + idx[q]);
+                        }
+                        vy[q] = oy == kUnset ? fy : oy;
+                        vc[q] = oc == kUnset ? fc : oc;
+                    }
+                }
+#ifdef NLE_SYTRD_PROBE
+                spins_probe = spins;
+#endif
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    ly[idx[q]] = __longlong_as_double((long long)vy[q]);
+                    lc[idx[q]] = __longlong_as_double((long long)vc[q]);
                 }
             }
 #ifdef NLE_SYTRD_PROBE
-            spins_probe = spins;
+            t_b = wall_clock64(); tp3 += t_b - t_a; t_a = t_b; nspin += spins_probe;
 #endif
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                ly[idx[q]] = __longlong_as_double((long long)vy[q]);
-                lc[idx[q]] = __longlong_as_double((long long)vc[q]);
+            if (__syncthreads_or(fail)) {
+                if (tid == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dead = true;
+                return;
             }
-        }
 #ifdef NLE_SYTRD_PROBE
-        t_b = wall_clock64(); tp3 += t_b - t_a; t_a = t_b; nspin += spins_probe;
+            t_b = wall_clock64(); tp0 += t_b - t_a; t_a = t_b;
 #endif
-        if (__syncthreads_or(fail)) {
-            if (tid == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-#ifdef NLE_SYTRD_PROBE
-        t_b = wall_clock64(); tp0 += t_b - t_a; t_a = t_b;
-#endif
-        // (2) s = y . v, w = tau (y - (tau s / 2) v) on the active rows (i > k), zero elsewhere.  (Skipping the blocks of 64
-        // rows that are done with costs more than it saves: 15 wave-uniform branches per loop, +1.3 us per step measured --
-        // with one wave per SIMD nothing hides a branch's refetch.  The step loop is kept as straight as it can be.)
-        double yl[RPL], cl[RPL];  // both LDS vectors requested up front
+            // (2) s = y . v, w = tau (y - (tau s / 2) v) on the active rows (i > k), zero elsewhere.  (Skipping the blocks of 64
+            // rows that are done with costs more than it saves: 15 wave-uniform branches per loop, +1.3 us per step measured --
+            // with one wave per SIMD nothing hides a branch's refetch.  The step loop is kept as straight as it can be.)
+            double yl[RPL], cl[RPL];  // both LDS vectors requested up front
 #pragma unroll
-        for (int m = 0; m < RPL; ++m) {
-            yl[m] = ly[lane + 64 * m];
-            cl[m] = lc[lane + 64 * m];
-        }
-        const double yk1 = ly[k + 1];
-        double pa = 0.0, pb = 0.0;  // two chains of dependent adds instead of one
-#pragma unroll
-        for (int m = 0; m < RPL; ++m) {
-            const int i = lane + 64 * m;
-            w[m] = (i > k && i < n) ? yl[m] : 0.0;
-            if (m & 1) pb += w[m] * v[m];
-            else pa += w[m] * v[m];
-        }
-        const double s = wave_sum_dpp(pa + pb);
-        const double hs = 0.5 * tau * s;
-#pragma unroll
-        for (int m = 0; m < RPL; ++m) w[m] = tau * (w[m] - hs * v[m]);  // (both zero on the other rows)
-        const double wk1 = tau * (yk1 - hs);  // w at row k+1, where v is 1
-        // (3) column k+1 after update k, and from it v_{k+1}, tau_{k+1}, beta_{k+1}
-        pa = 0.0;
-        pb = 0.0;
-#pragma unroll
-        for (int m = 0; m < RPL; ++m) {
-            const int i = lane + 64 * m;
-            const double cv = cl[m] - __dadd_rn(__dmul_rn(v[m], wk1), w[m]);  // v_{k+1} of v_k is 1
-            vn[m] = (i > k && i < n) ? cv : 0.0;
-            const double sq = i > k + 2 ? vn[m] * vn[m] : 0.0;
-            if (m & 1) pb += sq;
-            else pa += sq;
-        }
-        const double part2 = wave_sum_dpp(pa + pb);
-        const double dk1 = row_bcast<RPL>(vn, k + 1);
-        const double alpha = row_bcast<RPL>(vn, k + 2);
-        // (selects, not a branch: with part2 == 0 the quotients may be 0 / 0 and are discarded; reciprocals by v_rcp_f64 and
-        // two Newton steps -- every wave computes the same bits, and H = I - tau v v^T only needs tau to an ulp or two)
-        const bool nz = part2 != 0.0;
-        const double bq = -copysign(sqrt(alpha * alpha + part2), alpha);
-        double rb = __builtin_amdgcn_rcp(bq), rs = __builtin_amdgcn_rcp(alpha - bq);
-        rb = fma(fma(-bq, rb, 1.0), rb, rb);
-        rs = fma(fma(-(alpha - bq), rs, 1.0), rs, rs);
-        rb = fma(fma(-bq, rb, 1.0), rb, rb);
-        rs = fma(fma(-(alpha - bq), rs, 1.0), rs, rs);
-        const double beta1 = nz ? bq : alpha;
-        const double tau1 = nz ? (bq - alpha) * rb : 0.0;
-        const double scale1 = nz ? rs : 0.0;
-        const bool more = k + 3 < n;
-        if (!more && writer && lane == 0) {  // the trailing 2 x 2 block: column n-2 after the last update is (d_{n-2}, e_{n-1})
-            d_out[n - 2] = dk1;
-            e_out[n - 1] = alpha;
-        }
-#pragma unroll
-        for (int m = 0; m < RPL; ++m) {
-            const int i = lane + 64 * m;
-            vn[m] = i == k + 2 ? 1.0 : (i > k + 2 ? vn[m] * scale1 : 0.0);
-        }
-#ifdef NLE_SYTRD_PROBE
-        t_b = wall_clock64(); tp1 += t_b - t_a; t_a = t_b;
-#endif
-        // (4) own columns j >= k+2: A -= v w^T + w v^T (products rounded separately: the two stored copies of an entry stay
-        // bitwise equal), their products with v_{k+1} published as y_{k+1}; column k+2 published as it now stands
-        double* yrec1 = pub + (size_t)(k + 1) * S + n + 2;
-        double* crec1 = cbase + (size_t)(k + 2) * ldc;
-        const int c0 = (k + 2 > gw) ? (k + 2 - gw + NW - 1) / NW : 0;
-        for (int cc = c0; cc < cw; ++cc) {
-            const int j = gw + cc * NW;
-            if (j >= n) break;  // wave-uniform
-            double* col = mycols + (size_t)cc * ldc;
-            const double vj = row_bcast<RPL>(v, j), wj = row_bcast<RPL>(w, j);
-            double x[RPL];  // all of the column's loads in flight together, then the arithmetic, then the stores
-#pragma unroll
-            for (int m = 0; m < RPL; ++m) x[m] = col[lane + 64 * m];
-            double acc = 0.0;
-#pragma unroll
-            for (int m = 0; m < RPL; ++m) {
-                x[m] -= __dadd_rn(__dmul_rn(v[m], wj), __dmul_rn(w[m], vj));
-                acc += x[m] * vn[m];
+            for (int m = M0; m < RPL; ++m) {
+                yl[m] = ly[lane + 64 * m];
+                cl[m] = lc[lane + 64 * m];
             }
+            const double yk1 = ly[k + 1];
+            double pa = 0.0, pb = 0.0;  // two chains of dependent adds instead of one
 #pragma unroll
-            for (int m = 0; m < RPL; ++m) col[lane + 64 * m] = x[m];
-            if (more) {
-                if (j == k + 2) {
-#pragma unroll
-                    for (int m = 0; m < RPL; ++m) st_pub(crec1 + lane + 64 * m, x[m]);
-                }
-                acc = wave_sum_dpp(acc);
-                if (lane == 0) st_pub(yrec1 + j, acc);
-            } else if (j == n - 1) {
-                const double dl = row_bcast<RPL>(x, n - 1);
-                if (lane == 0) d_out[n - 1] = dl;
-            }
-        }
-#ifdef NLE_SYTRD_PROBE
-        t_b = wall_clock64(); tp2 += t_b - t_a;
-#endif
-        if (writer) {  // the record the back-transformation and the host read (after this wave's part of the hand-off)
-            double* rec = pub + (size_t)k * S;
-#pragma unroll
-            for (int m = 0; m < RPL; ++m) {
+            for (int m = M0; m < RPL; ++m) {
                 const int i = lane + 64 * m;
-                if (i > k && i < n) rec[i] = v[m];
+                w[m] = (i > k && i < n) ? yl[m] : 0.0;
+                if (m & 1) pb += w[m] * v[m];
+                else pa += w[m] * v[m];
             }
-            if (lane == 0) {
-                rec[n] = tau;
-                rec[n + 1] = beta;
-                d_out[k] = dk;
-                e_out[k + 1] = beta;
-            }
-        }
+            const double s = wave_sum_dpp(pa + pb);
+            const double hs = 0.5 * tau * s;
 #pragma unroll
-        for (int m = 0; m < RPL; ++m) v[m] = vn[m];
-        tau = tau1;
-        beta = beta1;
-        dk = dk1;
-    }
+            for (int m = M0; m < RPL; ++m) w[m] = tau * (w[m] - hs * v[m]);  // (both zero on the other rows)
+            const double wk1 = tau * (yk1 - hs);  // w at row k+1, where v is 1
+            // (3) column k+1 after update k, and from it v_{k+1}, tau_{k+1}, beta_{k+1}
+            pa = 0.0;
+            pb = 0.0;
+#pragma unroll
+            for (int m = M0; m < RPL; ++m) {
+                const int i = lane + 64 * m;
+                const double cv = cl[m] - __dadd_rn(__dmul_rn(v[m], wk1), w[m]);  // v_{k+1} of v_k is 1
+                vn[m] = (i > k && i < n) ? cv : 0.0;
+                const double sq = i > k + 2 ? vn[m] * vn[m] : 0.0;
+                if (m & 1) pb += sq;
+                else pa += sq;
+            }
+            const double part2 = wave_sum_dpp(pa + pb);
+            const double dk1 = row_bcast<RPL>(vn, k + 1);
+            const double alpha = row_bcast<RPL>(vn, k + 2);
+            // (selects, not a branch: with part2 == 0 the quotients may be 0 / 0 and are discarded; reciprocals by v_rcp_f64 and
+            // two Newton steps -- every wave computes the same bits, and H = I - tau v v^T only needs tau to an ulp or two)
+            const bool nz = part2 != 0.0;
+            const double bq = -copysign(sqrt(alpha * alpha + part2), alpha);
+            double rb = __builtin_amdgcn_rcp(bq), rs = __builtin_amdgcn_rcp(alpha - bq);
+            rb = fma(fma(-bq, rb, 1.0), rb, rb);
+            rs = fma(fma(-(alpha - bq), rs, 1.0), rs, rs);
+            rb = fma(fma(-bq, rb, 1.0), rb, rb);
+            rs = fma(fma(-(alpha - bq), rs, 1.0), rs, rs);
+            const double beta1 = nz ? bq : alpha;
+            const double tau1 = nz ? (bq - alpha) * rb : 0.0;
+            const double scale1 = nz ? rs : 0.0;
+            const bool more = k + 3 < n;
+            if (!more && writer && lane == 0) {  // the trailing 2 x 2 block: column n-2 after the last update is (d_{n-2}, e_{n-1})
+                d_out[n - 2] = dk1;
+                e_out[n - 1] = alpha;
+            }
+#pragma unroll
+            for (int m = M0; m < RPL; ++m) {
+                const int i = lane + 64 * m;
+                vn[m] = i == k + 2 ? 1.0 : (i > k + 2 ? vn[m] * scale1 : 0.0);
+            }
+#ifdef NLE_SYTRD_PROBE
+            t_b = wall_clock64(); tp1 += t_b - t_a; t_a = t_b;
+#endif
+            // (4) own columns j >= k+2: A -= v w^T + w v^T (products rounded separately: the two stored copies of an entry stay
+            // bitwise equal), their products with v_{k+1} published as y_{k+1}; column k+2 published as it now stands
+            double* yrec1 = pub + (size_t)(k + 1) * S + n + 2;
+            double* crec1 = cbase + (size_t)(k + 2) * ldc;
+            const int c0 = (k + 2 > gw) ? (k + 2 - gw + NW - 1) / NW : 0;
+            for (int cc = c0; cc < cw; ++cc) {
+                const int j = gw + cc * NW;
+                if (j >= n) break;  // wave-uniform
+                double* col = mycols + (size_t)cc * ldc;
+                const double vj = row_bcast<RPL>(v, j), wj = row_bcast<RPL>(w, j);
+                double x[RPL];  // all of the column's loads in flight together, then the arithmetic, then the stores
+#pragma unroll
+                for (int m = M0; m < RPL; ++m) x[m] = col[lane + 64 * m];
+                double acc = 0.0;
+#pragma unroll
+                for (int m = M0; m < RPL; ++m) {
+                    x[m] -= __dadd_rn(__dmul_rn(v[m], wj), __dmul_rn(w[m], vj));
+                    acc += x[m] * vn[m];
+                }
+#pragma unroll
+                for (int m = M0; m < RPL; ++m) col[lane + 64 * m] = x[m];
+                if (more) {
+                    if (j == k + 2) {
+#pragma unroll
+                        for (int m = M0; m < RPL; ++m) st_pub(crec1 + lane + 64 * m, x[m]);
+                    }
+                    acc = wave_sum_dpp(acc);
+                    if (lane == 0) st_pub(yrec1 + j, acc);
+                } else if (j == n - 1) {
+                    const double dl = row_bcast<RPL>(x, n - 1);
+                    if (lane == 0) d_out[n - 1] = dl;
+                }
+            }
+#ifdef NLE_SYTRD_PROBE
+            t_b = wall_clock64(); tp2 += t_b - t_a;
+#endif
+            if (writer) {  // the record the back-transformation and the host read (after this wave's part of the hand-off)
+                double* rec = pub + (size_t)k * S;
+#pragma unroll
+                for (int m = M0; m < RPL; ++m) {
+                    const int i = lane + 64 * m;
+                    if (i > k && i < n) rec[i] = v[m];
+                }
+                if (lane == 0) {
+                    rec[n] = tau;
+                    rec[n + 1] = beta;
+                    d_out[k] = dk;
+                    e_out[k + 1] = beta;
+                }
+            }
+#pragma unroll
+            for (int m = M0; m < RPL; ++m) v[m] = vn[m];
+            tau = tau1;
+            beta = beta1;
+            dk = dk1;
+            }
+    };
+    segments<RPL>(segment);
+    if (dead) return;
     if (writer && lane == 0) e_out[0] = 0.0;
 #ifdef NLE_SYTRD_PROBE
     if (lane == 0 && (gw == 0 || gw == NW - 1)) printf("[sytrd probe] n=%d gw=%d: poll %.1f us (%llu extra rounds), barrier %.1f us, (2)(3) %.1f us, (4) %.1f us (wall clock, 100 MHz)\n", n, gw, tp3 * 0.01, nspin, tp0 * 0.01, tp1 * 0.01, tp2 * 0.01);
