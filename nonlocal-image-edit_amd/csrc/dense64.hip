@@ -554,30 +554,47 @@ __global__ __launch_bounds__(256) void k_sytrd_back(int n, const double* __restr
         const int i = lane + 64 * m;
         z[m] = i < n ? Z[(size_t)c * ldz + i] : 0.0;
     }
-    auto load = [&](int k, double (&dst)[NM], double& tau) {
-        const double* rec = pub + (size_t)k * S;
+    // The reflectors are applied in NM segments of (up to) 64 steps, last rows first: in segment M0 (steps k with
+    // (k + 1) >> 6 == M0) the reflector is zero above row 64 M0, so the row loops start at M0 at compile time (the prefetch of
+    // the next record at M0 - 1: it may belong to the next segment).  No run-time skip, no branch per block (see k_sytrd_wave).
+    double tau = 0.0, taun = 0.0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) v[m] = vn[m] = 0.0;
+    {
+        const double* rec = pub + (size_t)(n - 3) * S;
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             const int i = lane + 64 * m;
-            dst[m] = (i > k && i < n) ? rec[i] : 0.0;
+            v[m] = (i > n - 3 && i < n) ? rec[i] : 0.0;
         }
         tau = rec[n];
-    };
-    double tau, taun = 0.0;
-    load(n - 3, v, tau);
-    for (int k = n - 3; k >= 0; --k) {
-        if (k > 0) load(k - 1, vn, taun);
-        double dot = 0.0;
-#pragma unroll
-        for (int m = 0; m < NM; ++m) dot += v[m] * z[m];
-        dot = wave_sum(dot) * tau;
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            z[m] -= dot * v[m];
-            v[m] = vn[m];
-        }
-        tau = taun;
     }
+    auto segment = [&](auto M0c) __attribute__((always_inline)) {
+        constexpr int M0 = NM - 1 - decltype(M0c)::value;  // descending
+        constexpr int ML = M0 > 0 ? M0 - 1 : 0;
+        const int k_hi = min(n - 3, 64 * M0 + 62), k_lo = max(0, 64 * M0 - 1);
+        for (int k = k_hi; k >= k_lo; --k) {
+            if (k > 0) {
+                const double* rec = pub + (size_t)(k - 1) * S;
+#pragma unroll
+                for (int m = ML; m < NM; ++m) {
+                    const int i = lane + 64 * m;
+                    vn[m] = (i > k - 1 && i < n) ? rec[i] : 0.0;
+                }
+                taun = rec[n];
+            }
+            double dot = 0.0;
+#pragma unroll
+            for (int m = M0; m < NM; ++m) dot += v[m] * z[m];
+            dot = wave_sum(dot) * tau;
+#pragma unroll
+            for (int m = M0; m < NM; ++m) z[m] -= dot * v[m];
+#pragma unroll
+            for (int m = ML; m < NM; ++m) v[m] = vn[m];
+            tau = taun;
+        }
+    };
+    segments<NM>(segment);
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
         const int i = lane + 64 * m;
